@@ -1,0 +1,215 @@
+/*
+ * include/nrc_hpm.h -- C ABI of the MI355X-native NRC-HPM hot path (libnrc_hpm.so).
+ *
+ * Drop-in boundary for the reference's hot path.  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference checkout).  Plain pointers and sizes only;
+ * `stream` arguments are hipStream_t passed as void* (0 = the null stream).  All functions return NRC_OK (0) or
+ * a negative error code and never abort; nrc_last_error() gives the thread-local message (the reference throws
+ * std::runtime_error("SkyRenderer ERROR: ..."), src/Log.cpp:16-20 -- the C++ layer in nrc_hpm.hpp does the same).
+ *
+ * Vulkan/CUDA-interop types of the reference are replaced as follows:
+ *   VkQueue                         -> hipStream_t (stream order replaces both external semaphores)
+ *   cudaExternalSemaphore_t x2      -> dropped
+ *   VkImage / VkImageView           -> device pointer to an RGBA32F row-major framebuffer
+ */
+#ifndef NRC_HPM_H
+#define NRC_HPM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRC_OK 0
+#define NRC_ERR_INVALID (-1)    /* bad argument / unsupported configuration */
+#define NRC_ERR_HIP (-2)        /* a HIP runtime call failed (message holds hipGetErrorString) */
+#define NRC_ERR_STATE (-3)      /* call order violated (e.g. InferAndTrain before Init) */
+
+const char* nrc_last_error(void);
+const char* nrc_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * en::AppConfig (include/engine/AppConfig.hpp:9-66; 17 positional CLI args src/AppConfig.cpp:154-182,
+ * defaults src/main.cu:429-440).  Scene preset values (src/AppConfig.cpp:93-150) are carried explicitly. */
+typedef struct nrc_config {
+    char loss_fn[32];              /* "RelativeL2Luminance" | "L2" | "RelativeL2" */
+    char optimizer[32];            /* "Adam" */
+    float learning_rate;
+    float ema_decay;
+    uint32_t pos_id;               /* 3 Frequency-12 | 1 Identity | 2 TriangleWave-12 (0 HashGrid: not yet) */
+    uint32_t dir_id;               /* 0 OneBlob-4 | 1 Identity | 2 TriangleWave-4 */
+    uint32_t nn_width;             /* 64 */
+    uint32_t nn_depth;             /* n_hidden_layers, 6 */
+    uint32_t log2_infer_batch_size;
+    uint32_t log2_train_batch_size;
+    uint32_t train_batch_count;
+    uint32_t scene_id;
+    float train_ring_buf_size;
+    uint32_t train_spp;
+    uint32_t primary_ray_length;
+    float primary_ray_prob;
+    uint32_t train_ray_length;
+    /* additions of this build */
+    uint32_t seed;                 /* weight-init seed (tiny-cuda-nn default 1337) */
+    uint32_t compat_fix;           /* bit 0: fix quirk Q1 (TRAIN_Y_DIST), bit 1: fix quirk Q2 (trainRayLength); 0 = faithful */
+} nrc_config;
+
+#define NRC_FIX_Q1_TRAIN_Y_DIST 1u
+#define NRC_FIX_Q2_TRAIN_RAY_LEN 2u
+
+/* fills the defaults of src/main.cu:432-439 with the north-star encoding (posID 3, dirID 0) */
+void nrc_config_default(nrc_config* cfg);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * en::NeuralRadianceCache (include/engine/graphics/NeuralRadianceCache.hpp:10-64, src/NeuralRadianceCache.cu) */
+typedef struct nrc_cache nrc_cache_t;
+
+/* NeuralRadianceCache::NeuralRadianceCache(const AppConfig&)  (src/NeuralRadianceCache.cu:11-40) */
+int nrc_cache_create(const nrc_config* cfg, nrc_cache_t** out);
+/* NeuralRadianceCache::Init(inferCount, dCuInferInput, dCuInferOutput, dCuTrainInput, dCuTrainTarget, sem, sem)
+ * (src/NeuralRadianceCache.cu:42-95).  Buffers are caller-owned DEVICE memory: [n][5] / [n][3] fp32 AoS. */
+int nrc_cache_init(nrc_cache_t* c, uint32_t infer_count, float* d_infer_input, float* d_infer_output,
+                   float* d_train_input, float* d_train_target, void* stream);
+/* NeuralRadianceCache::InferAndTrain(const uint32_t* inferFilter, bool train) (src/NeuralRadianceCache.cu:97-103).
+ * infer_filter: HOST array, one entry per inference batch, >0 => run; NULL => run every batch. */
+int nrc_cache_infer_and_train(nrc_cache_t* c, const uint32_t* infer_filter, int train);
+/* NeuralRadianceCache::Destroy (src/NeuralRadianceCache.cu:105-107); frees the object */
+int nrc_cache_destroy(nrc_cache_t* c);
+/* GetLoss / Get{Infer,Train}Batch{Count,Size} (src/NeuralRadianceCache.cu:109-132).  get_loss synchronises the stream. */
+float nrc_cache_get_loss(nrc_cache_t* c);
+size_t nrc_cache_get_infer_batch_count(nrc_cache_t* c);
+size_t nrc_cache_get_train_batch_count(nrc_cache_t* c);
+uint32_t nrc_cache_get_infer_batch_size(nrc_cache_t* c);
+uint32_t nrc_cache_get_train_batch_size(nrc_cache_t* c);
+
+/* --- finer-grained steps of the same path (what InferAndTrain is made of; used by the multi-GPU driver) --- */
+/* network->inference on an arbitrary device buffer (src/NeuralRadianceCache.cu:142); use_ema=1 is what Inference does */
+int nrc_cache_infer(nrc_cache_t* c, const float* d_input, float* d_output, uint32_t n, int use_ema);
+/* trainer->training_step minus the optimizer (src/NeuralRadianceCache.cu:153): forward (non-EMA weights) + loss + backward.
+ * n_norm: batch size the loss normaliser uses (= n on one GPU, the global batch when the batch is sharded). */
+int nrc_cache_backward(nrc_cache_t* c, const float* d_input, const float* d_target, uint32_t n, uint32_t n_norm);
+/* optimizer step (EMA{Adam}) from the gradient vector */
+int nrc_cache_optimizer_step(nrc_cache_t* c);
+/* device pointer / length of the fp32 gradient vector (sum over the local batch, times loss_scale 128) and of the
+ * 2-float {loss, unused} cell: the multi-GPU driver all-reduces these between backward and optimizer_step */
+float* nrc_cache_grad_ptr(nrc_cache_t* c);
+uint32_t nrc_cache_param_count(nrc_cache_t* c);
+float* nrc_cache_loss_ptr(nrc_cache_t* c);
+/* multi-GPU: the loss normaliser of InferAndTrain's train batches becomes 3 * trainBatchSize * factor (factor = world size) */
+int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor);
+/* move the cache's work to another hipStream_t (Init binds the first one) */
+int nrc_cache_set_stream(nrc_cache_t* c, void* stream);
+/* hook called by InferAndTrain between backward and the optimizer of every train batch (NULL = none) */
+typedef void (*nrc_grad_hook)(void* user, float* d_grad, uint32_t n_params, float* d_loss);
+int nrc_cache_set_grad_hook(nrc_cache_t* c, nrc_grad_hook hook, void* user);
+/* checkpointing: which = 0 master weights, 1 EMA weights, 2 Adam m, 3 Adam v, 4 gradient (host fp32 arrays) */
+int nrc_cache_get_params(nrc_cache_t* c, int which, float* host_out);
+int nrc_cache_set_params(nrc_cache_t* c, int which, const float* host_in);
+int nrc_cache_get_step(nrc_cache_t* c, uint32_t* step);
+int nrc_cache_set_step(nrc_cache_t* c, uint32_t step);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Scene inputs: the values the reference uploads as UBOs / textures.  HOST pointers; copied
+ * to the device at renderer creation. */
+typedef struct nrc_scene {
+    const uint8_t* density;        /* R8 UNORM voxels, index i + nx*(j + ny*k)  (src/Texture3D.cpp:99-111, one channel) */
+    uint32_t nx, ny, nz;
+    float size[3];                 /* skySize; all zero => normalize(extent)*107.5 (src/NrcHpmRenderer.cu:910-912) */
+    float density_factor;          /* VolumeData density (scene preset) */
+    float g;                       /* 0.8 (src/HpmScene.cpp:45) */
+    float dir_light_dir[3];        /* src/DirLight.cpp:5-14 */
+    float dir_light_strength;
+    float point_light_pos[3];
+    float point_light_strength;
+    float point_light_color[3];
+    float env_strength;
+    const float* env;              /* RGBA32F row-major env_h x env_w (src/HdrEnvMap.cpp), LINEAR clamp-to-edge */
+    uint32_t env_w, env_h;
+} nrc_scene;
+
+/* CameraMatrices.invProjView + camera.pos (include/engine/graphics/Camera.hpp:11-16, nrc-descriptors.glsl:1-11) */
+typedef struct nrc_camera {
+    float inv_proj_view[16];       /* column-major (glm) */
+    float pos[3];
+} nrc_camera;
+
+/* Pixel-tile shard of a frame (new: SURVEY.md section 8e).  This instance renders the columns
+ * x = x_offset + i*x_stride (i = 0..width-1) of a global_w x global_h frame; width passed to create is the LOCAL
+ * column count.  {0,1,W,H} = whole frame. */
+typedef struct nrc_tile {
+    uint32_t x_offset, x_stride, global_w, global_h;
+} nrc_tile;
+
+/* ---------------------------------------------------------------------------------------------------------
+ * en::NrcHpmRenderer (include/engine/graphics/renderer/NrcHpmRenderer.hpp:13-41, src/NrcHpmRenderer.cu) */
+typedef struct nrc_renderer nrc_renderer_t;
+
+/* NrcHpmRenderer(width, height, blend, camera, appConfig, hpmScene, nrc) (src/NrcHpmRenderer.cu:212-297).
+ * The renderer allocates the four NRC I/O buffers and calls nrc_cache_init (as the reference ctor does, :259-266).
+ * tile may be NULL. */
+int nrc_renderer_create(uint32_t width, uint32_t height, int blend, const nrc_camera* camera, const nrc_config* cfg,
+                        const nrc_scene* scene, nrc_cache_t* cache, const nrc_tile* tile, void* stream,
+                        nrc_renderer_t** out);
+/* NrcHpmRenderer::Render(VkQueue, bool train) (src/NrcHpmRenderer.cu:299-353) */
+int nrc_renderer_render(nrc_renderer_t* r, int train);
+/* NrcHpmRenderer::SetCamera / SetBlend (src/NrcHpmRenderer.cu:561-610) */
+int nrc_renderer_set_camera(nrc_renderer_t* r, const nrc_camera* camera);
+int nrc_renderer_set_blend(nrc_renderer_t* r, int blend);
+/* UniformData.showNrc (include/engine/graphics/renderer/NrcHpmRenderer.hpp:70-75) */
+int nrc_renderer_set_show_nrc(nrc_renderer_t* r, int show);
+/* UniformData.random: by default drawn per frame from std::mt19937(seed) (the reference uses glm::linearRand,
+ * src/NrcHpmRenderer.cu:308); this pins the next frame's value (parity tests) */
+int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float random4[4]);
+/* GetImage()/GetImageView() -> device pointer, RGBA32F, row-major height x width (local columns) */
+const float* nrc_renderer_framebuffer(nrc_renderer_t* r);
+/* ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493): scan-line EXR, FLOAT RGBA */
+int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
+/* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be
+ * NULL or float[8] = {clear, gen_rays, prep_infer(0: fused), filter(0), prep_train, nrc(infer+train), render, total} */
+float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
+/* NrcHpmRenderer::Destroy */
+int nrc_renderer_destroy(nrc_renderer_t* r);
+/* intermediate device buffers (tests / multi-GPU): 0 primary colour+throughput [h][w][4], 1 primary info [h][w],
+ * 2 nrc ray origin [h][w][4], 3 nrc ray dir [h][w][4], 4 infer input [w*h][5], 5 infer output [w*h][3],
+ * 6 train input [T][5], 7 train target [T][3], 8 train ring {head, tail, RayInfo[ring]} */
+void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes);
+/* density look-ups executed by gen_rays (measurement: algorithmic bytes of the integrator).
+ * Returns the count accumulated so far in *out (may be NULL), then enables/disables + zeroes the device counter. */
+int nrc_renderer_count_fetches(nrc_renderer_t* r, int enable, unsigned long long* out);
+/* train grid chosen by CalcTrainSubset (src/NrcHpmRenderer.cu:612-642): {TW, TH, xDist, yDist, ringSize} */
+int nrc_renderer_train_grid(nrc_renderer_t* r, uint32_t out5[5]);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * en::McHpmRenderer (include/engine/graphics/renderer/McHpmRenderer.hpp:10-31, src/McHpmRenderer.cpp) */
+typedef struct nrc_mc_renderer nrc_mc_renderer_t;
+
+/* McHpmRenderer(width, height, pathLength, blend, camera, scene) (src/McHpmRenderer.cpp:81-119) */
+int nrc_mc_renderer_create(uint32_t width, uint32_t height, uint32_t path_length, int blend, const nrc_camera* camera,
+                           const nrc_scene* scene, const nrc_tile* tile, void* stream, nrc_mc_renderer_t** out);
+/* McHpmRenderer::Render(VkQueue) (src/McHpmRenderer.cpp:121-151) */
+int nrc_mc_renderer_render(nrc_mc_renderer_t* r);
+int nrc_mc_renderer_set_camera(nrc_mc_renderer_t* r, const nrc_camera* camera);
+int nrc_mc_renderer_set_blend(nrc_mc_renderer_t* r, int blend);
+int nrc_mc_renderer_set_frame_random(nrc_mc_renderer_t* r, const float random4[4]);
+const float* nrc_mc_renderer_framebuffer(nrc_mc_renderer_t* r);   /* RGBA32F, alpha = blended didScatter */
+int nrc_mc_renderer_export_exr(nrc_mc_renderer_t* r, const char* path);
+float nrc_mc_renderer_frame_time_ms(nrc_mc_renderer_t* r);
+int nrc_mc_renderer_count_fetches(nrc_mc_renderer_t* r, int enable, unsigned long long* out);
+int nrc_mc_renderer_destroy(nrc_mc_renderer_t* r);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Reference::Result metrics (include/engine/graphics/Reference.hpp:17-29, data/shader/ref/cmp1,norm,cmp2.comp):
+ * device RGBA32F images of w*h pixels; result5 (host) = {mse, refMean, ownMean, ownVar, validPixelCount} */
+int nrc_compare_images(const float* d_ref_rgba, const float* d_own_rgba, uint32_t w, uint32_t h, void* stream,
+                       float result5[5]);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Test hooks (bit-parity of the math spec and RNG against the oracle; device pointers) */
+int nrc_test_math(int fn, const float* d_a, const float* d_b, uint32_t n, float* d_out, float* d_out2, void* stream);
+int nrc_test_rng(float u, float v, const float frame_random[4], uint32_t n, float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,514 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI of include/nrc_hpm.h.
+
+Same class / method names and argument meaning as the reference (so parity tests read like reference call sites):
+  AppConfig             include/engine/AppConfig.hpp:9-66, src/AppConfig.cpp:154-182 (17 positional CLI args)
+  NeuralRadianceCache   include/engine/graphics/NeuralRadianceCache.hpp:13-32
+  NrcHpmRenderer        include/engine/graphics/renderer/NrcHpmRenderer.hpp:16-41
+  McHpmRenderer         include/engine/graphics/renderer/McHpmRenderer.hpp:16-31
+Errors raise RuntimeError("SkyRenderer ERROR: ...") like Log::Error(msg, true) (src/Log.cpp:16-20).
+
+PyTorch is plumbing only (device memory, current stream, torch.distributed); all arithmetic runs in libnrc_hpm.so.
+There is no CPU fallback: loading fails loudly if the HIP library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnrc_hpm.so")
+
+NRC_FIX_Q1_TRAIN_Y_DIST = 1
+NRC_FIX_Q2_TRAIN_RAY_LEN = 2
+
+
+class NrcConfig(C.Structure):
+    _fields_ = [
+        ("loss_fn", C.c_char * 32), ("optimizer", C.c_char * 32),
+        ("learning_rate", C.c_float), ("ema_decay", C.c_float),
+        ("pos_id", C.c_uint32), ("dir_id", C.c_uint32), ("nn_width", C.c_uint32), ("nn_depth", C.c_uint32),
+        ("log2_infer_batch_size", C.c_uint32), ("log2_train_batch_size", C.c_uint32), ("train_batch_count", C.c_uint32),
+        ("scene_id", C.c_uint32), ("train_ring_buf_size", C.c_float), ("train_spp", C.c_uint32),
+        ("primary_ray_length", C.c_uint32), ("primary_ray_prob", C.c_float), ("train_ray_length", C.c_uint32),
+        ("seed", C.c_uint32), ("compat_fix", C.c_uint32),
+    ]
+
+
+class NrcScene(C.Structure):
+    _fields_ = [
+        ("density", C.c_void_p), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32),
+        ("size", C.c_float * 3), ("density_factor", C.c_float), ("g", C.c_float),
+        ("dir_light_dir", C.c_float * 3), ("dir_light_strength", C.c_float),
+        ("point_light_pos", C.c_float * 3), ("point_light_strength", C.c_float),
+        ("point_light_color", C.c_float * 3), ("env_strength", C.c_float),
+        ("env", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32),
+    ]
+
+
+class NrcCamera(C.Structure):
+    _fields_ = [("inv_proj_view", C.c_float * 16), ("pos", C.c_float * 3)]
+
+
+class NrcTile(C.Structure):
+    _fields_ = [("x_offset", C.c_uint32), ("x_stride", C.c_uint32), ("global_w", C.c_uint32), ("global_h", C.c_uint32)]
+
+
+GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)
+
+# every symbol include/nrc_hpm.h declares (tests/test_abi.py checks the built library exports all of them)
+ABI_SYMBOLS = [
+    "nrc_last_error", "nrc_version", "nrc_config_default",
+    "nrc_cache_create", "nrc_cache_init", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
+    "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
+    "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
+    "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
+    "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
+    "nrc_cache_get_step", "nrc_cache_set_step",
+    "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
+    "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_export_exr",
+    "nrc_renderer_frame_time_ms", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
+    "nrc_renderer_train_grid",
+    "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
+    "nrc_mc_renderer_set_frame_random", "nrc_mc_renderer_framebuffer", "nrc_mc_renderer_export_exr",
+    "nrc_mc_renderer_frame_time_ms", "nrc_mc_renderer_count_fetches", "nrc_mc_renderer_destroy",
+    "nrc_compare_images", "nrc_test_math", "nrc_test_rng",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libnrc_hpm.so (built by __graft_entry__.build() / csrc/Makefile).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("SkyRenderer ERROR: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the NRC path)" % LIB_PATH)
+    # ONE HIP runtime per process: torch bundles its own libamdhip64.so (soname libamdhip64.so.7).  Import torch first so
+    # that libnrc_hpm.so's NEEDED libamdhip64.so.7 binds to the copy torch already loaded -- streams and device pointers
+    # handed over from torch are only meaningful inside the same runtime instance.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    L.nrc_last_error.restype = C.c_char_p
+    L.nrc_version.restype = C.c_char_p
+    L.nrc_cache_get_loss.restype = C.c_float
+    L.nrc_cache_get_infer_batch_count.restype = C.c_size_t
+    L.nrc_cache_get_train_batch_count.restype = C.c_size_t
+    L.nrc_cache_get_infer_batch_size.restype = C.c_uint32
+    L.nrc_cache_get_train_batch_size.restype = C.c_uint32
+    L.nrc_cache_grad_ptr.restype = C.c_void_p
+    L.nrc_cache_loss_ptr.restype = C.c_void_p
+    L.nrc_cache_param_count.restype = C.c_uint32
+    L.nrc_renderer_framebuffer.restype = C.c_void_p
+    L.nrc_renderer_buffer.restype = C.c_void_p
+    L.nrc_renderer_frame_time_ms.restype = C.c_float
+    L.nrc_mc_renderer_framebuffer.restype = C.c_void_p
+    L.nrc_mc_renderer_frame_time_ms.restype = C.c_float
+    for name in ("nrc_cache_get_loss", "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count",
+                 "nrc_cache_get_infer_batch_size", "nrc_cache_get_train_batch_size", "nrc_cache_grad_ptr",
+                 "nrc_cache_loss_ptr", "nrc_cache_param_count", "nrc_renderer_framebuffer", "nrc_mc_renderer_framebuffer",
+                 "nrc_mc_renderer_frame_time_ms"):
+        getattr(L, name).argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != 0:
+        raise RuntimeError(load_library().nrc_last_error().decode() or "SkyRenderer ERROR: status %d" % status)
+
+
+def _vp(x):
+    return C.c_void_p(int(x) if x is not None else 0)
+
+
+def _dev_ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+    return C.c_void_p(int(stream))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class AppConfig:
+    """en::AppConfig.  AppConfig(argv) takes the reference's 18-entry argv (program name + 17 args,
+    src/AppConfig.cpp:154-182); AppConfig() gives the defaults of src/main.cu:432-439 with the north-star
+    encoding (posID 3 Frequency, dirID 0 OneBlob)."""
+
+    def __init__(self, argv=None, **overrides):
+        c = NrcConfig()
+        load_library().nrc_config_default(C.byref(c))
+        if argv is not None:
+            if len(argv) != 18:
+                raise RuntimeError("SkyRenderer ERROR: Argument count does not match requirements for AppConfig")
+            a = [str(x) for x in argv[1:]]
+            c.loss_fn, c.optimizer = a[0].encode(), a[1].encode()
+            c.learning_rate, c.ema_decay = float(a[2]), float(a[3])
+            c.pos_id, c.dir_id = int(a[4]), int(a[5])
+            c.nn_width, c.nn_depth = int(a[6]), int(a[7])
+            c.log2_infer_batch_size, c.log2_train_batch_size, c.train_batch_count = int(a[8]), int(a[9]), int(a[10])
+            c.scene_id = int(a[11])
+            c.train_ring_buf_size, c.train_spp = float(a[12]), int(a[13])
+            c.primary_ray_length, c.primary_ray_prob, c.train_ray_length = int(a[14]), float(a[15]), int(a[16])
+        for k, v in overrides.items():
+            if not hasattr(c, k):
+                raise AttributeError(k)
+            setattr(c, k, v.encode() if isinstance(v, str) else v)
+        self.c = c
+
+    def __getattr__(self, k):
+        v = getattr(self.__dict__["c"], k)
+        return v.decode() if isinstance(v, bytes) else v
+
+    def GetName(self):      # src/AppConfig.cpp:184-205 (std::to_string formatting)
+        c = self.c
+        f = "%.6f"
+        parts = [c.loss_fn.decode(), c.optimizer.decode(), f % c.learning_rate, f % c.ema_decay, c.pos_id, c.dir_id,
+                 c.nn_width, c.nn_depth, c.log2_infer_batch_size, c.log2_train_batch_size, c.train_batch_count,
+                 c.scene_id, f % c.train_ring_buf_size, c.train_spp, c.primary_ray_length, f % c.primary_ray_prob,
+                 c.train_ray_length]
+        return "_".join(str(p) for p in parts)
+
+
+def make_c_scene(scene):
+    """dict from nrc_hpm_renderer_amd.scene.make_scene -> nrc_scene (host pointers; keeps the arrays alive)."""
+    s = NrcScene()
+    dens = np.ascontiguousarray(scene["density"], np.uint8)
+    env = np.ascontiguousarray(scene["env"], np.float32)
+    s.density = dens.ctypes.data
+    s.nx, s.ny, s.nz = scene["dims"]
+    s.size[:] = [float(x) for x in scene["size"]]
+    s.density_factor = scene["density_factor"]
+    s.g = scene["g"]
+    s.dir_light_dir[:] = [float(x) for x in scene["dir_light_dir"]]
+    s.dir_light_strength = scene["dir_light_strength"]
+    s.point_light_pos[:] = [float(x) for x in scene["point_light_pos"]]
+    s.point_light_strength = scene["point_light_strength"]
+    s.point_light_color[:] = [float(x) for x in scene["point_light_color"]]
+    s.env_strength = scene["env_strength"]
+    s.env = env.ctypes.data
+    s.env_h, s.env_w = env.shape[0], env.shape[1]
+    s._keep = (dens, env)
+    return s
+
+
+def make_c_camera(cam):
+    c = NrcCamera()
+    c.inv_proj_view[:] = [float(x) for x in np.asarray(cam["inv_proj_view"], np.float32).reshape(16)]
+    c.pos[:] = [float(x) for x in cam["pos"]]
+    return c
+
+
+def _wrap_device(ptr, nbytes, dtype, shape):
+    """torch view over a device pointer owned by the library (no copy)."""
+    import torch
+
+    class _Arr:
+        pass
+
+    a = _Arr()
+    a.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    t = torch.as_tensor(a, device="cuda")
+    return t.view(dtype).view(*shape)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class NeuralRadianceCache:
+    """en::NeuralRadianceCache (src/NeuralRadianceCache.cu)."""
+    MASTER, EMA, ADAM_M, ADAM_V, GRAD = range(5)
+
+    def __init__(self, appConfig):
+        self.L = load_library()
+        self.cfg = appConfig
+        h = C.c_void_p()
+        _check(self.L.nrc_cache_create(C.byref(appConfig.c), C.byref(h)))
+        self.h = h
+        self._hook_keep = None
+        self._bufs = None
+
+    def Init(self, inferCount, dInferInput, dInferOutput, dTrainInput, dTrainTarget, stream=None):
+        """Buffers: torch CUDA float32 tensors [n,5] / [n,3] (caller-owned, as in the reference)."""
+        self._bufs = (dInferInput, dInferOutput, dTrainInput, dTrainTarget)
+        _check(self.L.nrc_cache_init(self.h, C.c_uint32(inferCount), _dev_ptr(dInferInput), _dev_ptr(dInferOutput),
+                                     _dev_ptr(dTrainInput), _dev_ptr(dTrainTarget), _stream_ptr(stream)))
+
+    def InferAndTrain(self, inferFilter, train):
+        f = None
+        if inferFilter is not None:
+            f = np.ascontiguousarray(inferFilter, np.uint32)
+        _check(self.L.nrc_cache_infer_and_train(self.h, f.ctypes.data_as(C.c_void_p) if f is not None else None,
+                                                C.c_int(int(bool(train)))))
+
+    def Destroy(self):
+        if self.h:
+            _check(self.L.nrc_cache_destroy(self.h))
+            self.h = None
+
+    def GetLoss(self):
+        return float(self.L.nrc_cache_get_loss(self.h))
+
+    def GetInferBatchCount(self):
+        return int(self.L.nrc_cache_get_infer_batch_count(self.h))
+
+    def GetTrainBatchCount(self):
+        return int(self.L.nrc_cache_get_train_batch_count(self.h))
+
+    def GetInferBatchSize(self):
+        return int(self.L.nrc_cache_get_infer_batch_size(self.h))
+
+    def GetTrainBatchSize(self):
+        return int(self.L.nrc_cache_get_train_batch_size(self.h))
+
+    # ---- finer-grained steps (multi-GPU driver, tests) ----
+    def SetStream(self, stream=None):
+        _check(self.L.nrc_cache_set_stream(self.h, _stream_ptr(stream)))
+
+    def Infer(self, dInput, dOutput, useEma=True):
+        _check(self.L.nrc_cache_infer(self.h, _dev_ptr(dInput), _dev_ptr(dOutput), C.c_uint32(dInput.shape[0]),
+                                      C.c_int(int(useEma))))
+
+    def Backward(self, dInput, dTarget, nNorm=0):
+        _check(self.L.nrc_cache_backward(self.h, _dev_ptr(dInput), _dev_ptr(dTarget), C.c_uint32(dInput.shape[0]),
+                                         C.c_uint32(nNorm)))
+
+    def OptimizerStep(self):
+        _check(self.L.nrc_cache_optimizer_step(self.h))
+
+    def ParamCount(self):
+        return int(self.L.nrc_cache_param_count(self.h))
+
+    def GradTensor(self):
+        import torch
+        n = self.ParamCount()
+        return _wrap_device(self.L.nrc_cache_grad_ptr(self.h), n * 4, torch.float32, (n,))
+
+    def LossTensor(self):
+        import torch
+        return _wrap_device(self.L.nrc_cache_loss_ptr(self.h), 8, torch.float32, (2,))
+
+    def SetLossNormFactor(self, factor):
+        _check(self.L.nrc_cache_set_loss_norm_factor(self.h, C.c_uint32(factor)))
+
+    def SetGradHook(self, fn):
+        """fn(grad_tensor, loss_tensor) is called between backward and the optimizer of every train batch."""
+        if fn is None:
+            self._hook_keep = None
+            _check(self.L.nrc_cache_set_grad_hook(self.h, None, None))
+            return
+        g, lo = self.GradTensor(), self.LossTensor()
+
+        def tramp(_user, _g, _n, _l):
+            fn(g, lo)
+
+        self._hook_keep = GRAD_HOOK(tramp)
+        _check(self.L.nrc_cache_set_grad_hook(self.h, self._hook_keep, None))
+
+    def GetParams(self, which=0):
+        out = np.zeros(self.ParamCount(), np.float32)
+        _check(self.L.nrc_cache_get_params(self.h, C.c_int(which), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def SetParams(self, which, values):
+        v = np.ascontiguousarray(values, np.float32)
+        assert v.size == self.ParamCount()
+        _check(self.L.nrc_cache_set_params(self.h, C.c_int(which), v.ctypes.data_as(C.c_void_p)))
+
+    def GetStep(self):
+        s = C.c_uint32(0)
+        _check(self.L.nrc_cache_get_step(self.h, C.byref(s)))
+        return s.value
+
+    def SetStep(self, step):
+        _check(self.L.nrc_cache_set_step(self.h, C.c_uint32(step)))
+
+    def state_dict(self):
+        """checkpoint (the reference has none): fp32 master/EMA weights + Adam state + step"""
+        return dict(step=self.GetStep(), **{k: self.GetParams(i) for i, k in enumerate(("w", "ema", "m", "v"))})
+
+    def load_state_dict(self, sd):
+        for i, k in enumerate(("w", "ema", "m", "v")):
+            self.SetParams(i, sd[k])
+        self.SetStep(int(sd["step"]))
+
+    def __del__(self):
+        try:
+            self.Destroy()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class NrcHpmRenderer:
+    """en::NrcHpmRenderer (src/NrcHpmRenderer.cu).  `queue` arguments of the reference become the HIP stream."""
+    BUF = dict(primary=0, info=1, origin=2, dir=3, infer_input=4, infer_output=5, train_input=6, train_target=7, ring=8)
+
+    def __init__(self, width, height, blend, camera, appConfig, hpmScene, nrc, tile=None, stream=None):
+        self.L = load_library()
+        self.width, self.height = width, height
+        self.nrc = nrc
+        self._scene = make_c_scene(hpmScene)
+        cam = make_c_camera(camera)
+        t = None
+        if tile is not None:
+            t = NrcTile(*[int(x) for x in tile])
+        h = C.c_void_p()
+        _check(self.L.nrc_renderer_create(C.c_uint32(width), C.c_uint32(height), C.c_int(int(blend)), C.byref(cam),
+                                          C.byref(appConfig.c), C.byref(self._scene), nrc.h,
+                                          C.byref(t) if t is not None else None, _stream_ptr(stream), C.byref(h)))
+        self.h = h
+
+    def Render(self, queue=None, train=False):
+        _check(self.L.nrc_renderer_render(self.h, C.c_int(int(bool(train)))))
+
+    def SetCamera(self, queue, camera):
+        cam = make_c_camera(camera)
+        _check(self.L.nrc_renderer_set_camera(self.h, C.byref(cam)))
+
+    def SetBlend(self, blend):
+        _check(self.L.nrc_renderer_set_blend(self.h, C.c_int(int(blend))))
+
+    def SetShowNrc(self, show):
+        _check(self.L.nrc_renderer_set_show_nrc(self.h, C.c_int(int(show))))
+
+    def SetFrameRandom(self, r4):
+        r = (C.c_float * 4)(*[float(x) for x in r4])
+        _check(self.L.nrc_renderer_set_frame_random(self.h, r))
+
+    def ExportOutputImageToFile(self, queue, filePath):
+        _check(self.L.nrc_renderer_export_exr(self.h, filePath.encode()))
+
+    def GetFrameTimeMS(self):
+        return float(self.L.nrc_renderer_frame_time_ms(self.h, None))
+
+    def EvaluateTimestampQueries(self):
+        st = (C.c_float * 8)()
+        self.L.nrc_renderer_frame_time_ms(self.h, st)
+        names = ("clear", "gen_rays", "prep_infer", "filter", "prep_train", "nrc", "render", "total")
+        return dict(zip(names, [float(x) for x in st]))
+
+    def GetImage(self):
+        """RGBA32F framebuffer as a torch CUDA tensor view [height, width, 4]."""
+        import torch
+        p = self.L.nrc_renderer_framebuffer(self.h)
+        return _wrap_device(p, self.width * self.height * 16, torch.float32, (self.height, self.width, 4))
+
+    def Buffer(self, name):
+        import torch
+        nbytes = C.c_size_t(0)
+        p = self.L.nrc_renderer_buffer(self.h, C.c_int(self.BUF[name]), C.byref(nbytes))
+        if not p:
+            _check(-1)
+        if name == "ring":
+            return _wrap_device(p, nbytes.value, torch.int32, (nbytes.value // 4,))
+        inner = {"primary": 4, "info": 1, "origin": 4, "dir": 4, "infer_input": 5, "infer_output": 3,
+                 "train_input": 5, "train_target": 3}[name]
+        return _wrap_device(p, nbytes.value, torch.float32, (nbytes.value // (4 * inner), inner))
+
+    def TrainGrid(self):
+        o = (C.c_uint32 * 5)()
+        _check(self.L.nrc_renderer_train_grid(self.h, o))
+        return dict(tw=o[0], th=o[1], x_dist=o[2], y_dist=o[3], ring_size=o[4])
+
+    def CountFetches(self, enable=True):
+        v = C.c_ulonglong(0)
+        _check(self.L.nrc_renderer_count_fetches(self.h, C.c_int(int(enable)), C.byref(v)))
+        return v.value
+
+    def Destroy(self):
+        if self.h:
+            _check(self.L.nrc_renderer_destroy(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.Destroy()
+        except Exception:
+            pass
+
+
+class McHpmRenderer:
+    """en::McHpmRenderer (src/McHpmRenderer.cpp)."""
+
+    def __init__(self, width, height, pathLength, blend, camera, scene, tile=None, stream=None):
+        self.L = load_library()
+        self.width, self.height = width, height
+        self._scene = make_c_scene(scene)
+        cam = make_c_camera(camera)
+        t = NrcTile(*[int(x) for x in tile]) if tile is not None else None
+        h = C.c_void_p()
+        _check(self.L.nrc_mc_renderer_create(C.c_uint32(width), C.c_uint32(height), C.c_uint32(pathLength),
+                                             C.c_int(int(blend)), C.byref(cam), C.byref(self._scene),
+                                             C.byref(t) if t is not None else None, _stream_ptr(stream), C.byref(h)))
+        self.h = h
+
+    def Render(self, queue=None):
+        _check(self.L.nrc_mc_renderer_render(self.h))
+
+    def SetCamera(self, queue, camera):
+        cam = make_c_camera(camera)
+        _check(self.L.nrc_mc_renderer_set_camera(self.h, C.byref(cam)))
+
+    def SetBlend(self, blend):
+        _check(self.L.nrc_mc_renderer_set_blend(self.h, C.c_int(int(blend))))
+
+    def SetFrameRandom(self, r4):
+        r = (C.c_float * 4)(*[float(x) for x in r4])
+        _check(self.L.nrc_mc_renderer_set_frame_random(self.h, r))
+
+    def ExportOutputImageToFile(self, queue, filePath):
+        _check(self.L.nrc_mc_renderer_export_exr(self.h, filePath.encode()))
+
+    def GetFrameTimeMS(self):
+        return float(self.L.nrc_mc_renderer_frame_time_ms(self.h))
+
+    def GetImage(self):
+        import torch
+        p = self.L.nrc_mc_renderer_framebuffer(self.h)
+        return _wrap_device(p, self.width * self.height * 16, torch.float32, (self.height, self.width, 4))
+
+    def CountFetches(self, enable=True):
+        v = C.c_ulonglong(0)
+        _check(self.L.nrc_mc_renderer_count_fetches(self.h, C.c_int(int(enable)), C.byref(v)))
+        return v.value
+
+    def Destroy(self):
+        if self.h:
+            _check(self.L.nrc_mc_renderer_destroy(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.Destroy()
+        except Exception:
+            pass
+
+
+def CompareImages(ref, own, stream=None):
+    """Reference::Result (include/engine/graphics/Reference.hpp:17-29): torch CUDA RGBA32F [h,w,4] images."""
+    r = (C.c_float * 5)()
+    h, w = ref.shape[0], ref.shape[1]
+    _check(load_library().nrc_compare_images(_dev_ptr(ref), _dev_ptr(own), C.c_uint32(w), C.c_uint32(h),
+                                             _stream_ptr(stream), r))
+    return dict(mse=r[0], ref_mean=r[1], own_mean=r[2], own_var=r[3], valid=r[4])
+
+
+def test_math(fn, a, b=None):
+    """bit-parity hook: evaluates math-spec function `fn` on the device (torch CUDA float tensors)."""
+    import torch
+    out, out2 = torch.empty_like(a), torch.empty_like(a)
+    _check(load_library().nrc_test_math(C.c_int(fn), _dev_ptr(a), _dev_ptr(b) if b is not None else None,
+                                        C.c_uint32(a.numel()), _dev_ptr(out), _dev_ptr(out2), _stream_ptr(None)))
+    return out, out2
+
+
+def test_rng(u, v, frame_random, n):
+    import torch
+    out = torch.zeros(n + 1, device="cuda")
+    fr = (C.c_float * 4)(*[float(x) for x in frame_random])
+    _check(load_library().nrc_test_rng(C.c_float(u), C.c_float(v), fr, C.c_uint32(n), _dev_ptr(out), _stream_ptr(None)))
+    return out

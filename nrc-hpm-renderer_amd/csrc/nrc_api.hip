@@ -1,0 +1,733 @@
+// nrc_api.hip -- host side of libnrc_hpm: the reference's NeuralRadianceCache / NrcHpmRenderer / McHpmRenderer
+// behaviour over one HIP stream, exported through the C ABI of include/nrc_hpm.h.
+//
+//   nrc::Cache       <- en::NeuralRadianceCache   (src/NeuralRadianceCache.cu)
+//   nrc::Renderer    <- en::NrcHpmRenderer        (src/NrcHpmRenderer.cu:212-353,561-642,823-881,908-1061)
+//   nrc::McRenderer  <- en::McHpmRenderer         (src/McHpmRenderer.cpp:81-151,432-449)
+// One instance per GPU and stream; no hidden globals (SURVEY.md 8b "Threading").
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "nrc_integrator.hpp"
+#include "nrc_mlp.hpp"
+
+namespace nrc {
+
+static thread_local std::string g_last_error;
+
+// ---------------------------------------------------------------------------------------------------- Cache
+class Cache {
+public:
+    explicit Cache(const nrc_config& cfg)
+        : cfg_(cfg),
+          infer_batch_size_(2u << (cfg.log2_infer_batch_size - 1)),      // src/NeuralRadianceCache.cu:12-14
+          train_batch_size_(2u << (cfg.log2_train_batch_size - 1)),
+          train_batch_count_(cfg.train_batch_count),
+          mlp_(new Mlp(cfg))
+    {
+        if (cfg.log2_infer_batch_size == 0 || cfg.log2_infer_batch_size > 30 || cfg.log2_train_batch_size < 5 ||
+            cfg.log2_train_batch_size > 30)
+            fail("log2 batch sizes out of range");
+    }
+
+    void init(uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_ttarget, hipStream_t s)
+    {
+        if (infer_count % 16 != 0) fail("NRC requires inferCount to be a multiple of 16");   // :52
+        infer_count_ = infer_count;
+        d_infer_in_ = d_in; d_infer_out_ = d_out; d_train_in_ = d_tin; d_train_target_ = d_ttarget;
+        stream_ = s;
+        // batch slicing, :67-92
+        infer_batches_.clear();
+        const uint32_t full = infer_count / infer_batch_size_;
+        for (uint32_t i = 0; i < full; i++) infer_batches_.push_back({i * infer_batch_size_, infer_batch_size_});
+        const uint32_t last = infer_count - full * infer_batch_size_;
+        if (last > 0) infer_batches_.push_back({full * infer_batch_size_, last});
+        initialised_ = true;
+    }
+
+    void infer_and_train(const uint32_t* filter, bool train)       // :97-103
+    {
+        if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
+        for (size_t i = 0; i < infer_batches_.size(); i++) {       // Inference, :134-145
+            if (filter != nullptr && filter[i] == 0) continue;
+            const auto& b = infer_batches_[i];
+            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, stream_);
+        }
+        if (train) {                                               // Train, :147-156
+            for (uint32_t b = 0; b < train_batch_count_; b++) {
+                const size_t o = (size_t)b * train_batch_size_;
+                mlp_->backward(d_train_in_ + o * 5, d_train_target_ + o * 3, train_batch_size_,
+                               train_batch_size_ * loss_norm_factor_, stream_);
+                if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr());
+                mlp_->optimizer_step(stream_);
+            }
+            loss_dirty_ = true;
+        }
+    }
+
+    float get_loss()
+    {
+        if (loss_dirty_) {
+            NRC_HIP(hipMemcpyAsync(&loss_, mlp_->loss_ptr(), sizeof(float), hipMemcpyDeviceToHost, stream_));
+            NRC_HIP(hipStreamSynchronize(stream_));
+            loss_dirty_ = false;
+        }
+        return loss_;
+    }
+
+    Mlp& mlp() { return *mlp_; }
+    hipStream_t stream() const { return stream_; }
+    void set_stream(hipStream_t s) { stream_ = s; }
+    size_t infer_batch_count() const { return infer_batches_.size(); }
+    size_t train_batch_count() const { return train_batch_count_; }
+    uint32_t infer_batch_size() const { return infer_batch_size_; }
+    uint32_t train_batch_size() const { return train_batch_size_; }
+    void set_hook(nrc_grad_hook h, void* u) { hook_ = h; hook_user_ = u; }
+    void set_loss_norm_factor(uint32_t f) { loss_norm_factor_ = f ? f : 1; }
+    void mark_loss_dirty() { loss_dirty_ = true; }
+    const nrc_config& config() const { return cfg_; }
+
+private:
+    nrc_config cfg_;
+    const uint32_t infer_batch_size_, train_batch_size_, train_batch_count_;
+    std::unique_ptr<Mlp> mlp_;
+    uint32_t infer_count_ = 0;
+    float *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
+    hipStream_t stream_ = nullptr;
+    std::vector<std::pair<uint32_t, uint32_t>> infer_batches_;
+    bool initialised_ = false;
+    nrc_grad_hook hook_ = nullptr;
+    void* hook_user_ = nullptr;
+    uint32_t loss_norm_factor_ = 1;
+    float loss_ = 0.0f;
+    bool loss_dirty_ = false;
+};
+
+// ---------------------------------------------------------------------------------------------------- scene upload
+struct SceneDev {
+    DevScene d{};
+    void* d_density = nullptr;
+    void* d_env = nullptr;
+
+    void upload(const nrc_scene& s)
+    {
+        if (!s.density || s.nx == 0 || s.ny == 0 || s.nz == 0) fail("scene has no density volume");
+        if (!(s.density_factor > 0.0f)) fail("scene density factor must be positive");
+        const size_t nvox = (size_t)s.nx * s.ny * s.nz;
+        NRC_HIP(hipMalloc(&d_density, nvox));
+        NRC_HIP(hipMemcpy(d_density, s.density, nvox, hipMemcpyHostToDevice));
+        d.density = (const uint8_t*)d_density;
+        d.nx = s.nx; d.ny = s.ny; d.nz = s.nz;
+        d.fnx = (float)s.nx; d.fny = (float)s.ny; d.fnz = (float)s.nz;
+        float size[3] = {s.size[0], s.size[1], s.size[2]};
+        if (size[0] == 0.0f && size[1] == 0.0f && size[2] == 0.0f) {
+            // volumeSizeF = normalize(extent) * 107.5 (src/NrcHpmRenderer.cu:910-912)
+            const float l = sqrtf((d.fnx * d.fnx + d.fny * d.fny) + d.fnz * d.fnz);
+            size[0] = d.fnx / l * 107.5f; size[1] = d.fny / l * 107.5f; size[2] = d.fnz / l * 107.5f;
+        }
+        for (int k = 0; k < 3; k++) {
+            d.size[k] = size[k];
+            d.half_size[k] = size[k] * 0.5f;
+            d.inv_size[k] = 1.0f / size[k];
+        }
+        const float tx = 2.0f * size[0], ty = 2.0f * size[1], tz = 2.0f * size[2];
+        d.len2size = sqrtf((tx * tx + ty * ty) + tz * tz);
+        d.density_factor = s.density_factor;
+        d.inv_max_density = 1.0f / s.density_factor;
+        d.g = s.g;
+        for (int k = 0; k < 3; k++) {
+            d.dir_light_dir[k] = s.dir_light_dir[k];
+            d.point_light_pos[k] = s.point_light_pos[k];
+            d.point_light_color[k] = s.point_light_color[k];
+        }
+        d.dir_light_strength = s.dir_light_strength;
+        d.point_light_strength = s.point_light_strength;
+        d.env_strength = s.env_strength;
+        d.env = nullptr; d.env_w = d.env_h = 0;
+        if (s.env && s.env_w && s.env_h) {
+            const size_t eb = (size_t)s.env_w * s.env_h * 16;
+            NRC_HIP(hipMalloc(&d_env, eb));
+            NRC_HIP(hipMemcpy(d_env, s.env, eb, hipMemcpyHostToDevice));
+            d.env = (const float*)d_env; d.env_w = s.env_w; d.env_h = s.env_h;
+        }
+    }
+    ~SceneDev()
+    {
+        if (d_density) (void)hipFree(d_density);
+        if (d_env) (void)hipFree(d_env);
+    }
+};
+
+static DevCamera to_dev(const nrc_camera& c)
+{
+    DevCamera d;
+    std::memcpy(d.m, c.inv_proj_view, sizeof(d.m));
+    std::memcpy(d.pos, c.pos, sizeof(d.pos));
+    return d;
+}
+
+static DevFrame make_frame(uint32_t w, uint32_t h, const nrc_tile* tile)
+{
+    DevFrame f{};
+    f.w = w; f.h = h;
+    nrc_tile t = tile ? *tile : nrc_tile{0, 1, w, h};
+    if (t.x_stride == 0 || t.global_w == 0 || t.global_h == 0) fail("bad tile description");
+    if (t.global_h != h) fail("tile: global_h must equal the local height (column sharding)");
+    if ((uint64_t)t.x_offset + (uint64_t)(w - 1) * t.x_stride >= t.global_w) fail("tile columns exceed the global frame");
+    f.x_offset = t.x_offset; f.x_stride = t.x_stride;
+    f.inv_gw = 1.0f / (float)t.global_w;      // ONE_OVER_RENDER_WIDTH (nrc-constants.glsl:28)
+    f.inv_gh = 1.0f / (float)t.global_h;
+    return f;
+}
+
+// uncompressed scan-line EXR, FLOAT channels A,B,G,R (what tinyexr's SaveEXR writes for the reference, minus ZIP)
+static void write_exr(const std::string& path, const std::vector<float>& rgba, uint32_t w, uint32_t h)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) fail("cannot open " + path);
+    auto put = [&](const void* p, size_t n) { f.write((const char*)p, (std::streamsize)n); };
+    auto u32 = [&](uint32_t v) { put(&v, 4); };
+    auto i32 = [&](int32_t v) { put(&v, 4); };
+    auto str = [&](const char* s) { put(s, std::strlen(s) + 1); };
+    u32(20000630); u32(2);
+    str("channels"); str("chlist"); i32(4 * 18 + 1);
+    for (const char* cn : {"A", "B", "G", "R"}) { str(cn); i32(2); u32(0); i32(1); i32(1); }
+    { char z = 0; put(&z, 1); }
+    str("compression"); str("compression"); i32(1); { char z = 0; put(&z, 1); }
+    auto box = [&](const char* name) { str(name); str("box2i"); i32(16); i32(0); i32(0); i32((int32_t)w - 1); i32((int32_t)h - 1); };
+    box("dataWindow"); box("displayWindow");
+    str("lineOrder"); str("lineOrder"); i32(1); { char z = 0; put(&z, 1); }
+    { float one = 1.0f; str("pixelAspectRatio"); str("float"); i32(4); put(&one, 4); }
+    { float z2[2] = {0, 0}; str("screenWindowCenter"); str("v2f"); i32(8); put(z2, 8); }
+    { float one = 1.0f; str("screenWindowWidth"); str("float"); i32(4); put(&one, 4); }
+    { char z = 0; put(&z, 1); }
+    const uint64_t table_pos = (uint64_t)f.tellp();
+    const uint64_t line_bytes = 8 + (uint64_t)w * 16;
+    for (uint32_t y = 0; y < h; y++) { uint64_t off = table_pos + 8ull * h + y * line_bytes; put(&off, 8); }
+    std::vector<float> line((size_t)w * 4);
+    const int order[4] = {3, 2, 1, 0};
+    for (uint32_t y = 0; y < h; y++) {
+        i32((int32_t)y); i32((int32_t)(w * 16));
+        for (int c = 0; c < 4; c++)
+            for (uint32_t x = 0; x < w; x++) line[(size_t)c * w + x] = rgba[((size_t)y * w + x) * 4 + order[c]];
+        put(line.data(), line.size() * 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- Renderer
+class Renderer {
+public:
+    Renderer(uint32_t w, uint32_t h, bool blend, const nrc_camera& cam, const nrc_config& cfg, const nrc_scene& scene,
+             Cache& cache, const nrc_tile* tile, hipStream_t s)
+        : w_(w), h_(h), blend_(blend), cam_(to_dev(cam)), cfg_(cfg), cache_(cache), stream_(s), rng_(cfg.seed)
+    {
+        if (w == 0 || h == 0) fail("render size must be non-zero");
+        frame_ = make_frame(w, h, tile);
+        scene_.upload(scene);
+        calc_train_subset(cfg.train_batch_count * cache.train_batch_size());
+        tg_.spp = cfg.train_spp;
+        // quirk Q2: trainRayLength never reaches the shader, TRAIN_RAY_LENGTH stays 1 (NrcHpmRenderer.cu:991-994 vs :1036-1055)
+        tg_.ray_length = (cfg.compat_fix & NRC_FIX_Q2_TRAIN_RAY_LEN) ? cfg.train_ray_length : 1u;
+        tg_.ring_size = (uint32_t)(cfg.train_ring_buf_size * (float)(tg_.tw * tg_.th));   // :253
+        const size_t px = (size_t)w * h, T = (size_t)tg_.tw * tg_.th;
+        alloc(&d_primary_, px * 16); alloc(&d_info_, px * 4); alloc(&d_origin_, px * 16); alloc(&d_dir_, px * 16);
+        alloc(&d_out_, px * 16); alloc(&d_infer_in_, px * 20); alloc(&d_infer_out_, px * 12);
+        alloc(&d_train_in_, T * 20); alloc(&d_train_target_, T * 12);
+        ring_entries_ = std::max<size_t>(T, tg_.ring_size);
+        alloc(&d_ring_, 8 + ring_entries_ * 24);
+        alloc(&d_scratch_, (2 * T + 4) * 4);
+        alloc(&d_fetch_, 8);
+        // CreateNrcTrainRingBuffer: head = tail = 0, pos = 0, dir = (0,0,1)  (:866-875)
+        std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
+        for (size_t r = 0; r < ring_entries_; r++) { float one = 1.0f; std::memcpy(&ring[2 + 6 * r + 5], &one, 4); }
+        NRC_HIP(hipMemcpy(d_ring_, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
+        for (auto& e : ev_) NRC_HIP(hipEventCreate(&e));
+        cache_.init((uint32_t)px, (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_, (float*)d_train_target_, s);
+    }
+
+    ~Renderer()
+    {
+        for (void* p : allocs_) (void)hipFree(p);
+        for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    }
+
+    void render(bool train)      // NrcHpmRenderer::Render, :299-353
+    {
+        const float blend_factor = 1.0f / (float)blend_index_;
+        if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
+        else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
+        if (blend_) blend_index_++;
+        NRC_HIP(hipEventRecord(ev_[0], stream_));
+        launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
+                        (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
+                        count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
+        NRC_HIP(hipEventRecord(ev_[1], stream_));
+        // the reference records prep_train_rays into every frame's pre-CUDA command buffer (:2039-2040), trained or not
+        launch_prep_train(scene_.d, frame_, tg_, (const float*)d_info_, (const float*)d_origin_, (const float*)d_dir_,
+                          (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, stream_);
+        NRC_HIP(hipEventRecord(ev_[2], stream_));
+        cache_.set_stream(stream_);
+        cache_.infer_and_train(nullptr, train);      // no host read-back of the batch filter: every batch runs
+        NRC_HIP(hipEventRecord(ev_[3], stream_));
+        launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
+                         (const float*)d_infer_out_, (float*)d_out_, stream_);
+        NRC_HIP(hipEventRecord(ev_[4], stream_));
+        timed_ = true;
+    }
+
+    void set_camera(const nrc_camera& c)       // SetCamera, :561-604: reset blending, clear the accumulation images
+    {
+        cam_ = to_dev(c);
+        blend_index_ = 1;
+        const size_t px = (size_t)w_ * h_;
+        NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
+        NRC_HIP(hipMemsetAsync(d_primary_, 0, px * 16, stream_));
+        NRC_HIP(hipMemsetAsync(d_info_, 0, px * 4, stream_));
+    }
+    void set_blend(bool b) { blend_ = b; blend_index_ = 1; }      // :606-610
+    void set_show_nrc(bool s) { show_nrc_ = s ? 1u : 0u; }
+    void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
+    void set_count_fetches(bool on)
+    {
+        count_fetches_ = on;
+        NRC_HIP(hipMemsetAsync(d_fetch_, 0, 8, stream_));
+    }
+    unsigned long long fetches()
+    {
+        unsigned long long v = 0;
+        NRC_HIP(hipMemcpyAsync(&v, d_fetch_, 8, hipMemcpyDeviceToHost, stream_));
+        NRC_HIP(hipStreamSynchronize(stream_));
+        return v;
+    }
+
+    float frame_time_ms(float* stage)       // EvaluateTimestampQueries / GetFrameTimeMS, :495-530
+    {
+        if (!timed_) return 0.0f;
+        NRC_HIP(hipEventSynchronize(ev_[4]));
+        float gen = 0, prep = 0, nrc = 0, comp = 0, total = 0;
+        NRC_HIP(hipEventElapsedTime(&gen, ev_[0], ev_[1]));
+        NRC_HIP(hipEventElapsedTime(&prep, ev_[1], ev_[2]));
+        NRC_HIP(hipEventElapsedTime(&nrc, ev_[2], ev_[3]));
+        NRC_HIP(hipEventElapsedTime(&comp, ev_[3], ev_[4]));
+        NRC_HIP(hipEventElapsedTime(&total, ev_[0], ev_[4]));
+        if (stage) { stage[0] = 0; stage[1] = gen; stage[2] = 0; stage[3] = 0; stage[4] = prep; stage[5] = nrc; stage[6] = comp; stage[7] = total; }
+        return total;
+    }
+
+    void export_exr(const char* path)
+    {
+        std::vector<float> host((size_t)w_ * h_ * 4);
+        NRC_HIP(hipMemcpyAsync(host.data(), d_out_, host.size() * 4, hipMemcpyDeviceToHost, stream_));
+        NRC_HIP(hipStreamSynchronize(stream_));
+        write_exr(path, host, w_, h_);
+    }
+
+    void* buffer(int which, size_t* bytes)
+    {
+        const size_t px = (size_t)w_ * h_, T = (size_t)tg_.tw * tg_.th;
+        void* p = nullptr; size_t b = 0;
+        switch (which) {
+        case 0: p = d_primary_; b = px * 16; break;
+        case 1: p = d_info_; b = px * 4; break;
+        case 2: p = d_origin_; b = px * 16; break;
+        case 3: p = d_dir_; b = px * 16; break;
+        case 4: p = d_infer_in_; b = px * 20; break;
+        case 5: p = d_infer_out_; b = px * 12; break;
+        case 6: p = d_train_in_; b = T * 20; break;
+        case 7: p = d_train_target_; b = T * 12; break;
+        case 8: p = d_ring_; b = 8 + ring_entries_ * 24; break;
+        default: fail("bad buffer id");
+        }
+        if (bytes) *bytes = b;
+        return p;
+    }
+    const float* framebuffer() const { return (const float*)d_out_; }
+    const TrainGrid& train_grid() const { return tg_; }
+    hipStream_t stream() const { return stream_; }
+
+private:
+    void alloc(void** p, size_t bytes)
+    {
+        NRC_HIP(hipMalloc(p, bytes));
+        NRC_HIP(hipMemset(*p, 0, bytes));     // the reference never clears its images at creation (quirk Q14); this build does
+        allocs_.push_back(*p);
+    }
+
+    void calc_train_subset(uint32_t train_pixel_count)       // CalcTrainSubset, :612-642
+    {
+        const uint32_t sq = (uint32_t)std::sqrt((double)train_pixel_count);
+        for (uint32_t factor = sq; factor >= 2; factor--) {
+            if (train_pixel_count % factor == 0) {
+                const uint32_t other = train_pixel_count / factor;
+                const uint32_t bigger = std::max(factor, other), smaller = std::min(factor, other);
+                if (w_ > h_) { tg_.tw = bigger; tg_.th = smaller; }
+                else { tg_.tw = smaller; tg_.th = bigger; }
+                tg_.x_dist = w_ / tg_.tw;
+                const uint32_t y_dist = h_ / tg_.th;
+                // quirk Q1: TRAIN_Y_DIST is specialised from trainXDist (:966-969)
+                tg_.y_dist = (cfg_.compat_fix & NRC_FIX_Q1_TRAIN_Y_DIST) ? y_dist : tg_.x_dist;
+                return;
+            }
+        }
+        fail("Could not find suitable division of trainPixelCount");
+    }
+
+    uint32_t w_, h_;
+    bool blend_;
+    uint32_t blend_index_ = 1;
+    uint32_t show_nrc_ = 1;
+    DevCamera cam_;
+    DevFrame frame_{};
+    nrc_config cfg_;
+    Cache& cache_;
+    hipStream_t stream_;
+    std::mt19937 rng_;
+    SceneDev scene_;
+    TrainGrid tg_{};
+    size_t ring_entries_ = 0;
+    void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
+    void *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
+    void *d_ring_ = nullptr, *d_scratch_ = nullptr, *d_fetch_ = nullptr;
+    std::vector<void*> allocs_;
+    hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed_ = false;
+    float pinned_random_[4] = {0, 0, 0, 0};
+    bool have_pinned_random_ = false;
+    bool count_fetches_ = false;
+};
+
+// ---------------------------------------------------------------------------------------------------- McRenderer
+class McRenderer {
+public:
+    McRenderer(uint32_t w, uint32_t h, uint32_t path_length, bool blend, const nrc_camera& cam, const nrc_scene& scene,
+               const nrc_tile* tile, hipStream_t s)
+        : w_(w), h_(h), path_length_(path_length), blend_(blend), cam_(to_dev(cam)), stream_(s), rng_(1337)
+    {
+        if (w == 0 || h == 0) fail("render size must be non-zero");
+        frame_ = make_frame(w, h, tile);
+        scene_.upload(scene);
+        const size_t px = (size_t)w * h;
+        NRC_HIP(hipMalloc(&d_out_, px * 16)); NRC_HIP(hipMemset(d_out_, 0, px * 16));
+        NRC_HIP(hipMalloc(&d_info_, px * 4)); NRC_HIP(hipMemset(d_info_, 0, px * 4));
+        NRC_HIP(hipMalloc(&d_fetch_, 8)); NRC_HIP(hipMemset(d_fetch_, 0, 8));
+        NRC_HIP(hipEventCreate(&ev_[0])); NRC_HIP(hipEventCreate(&ev_[1]));
+    }
+    ~McRenderer()
+    {
+        if (d_out_) (void)hipFree(d_out_);
+        if (d_info_) (void)hipFree(d_info_);
+        if (d_fetch_) (void)hipFree(d_fetch_);
+        for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    }
+    void render()        // McHpmRenderer::Render, src/McHpmRenderer.cpp:121-151
+    {
+        const float blend_factor = 1.0f / (float)blend_index_;
+        if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
+        else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
+        if (blend_) blend_index_++;
+        NRC_HIP(hipEventRecord(ev_[0], stream_));
+        launch_mc_render(scene_.d, cam_, frame_, path_length_, blend_factor, (float*)d_out_, (float*)d_info_,
+                         count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
+        NRC_HIP(hipEventRecord(ev_[1], stream_));
+        timed_ = true;
+    }
+    void set_camera(const nrc_camera& c)
+    {
+        cam_ = to_dev(c);
+        blend_index_ = 1;
+        NRC_HIP(hipMemsetAsync(d_out_, 0, (size_t)w_ * h_ * 16, stream_));
+    }
+    void set_blend(bool b) { blend_ = b; blend_index_ = 1; }
+    void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
+    void set_count_fetches(bool on) { count_fetches_ = on; NRC_HIP(hipMemsetAsync(d_fetch_, 0, 8, stream_)); }
+    unsigned long long fetches()
+    {
+        unsigned long long v = 0;
+        NRC_HIP(hipMemcpyAsync(&v, d_fetch_, 8, hipMemcpyDeviceToHost, stream_));
+        NRC_HIP(hipStreamSynchronize(stream_));
+        return v;
+    }
+    float frame_time_ms()
+    {
+        if (!timed_) return 0.0f;
+        float ms = 0;
+        NRC_HIP(hipEventSynchronize(ev_[1]));
+        NRC_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+        return ms;
+    }
+    void export_exr(const char* path)
+    {
+        std::vector<float> host((size_t)w_ * h_ * 4);
+        NRC_HIP(hipMemcpyAsync(host.data(), d_out_, host.size() * 4, hipMemcpyDeviceToHost, stream_));
+        NRC_HIP(hipStreamSynchronize(stream_));
+        write_exr(path, host, w_, h_);
+    }
+    const float* framebuffer() const { return (const float*)d_out_; }
+
+private:
+    uint32_t w_, h_, path_length_;
+    bool blend_;
+    uint32_t blend_index_ = 1;
+    DevCamera cam_;
+    DevFrame frame_{};
+    hipStream_t stream_;
+    std::mt19937 rng_;
+    SceneDev scene_;
+    void *d_out_ = nullptr, *d_info_ = nullptr, *d_fetch_ = nullptr;
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    bool timed_ = false;
+    float pinned_random_[4] = {0, 0, 0, 0};
+    bool have_pinned_random_ = false;
+    bool count_fetches_ = false;
+};
+
+}  // namespace nrc
+
+// ==================================================================================================== C ABI
+struct nrc_cache { nrc::Cache impl; explicit nrc_cache(const nrc_config& c) : impl(c) {} };
+struct nrc_renderer { nrc::Renderer impl; template <class... A> explicit nrc_renderer(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct nrc_mc_renderer { nrc::McRenderer impl; template <class... A> explicit nrc_mc_renderer(A&&... a) : impl(std::forward<A>(a)...) {} };
+
+template <class F>
+static int guarded(F f)
+{
+    try {
+        f();
+        return NRC_OK;
+    } catch (const nrc::HipError& e) {
+        nrc::g_last_error = e.what();
+        return NRC_ERR_HIP;
+    } catch (const std::logic_error& e) {
+        nrc::g_last_error = e.what();
+        return NRC_ERR_STATE;
+    } catch (const std::exception& e) {
+        nrc::g_last_error = e.what();
+        return NRC_ERR_INVALID;
+    } catch (...) {
+        nrc::g_last_error = "unknown error";
+        return NRC_ERR_INVALID;
+    }
+}
+#define NRC_REQUIRE(p) do { if (!(p)) { nrc::g_last_error = "SkyRenderer ERROR: null argument: " #p; return NRC_ERR_INVALID; } } while (0)
+
+extern "C" {
+
+const char* nrc_last_error(void) { return nrc::g_last_error.c_str(); }
+const char* nrc_version(void) { return "nrc-hpm-renderer_amd 0.1 (gfx950)"; }
+
+void nrc_config_default(nrc_config* c)     // src/main.cu:432-439, with posID 3 / dirID 0 (BASELINE.json north-star)
+{
+    std::memset(c, 0, sizeof(*c));
+    std::strcpy(c->loss_fn, "RelativeL2Luminance");
+    std::strcpy(c->optimizer, "Adam");
+    c->learning_rate = 0.01f; c->ema_decay = 0.99f;
+    c->pos_id = 3; c->dir_id = 0;
+    c->nn_width = 64; c->nn_depth = 6;
+    c->log2_infer_batch_size = 21; c->log2_train_batch_size = 14; c->train_batch_count = 4;
+    c->scene_id = 4;
+    c->train_ring_buf_size = 1.0f; c->train_spp = 1; c->primary_ray_length = 1; c->primary_ray_prob = 0.0f;
+    c->train_ray_length = 32;
+    c->seed = 1337; c->compat_fix = 0;
+}
+
+int nrc_cache_create(const nrc_config* cfg, nrc_cache_t** out)
+{
+    NRC_REQUIRE(cfg); NRC_REQUIRE(out);
+    return guarded([&] { *out = new nrc_cache(*cfg); });
+}
+int nrc_cache_init(nrc_cache_t* c, uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_tt, void* stream)
+{
+    NRC_REQUIRE(c);
+    return guarded([&] { c->impl.init(infer_count, d_in, d_out, d_tin, d_tt, (hipStream_t)stream); });
+}
+int nrc_cache_infer_and_train(nrc_cache_t* c, const uint32_t* filter, int train)
+{
+    NRC_REQUIRE(c);
+    return guarded([&] { c->impl.infer_and_train(filter, train != 0); });
+}
+int nrc_cache_destroy(nrc_cache_t* c)
+{
+    if (!c) return NRC_OK;
+    return guarded([&] { delete c; });
+}
+float nrc_cache_get_loss(nrc_cache_t* c)
+{
+    float v = NAN;
+    if (c) guarded([&] { v = c->impl.get_loss(); });
+    return v;
+}
+size_t nrc_cache_get_infer_batch_count(nrc_cache_t* c) { return c ? c->impl.infer_batch_count() : 0; }
+size_t nrc_cache_get_train_batch_count(nrc_cache_t* c) { return c ? c->impl.train_batch_count() : 0; }
+uint32_t nrc_cache_get_infer_batch_size(nrc_cache_t* c) { return c ? c->impl.infer_batch_size() : 0; }
+uint32_t nrc_cache_get_train_batch_size(nrc_cache_t* c) { return c ? c->impl.train_batch_size() : 0; }
+
+int nrc_cache_set_stream(nrc_cache_t* c, void* stream)
+{
+    NRC_REQUIRE(c);
+    return guarded([&] { c->impl.set_stream((hipStream_t)stream); });
+}
+int nrc_cache_infer(nrc_cache_t* c, const float* d_in, float* d_out, uint32_t n, int use_ema)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(d_in); NRC_REQUIRE(d_out);
+    return guarded([&] { c->impl.mlp().infer(d_in, d_out, n, use_ema != 0, c->impl.stream()); });
+}
+int nrc_cache_backward(nrc_cache_t* c, const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(d_in); NRC_REQUIRE(d_target);
+    return guarded([&] { c->impl.mlp().backward(d_in, d_target, n, n_norm ? n_norm : n, c->impl.stream()); c->impl.mark_loss_dirty(); });
+}
+int nrc_cache_optimizer_step(nrc_cache_t* c)
+{
+    NRC_REQUIRE(c);
+    return guarded([&] { c->impl.mlp().optimizer_step(c->impl.stream()); });
+}
+float* nrc_cache_grad_ptr(nrc_cache_t* c) { return c ? c->impl.mlp().grad_ptr() : nullptr; }
+uint32_t nrc_cache_param_count(nrc_cache_t* c) { return c ? c->impl.mlp().n_params() : 0; }
+float* nrc_cache_loss_ptr(nrc_cache_t* c) { return c ? c->impl.mlp().loss_ptr() : nullptr; }
+int nrc_cache_set_grad_hook(nrc_cache_t* c, nrc_grad_hook hook, void* user)
+{
+    NRC_REQUIRE(c);
+    c->impl.set_hook(hook, user);
+    return NRC_OK;
+}
+int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor)
+{
+    NRC_REQUIRE(c);
+    c->impl.set_loss_norm_factor(factor);
+    return NRC_OK;
+}
+int nrc_cache_get_params(nrc_cache_t* c, int which, float* host_out)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(host_out);
+    return guarded([&] {
+        NRC_HIP(hipStreamSynchronize(c->impl.stream()));
+        NRC_HIP(hipMemcpy(host_out, c->impl.mlp().buffer(which), (size_t)c->impl.mlp().n_params() * 4, hipMemcpyDeviceToHost));
+    });
+}
+int nrc_cache_set_params(nrc_cache_t* c, int which, const float* host_in)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(host_in);
+    return guarded([&] {
+        NRC_HIP(hipStreamSynchronize(c->impl.stream()));
+        NRC_HIP(hipMemcpy(c->impl.mlp().buffer(which), host_in, (size_t)c->impl.mlp().n_params() * 4, hipMemcpyHostToDevice));
+        if (which == 0 || which == 1) { c->impl.mlp().repack(c->impl.stream()); NRC_HIP(hipStreamSynchronize(c->impl.stream())); }
+    });
+}
+int nrc_cache_get_step(nrc_cache_t* c, uint32_t* step)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(step);
+    *step = c->impl.mlp().step;
+    return NRC_OK;
+}
+int nrc_cache_set_step(nrc_cache_t* c, uint32_t step)
+{
+    NRC_REQUIRE(c);
+    c->impl.mlp().step = step;
+    return NRC_OK;
+}
+
+int nrc_renderer_create(uint32_t w, uint32_t h, int blend, const nrc_camera* cam, const nrc_config* cfg, const nrc_scene* scene,
+                        nrc_cache_t* cache, const nrc_tile* tile, void* stream, nrc_renderer_t** out)
+{
+    NRC_REQUIRE(cam); NRC_REQUIRE(cfg); NRC_REQUIRE(scene); NRC_REQUIRE(cache); NRC_REQUIRE(out);
+    return guarded([&] { *out = new nrc_renderer(w, h, blend != 0, *cam, *cfg, *scene, cache->impl, tile, (hipStream_t)stream); });
+}
+int nrc_renderer_render(nrc_renderer_t* r, int train) { NRC_REQUIRE(r); return guarded([&] { r->impl.render(train != 0); }); }
+int nrc_renderer_set_camera(nrc_renderer_t* r, const nrc_camera* c) { NRC_REQUIRE(r); NRC_REQUIRE(c); return guarded([&] { r->impl.set_camera(*c); }); }
+int nrc_renderer_set_blend(nrc_renderer_t* r, int b) { NRC_REQUIRE(r); r->impl.set_blend(b != 0); return NRC_OK; }
+int nrc_renderer_set_show_nrc(nrc_renderer_t* r, int s) { NRC_REQUIRE(r); r->impl.set_show_nrc(s != 0); return NRC_OK; }
+int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float* v) { NRC_REQUIRE(r); NRC_REQUIRE(v); r->impl.set_frame_random(v); return NRC_OK; }
+const float* nrc_renderer_framebuffer(nrc_renderer_t* r) { return r ? r->impl.framebuffer() : nullptr; }
+int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path) { NRC_REQUIRE(r); NRC_REQUIRE(path); return guarded([&] { r->impl.export_exr(path); }); }
+float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms)
+{
+    float v = -1.0f;
+    if (r) guarded([&] { v = r->impl.frame_time_ms(stage_ms); });
+    return v;
+}
+int nrc_renderer_destroy(nrc_renderer_t* r)
+{
+    if (!r) return NRC_OK;
+    return guarded([&] { (void)hipStreamSynchronize(r->impl.stream()); delete r; });
+}
+void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes)
+{
+    void* p = nullptr;
+    if (r) guarded([&] { p = r->impl.buffer(which, bytes); });
+    return p;
+}
+int nrc_renderer_train_grid(nrc_renderer_t* r, uint32_t out5[5])
+{
+    NRC_REQUIRE(r); NRC_REQUIRE(out5);
+    const nrc::TrainGrid& t = r->impl.train_grid();
+    out5[0] = t.tw; out5[1] = t.th; out5[2] = t.x_dist; out5[3] = t.y_dist; out5[4] = t.ring_size;
+    return NRC_OK;
+}
+int nrc_renderer_count_fetches(nrc_renderer_t* r, int enable, unsigned long long* out)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { if (out) *out = r->impl.fetches(); r->impl.set_count_fetches(enable != 0); });
+}
+
+int nrc_mc_renderer_create(uint32_t w, uint32_t h, uint32_t path_length, int blend, const nrc_camera* cam, const nrc_scene* scene,
+                           const nrc_tile* tile, void* stream, nrc_mc_renderer_t** out)
+{
+    NRC_REQUIRE(cam); NRC_REQUIRE(scene); NRC_REQUIRE(out);
+    return guarded([&] { *out = new nrc_mc_renderer(w, h, path_length, blend != 0, *cam, *scene, tile, (hipStream_t)stream); });
+}
+int nrc_mc_renderer_render(nrc_mc_renderer_t* r) { NRC_REQUIRE(r); return guarded([&] { r->impl.render(); }); }
+int nrc_mc_renderer_set_camera(nrc_mc_renderer_t* r, const nrc_camera* c) { NRC_REQUIRE(r); NRC_REQUIRE(c); return guarded([&] { r->impl.set_camera(*c); }); }
+int nrc_mc_renderer_set_blend(nrc_mc_renderer_t* r, int b) { NRC_REQUIRE(r); r->impl.set_blend(b != 0); return NRC_OK; }
+int nrc_mc_renderer_set_frame_random(nrc_mc_renderer_t* r, const float* v) { NRC_REQUIRE(r); NRC_REQUIRE(v); r->impl.set_frame_random(v); return NRC_OK; }
+const float* nrc_mc_renderer_framebuffer(nrc_mc_renderer_t* r) { return r ? r->impl.framebuffer() : nullptr; }
+int nrc_mc_renderer_export_exr(nrc_mc_renderer_t* r, const char* path) { NRC_REQUIRE(r); NRC_REQUIRE(path); return guarded([&] { r->impl.export_exr(path); }); }
+float nrc_mc_renderer_frame_time_ms(nrc_mc_renderer_t* r)
+{
+    float v = -1.0f;
+    if (r) guarded([&] { v = r->impl.frame_time_ms(); });
+    return v;
+}
+int nrc_mc_renderer_count_fetches(nrc_mc_renderer_t* r, int enable, unsigned long long* out)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { if (out) *out = r->impl.fetches(); r->impl.set_count_fetches(enable != 0); });
+}
+int nrc_mc_renderer_destroy(nrc_mc_renderer_t* r)
+{
+    if (!r) return NRC_OK;
+    return guarded([&] { delete r; });
+}
+
+int nrc_compare_images(const float* d_ref, const float* d_own, uint32_t w, uint32_t h, void* stream, float result5[5])
+{
+    NRC_REQUIRE(d_ref); NRC_REQUIRE(d_own); NRC_REQUIRE(result5);
+    return guarded([&] {
+        double* scratch = nullptr;
+        float* d_res = nullptr;
+        NRC_HIP(hipMalloc(&scratch, (8 + 5 * 256) * sizeof(double)));
+        NRC_HIP(hipMalloc(&d_res, 5 * sizeof(float)));
+        nrc::launch_compare(d_ref, d_own, w * h, scratch, d_res, (hipStream_t)stream);
+        NRC_HIP(hipMemcpyAsync(result5, d_res, 5 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        NRC_HIP(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(scratch);
+        (void)hipFree(d_res);
+    });
+}
+
+int nrc_test_math(int fn, const float* d_a, const float* d_b, uint32_t n, float* d_out, float* d_out2, void* stream)
+{
+    NRC_REQUIRE(d_a); NRC_REQUIRE(d_out);
+    return guarded([&] { nrc::launch_test_math(fn, d_a, d_b ? d_b : d_a, n, d_out, d_out2, (hipStream_t)stream); });
+}
+int nrc_test_rng(float u, float v, const float fr[4], uint32_t n, float* d_out, void* stream)
+{
+    NRC_REQUIRE(fr); NRC_REQUIRE(d_out);
+    return guarded([&] { nrc::launch_test_rng(u, v, fr, n, d_out, (hipStream_t)stream); });
+}
+
+}  // extern "C"

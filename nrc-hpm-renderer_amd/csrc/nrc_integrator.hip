@@ -1,0 +1,771 @@
+// nrc_integrator.hip -- headless HIP path integrator for gfx950: one lane per pixel path, density grid as R8 in HBM
+// (served from L2 / Infinity Cache), HDR framebuffer out.  Compiled with -ffp-contract=off: together with
+// nrc_math.h this makes every per-pixel branch decision reproducible against the CPU oracle.
+//
+// Restates (paths relative to the reference checkout):
+//   data/shader/include/random.glsl      hash RNG                         -> Rng
+//   data/shader/include/volume.glsl      box SDF, entry/exit, density     -> sky_sdf, find_entry_exit, get_density
+//   data/shader/include/dir_gen.glsl     HG phase + direction sampling    -> hg_phase, new_ray_dir
+//   data/shader/include/path_trace.glsl  ratio/delta tracking, lights     -> ratio_track, delta_track, trace_scene
+//   data/shader/nrc/gen_rays.comp + prep_infer_rays.comp (fused)          -> k_gen_rays
+//   data/shader/mc/render.comp                                            -> k_mc_render
+//   data/shader/nrc/clear.comp + prep_train_rays.comp                     -> k_train_scan + k_prep_train
+//   data/shader/nrc/render.comp                                           -> k_composite
+//   data/shader/ref/{cmp1,norm,cmp2}.comp                                 -> k_compare_*
+#include "nrc_integrator.hpp"
+#include "nrc_math.h"
+
+namespace nrc {
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 mul(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a)
+{
+    float l = length(a);
+    return v3(a.x / l, a.y / l, a.z / l);
+}
+
+// ---- include/random.glsl:24-70
+__device__ __forceinline__ uint32_t hash1(uint32_t x)
+{
+    x += (x << 10);
+    x ^= (x >> 6);
+    x += (x << 3);
+    x ^= (x >> 11);
+    x += (x << 15);
+    return x;
+}
+__device__ __forceinline__ float float_construct(uint32_t m) { return nrc_u2f((m & 0x007fffffu) | 0x3f800000u) - 1.0f; }
+__device__ __forceinline__ float random1(float x) { return float_construct(hash1(nrc_f2u(x))); }
+__device__ __forceinline__ float random2(float x, float y) { return float_construct(hash1(nrc_f2u(x) ^ hash1(nrc_f2u(y)))); }
+__device__ __forceinline__ float random4(const float* v)
+{
+    return float_construct(hash1(nrc_f2u(v[0]) ^ hash1(nrc_f2u(v[1])) ^ hash1(nrc_f2u(v[2])) ^ hash1(nrc_f2u(v[3]))));
+}
+
+struct Ctx {
+    const DevScene& sc;
+    float rng;              // randomState
+    uint32_t fetches;
+    __device__ __forceinline__ float rand(float max_val)
+    {
+        rng = random1(rng);
+        return rng * max_val;
+    }
+};
+
+__device__ __forceinline__ void init_random(Ctx& c, float u, float v, const float* frame_random)
+{
+    c.rng = random2(random2(u, v), random4(frame_random));
+}
+
+// ---- include/volume.glsl
+__device__ __forceinline__ float sky_sdf(const DevScene& s, V3 p)
+{
+    V3 d = v3(fabsf(p.x) - s.half_size[0], fabsf(p.y) - s.half_size[1], fabsf(p.z) - s.half_size[2]);
+    V3 dm = v3(fmaxf(d.x, 0.0f), fmaxf(d.y, 0.0f), fmaxf(d.z, 0.0f));
+    return length(dm) + fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f);
+}
+
+__device__ __forceinline__ void find_entry_exit(const DevScene& s, V3 ro, V3 rd, V3* entry, V3* exit_)
+{
+    float dist;
+    do {
+        dist = sky_sdf(s, ro);
+        ro = add(ro, mul(rd, dist));
+    } while (dist > 0.125f && dist < 100000.0f);
+    *entry = ro;
+    ro = add(ro, mul(rd, s.len2size));
+    rd = neg(rd);
+    do {
+        dist = sky_sdf(s, ro);
+        ro = add(ro, mul(rd, dist));
+    } while (dist > 0.125f && dist < 100000.0f);
+    *exit_ = ro;
+}
+
+// volume.glsl:31-39; sampler: R8 UNORM, NEAREST, CLAMP_TO_BORDER black (src/Texture3D.cpp:79-81,221)
+__device__ __forceinline__ float get_density(Ctx& c, V3 p)
+{
+    const DevScene& s = c.sc;
+    float u = p.x * s.inv_size[0] + 0.5f;
+    float v = p.y * s.inv_size[1] + 0.5f;
+    float w = p.z * s.inv_size[2] + 0.5f;
+    float fx = u * s.fnx, fy = v * s.fny, fz = w * s.fnz;
+    c.fetches++;
+    if (!(fx >= 0.0f && fx < s.fnx && fy >= 0.0f && fy < s.fny && fz >= 0.0f && fz < s.fnz)) return 0.0f;
+    uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
+    uint8_t t = s.density[(size_t)ix + (size_t)s.nx * ((size_t)iy + (size_t)s.ny * (size_t)iz)];
+    return s.density_factor * ((float)t * (1.0f / 255.0f));
+}
+
+// ---- include/dir_gen.glsl
+__device__ __forceinline__ float hg_phase(const DevScene& s, float cos_theta)
+{
+    float g = s.g;
+    float g2 = g * g;
+    float x = (1.0f + g2) - (2.0f * g) * cos_theta;
+    return (0.5f * (1.0f - g2)) / (x * sqrtf(x));
+}
+
+__device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
+{
+    axis = normalize(axis);
+    float s, co;
+    nrc_sincosf(angle, &s, &co);
+    float oc = 1.0f - co;
+    V3 c0 = v3(oc * axis.x * axis.x + co, oc * axis.x * axis.y - axis.z * s, oc * axis.z * axis.x + axis.y * s);
+    V3 c1 = v3(oc * axis.x * axis.y + axis.z * s, oc * axis.y * axis.y + co, oc * axis.y * axis.z - axis.x * s);
+    V3 c2 = v3(oc * axis.z * axis.x - axis.y * s, oc * axis.y * axis.z + axis.x * s, oc * axis.z * axis.z + co);
+    return v3((c0.x * v.x + c1.x * v.y) + c2.x * v.z, (c0.y * v.x + c1.y * v.y) + c2.y * v.z,
+              (c0.z * v.x + c1.z * v.y) + c2.z * v.z);
+}
+
+__device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_sampling)
+{
+    old_dir = normalize(old_dir);
+    V3 ortho = old_dir.z < old_dir.x ? v3(old_dir.y, -old_dir.x, 0.0f) : v3(0.0f, -old_dir.z, old_dir.y);
+    if (ortho.x == 0.0f && ortho.y == 0.0f && ortho.z == 0.0f) ortho = v3(0.0f, 1.0f, 0.0f);   // robustness
+    ortho = normalize(ortho);
+    float angle;
+    if (phase_sampling) {
+        float g = c.sc.g;
+        float cos_theta;
+        if (fabsf(g) < 0.001f) {
+            cos_theta = 1.0f - 2.0f * c.rand(1.0f);
+        } else {
+            float sqr_term = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * c.rand(1.0f));
+            cos_theta = ((1.0f + g * g) - sqr_term * sqr_term) / (2.0f * g);
+        }
+        angle = nrc_acosf_clamped(cos_theta);
+    } else {
+        angle = c.rand(NRC_PI);
+    }
+    V3 nd = rotate(ortho, angle, old_dir);
+    angle = c.rand(NRC_TWO_PI);
+    nd = rotate(old_dir, angle, nd);
+    return normalize(nd);
+}
+
+// ---- include/path_trace.glsl
+__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
+{
+    V3 d = sub(end, start);
+    V3 dir = normalize(d);
+    float t_max = length(d);
+    float tr = 1.0f, t = 0.0f;
+    for (uint32_t i = 0; i < 128; i++) {
+        t -= nrc_logf(1.0f - c.rand(1.0f)) * c.sc.inv_max_density;
+        if (t >= t_max) break;
+        V3 p = add(start, mul(dir, t));
+        tr *= 1.0f - get_density(c, p) * c.sc.inv_max_density;
+    }
+    return tr;
+}
+
+__device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir)
+{
+    const DevScene& s = c.sc;
+    if (s.dir_light_strength == 0.0f) return v3(0, 0, 0);
+    V3 ld = v3(s.dir_light_dir[0], s.dir_light_dir[1], s.dir_light_dir[2]);
+    V3 en, ex;
+    find_entry_exit(s, pos, neg(normalize(ld)), &en, &ex);
+    float tr = ratio_track(c, pos, ex);
+    float phase = hg_phase(s, dot(ld, neg(dir)));
+    float l = (1.0f * tr) * s.dir_light_strength * phase;
+    return v3(l, l, l);
+}
+
+__device__ __forceinline__ V3 trace_point_light(Ctx& c, V3 pos, V3 dir)
+{
+    const DevScene& s = c.sc;
+    if (s.point_light_strength == 0.0f) return v3(0, 0, 0);
+    V3 lp = v3(s.point_light_pos[0], s.point_light_pos[1], s.point_light_pos[2]);
+    float tr = ratio_track(c, lp, pos);
+    float phase = hg_phase(s, dot(normalize(sub(lp, pos)), neg(dir)));
+    return v3(((s.point_light_color[0] * s.point_light_strength) * tr) * phase,
+              ((s.point_light_color[1] * s.point_light_strength) * tr) * phase,
+              ((s.point_light_color[2] * s.point_light_strength) * tr) * phase);
+}
+
+__device__ __forceinline__ V3 env_lookup(const DevScene& s, float u, float v)
+{
+    if (s.env == nullptr || s.env_w == 0) return v3(0, 0, 0);
+    float fx = u * (float)s.env_w - 0.5f, fy = v * (float)s.env_h - 0.5f;
+    float flx = floorf(fx), fly = floorf(fy);
+    float wx = fx - flx, wy = fy - fly;
+    int x0 = (int)flx, y0 = (int)fly, x1 = x0 + 1, y1 = y0 + 1;
+    int mw = (int)s.env_w - 1, mh = (int)s.env_h - 1;
+    x0 = min(max(x0, 0), mw);
+    x1 = min(max(x1, 0), mw);
+    y0 = min(max(y0, 0), mh);
+    y1 = min(max(y1, 0), mh);
+    const float* p00 = s.env + 4 * ((size_t)y0 * s.env_w + x0);
+    const float* p10 = s.env + 4 * ((size_t)y0 * s.env_w + x1);
+    const float* p01 = s.env + 4 * ((size_t)y1 * s.env_w + x0);
+    const float* p11 = s.env + 4 * ((size_t)y1 * s.env_w + x1);
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = p00[k] + wx * (p10[k] - p00[k]);
+        float b = p01[k] + wx * (p11[k] - p01[k]);
+        r[k] = (a + wy * (b - a)) * s.env_strength;
+    }
+    return v3(r[0], r[1], r[2]);
+}
+
+__device__ __forceinline__ V3 sample_env_dir(const DevScene& s, V3 dir)
+{
+    float phi = nrc_atan2f(dir.z, dir.x);
+    float theta = nrc_asinf(dir.y);
+    return env_lookup(s, phi * 0.1591f + 0.5f, theta * 0.3183f + 0.5f);
+}
+
+__device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir)
+{
+    if (c.sc.env_strength == 0.0f) return v3(0, 0, 0);
+    V3 rdir = new_ray_dir(c, dir, false);
+    float phase = hg_phase(c.sc, dot(rdir, neg(dir)));
+    V3 en, ex;
+    find_entry_exit(c.sc, pos, rdir, &en, &ex);
+    float tr = ratio_track(c, pos, ex);
+    V3 e = sample_env_dir(c.sc, rdir);
+    return v3((e.x * phase) * tr, (e.y * phase) * tr, (e.z * phase) * tr);
+}
+
+__device__ __forceinline__ V3 trace_scene(Ctx& c, V3 pos, V3 dir)
+{
+    V3 a = trace_dir_light(c, pos, dir);
+    V3 b = trace_point_light(c, pos, dir);
+    V3 e = sample_env(c, pos, dir);
+    return add(add(a, b), e);
+}
+
+__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)
+{
+    *volume_exit = false;
+    V3 en, ex;
+    find_entry_exit(c.sc, ro, rd, &en, &ex);
+    float t_max = length(sub(ex, ro));
+    float t = 0.0f;
+    for (uint32_t i = 0; i < 128; i++) {
+        t -= nrc_logf(1.0f - c.rand(1.0f)) * c.sc.inv_max_density;
+        if (t >= t_max) {
+            *volume_exit = true;
+            break;
+        }
+        V3 p = add(ro, mul(rd, t));
+        if (get_density(c, p) * c.sc.inv_max_density > c.rand(1.0f)) return p;
+    }
+    return add(ro, mul(rd, c.rand(t_max)));
+}
+
+// camera ray: mc/render.comp:42-60, nrc/gen_rays.comp:53-72 (no half-pixel offset, no y flip)
+__device__ __forceinline__ void camera_ray(const DevCamera& cam, float u, float v, V3* ro, V3* rd)
+{
+    float sx = u * 2.0f - 1.0f, sy = v * 2.0f - 1.0f;
+    const float* m = cam.m;
+    float wx = ((m[0] * sx + m[4] * sy) + m[8] * 0.0f) + m[12];
+    float wy = ((m[1] * sx + m[5] * sy) + m[9] * 0.0f) + m[13];
+    float wz = ((m[2] * sx + m[6] * sy) + m[10] * 0.0f) + m[14];
+    float ww = ((m[3] * sx + m[7] * sy) + m[11] * 0.0f) + m[15];
+    V3 p = v3(wx / ww, wy / ww, wz / ww);
+    *ro = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    *rd = normalize(sub(p, *ro));
+}
+
+// StoreNrcInferInput / StoreNrcTrainData normalisation (quirks Q3-Q5 kept)
+__device__ __forceinline__ void nrc_query(const DevScene& s, V3 pos, V3 dir, float* q)
+{
+    q[0] = pos.x / s.size[0] + s.size[0] / 2.0f;
+    q[1] = pos.y / s.size[1] + s.size[1] / 2.0f;
+    q[2] = pos.z / s.size[2] + s.size[2] / 2.0f;
+    float theta = nrc_atan2f(dir.z, dir.x);
+    q[3] = theta / NRC_PI + 0.5f;
+    float lxz = sqrtf(dir.x * dir.x + dir.z * dir.z);
+    float phi = nrc_acosf(dir.y / lxz);
+    q[4] = phi / NRC_PI;
+}
+
+// 16x16 pixel tile per 256-thread workgroup, 8x8 per wave (coherent paths inside a wave)
+__device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx, uint32_t* y)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    *lx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    *y = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    return *lx < fr.w && *y < fr.h;
+}
+
+__device__ __forceinline__ void count_fetches(unsigned long long* counter, uint32_t n)
+{
+    if (counter == nullptr) return;
+    unsigned long long v = n;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(counter, v);
+}
+
+// ------------------------------------------------------------------------------------------------ nrc/gen_rays.comp + prep_infer_rays.comp
+__global__ __launch_bounds__(256) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
+                                                 float primary_ray_prob, float4* __restrict__ primary,
+                                                 float* __restrict__ info, float4* __restrict__ origin,
+                                                 float4* __restrict__ dirs, float* __restrict__ infer_in,
+                                                 unsigned long long* fetch_counter)
+{
+    uint32_t lx, y;
+    const bool inside = pixel_of_thread(fr, &lx, &y);
+    Ctx c{sc, 0.0f, 0u};
+    if (inside) {
+        const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+        const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+        V3 ro, rd;
+        camera_ray(cam, u, v, &ro, &rd);
+        init_random(c, u, v, fr.random);
+        V3 entry, ex;
+        find_entry_exit(sc, ro, rd, &entry, &ex);
+        const size_t pix = (size_t)y * fr.w + lx;
+        V3 col;
+        float thr = 1.0f;
+        bool did_scatter = false;
+        float q[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (sky_sdf(sc, entry) > 100000.0f) {
+            col = sample_env_dir(sc, rd);
+        } else {
+            V3 light = v3(0, 0, 0);
+            V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
+            float factor = 1.0f;
+            bool vexit = false;
+            for (int i = 0;; i++) {
+                cur = delta_track(c, cur, dir, &vexit);
+                if (vexit) break;
+                did_scatter = true;
+                factor *= 0.5f;
+                light = add(light, mul(trace_scene(c, cur, dir), factor));
+                dir = new_ray_dir(c, dir, true);
+                if ((uint32_t)i >= primary_ray_length) {
+                    if (c.rand(1.0f) >= primary_ray_prob || i == 128) break;
+                }
+            }
+            origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
+            dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            col = light;
+            thr = factor;
+            if (!did_scatter) {
+                col = sample_env_dir(sc, rd);
+                thr = 1.0f;
+            } else {
+                nrc_query(sc, cur, dir, q);
+            }
+        }
+        primary[pix] = make_float4(col.x, col.y, col.z, thr);
+        info[pix] = did_scatter ? 1.0f : 0.0f;
+        // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
+        // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
+        float* qo = infer_in + ((size_t)lx * fr.h + y) * 5u;
+#pragma unroll
+        for (int k = 0; k < 5; k++) qo[k] = q[k];
+    }
+    count_fetches(fetch_counter, c.fetches);
+}
+
+// ------------------------------------------------------------------------------------------------ mc/render.comp
+__global__ __launch_bounds__(256) void k_mc_render(DevScene sc, DevCamera cam, DevFrame fr, uint32_t path_length,
+                                                  float blend_factor, float4* __restrict__ out_rgba,
+                                                  float* __restrict__ info, unsigned long long* fetch_counter)
+{
+    uint32_t lx, y;
+    const bool inside = pixel_of_thread(fr, &lx, &y);
+    Ctx c{sc, 0.0f, 0u};
+    if (inside) {
+        const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+        const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+        V3 ro, rd;
+        camera_ray(cam, u, v, &ro, &rd);
+        init_random(c, u, v, fr.random);
+        V3 entry, ex;
+        find_entry_exit(sc, ro, rd, &entry, &ex);
+        V3 col;
+        bool did_scatter = false;
+        if (sky_sdf(sc, entry) > 100000.0f) {
+            col = sample_env_dir(sc, rd);
+        } else {
+            V3 light = v3(0, 0, 0);
+            V3 cur = entry, dir = rd;
+            float factor = 1.0f;
+            bool vexit = false;
+            for (uint32_t i = 0; i < path_length; i++) {
+                cur = delta_track(c, cur, dir, &vexit);
+                if (vexit) break;
+                did_scatter = true;
+                factor *= 0.5f;
+                light = add(light, mul(trace_scene(c, cur, dir), factor));
+                dir = new_ray_dir(c, dir, true);
+            }
+            col = light;
+            if (!did_scatter) col = sample_env_dir(sc, rd);
+        }
+        const float a = did_scatter ? 1.0f : 0.0f;
+        const size_t pix = (size_t)y * fr.w + lx;
+        const float4 prev = out_rgba[pix];
+        const float ib = 1.0f - blend_factor;
+        out_rgba[pix] = make_float4(blend_factor * col.x + ib * prev.x, blend_factor * col.y + ib * prev.y,
+                                    blend_factor * col.z + ib * prev.z, blend_factor * a + ib * prev.w);
+        if (info) info[pix] = a;
+    }
+    count_fetches(fetch_counter, c.fetches);
+}
+
+// ------------------------------------------------------------------------------------------------ nrc/clear.comp + ring ordering
+// scratch layout: [0..T) scatter flag, [T..2T) exclusive rank among its kind (push rank if scattered, pop rank otherwise),
+// [2T] n_push, [2T+1] n_pop, [2T+2] head (wrapped), [2T+3] tail (wrapped).
+// Deterministic replacement of the two atomic counters of prep_train_rays.comp:7-31: ranks in linear train-index order.
+__global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, const float* __restrict__ info,
+                                                    uint32_t* __restrict__ ring, uint32_t* __restrict__ scratch)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t T = tg.tw * tg.th;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < T; base += 1024u) {
+        const uint32_t i = base + tid;
+        uint32_t f = 0;
+        if (i < T) {
+            const uint32_t tx = i % tg.tw, ty = i / tg.tw;
+            const uint32_t rx = tx * tg.x_dist, ry = ty * tg.y_dist;
+            f = (rx < fr.w && ry < fr.h) ? (info[(size_t)ry * fr.w + rx] == 1.0f ? 1u : 0u) : 0u;   // OOB imageLoad -> 0 (Q1)
+        }
+        // wave-inclusive scan of f
+        uint32_t incl = f;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        const uint32_t excl_push = carry + woff + incl - f;      // scattered entries before i
+        if (i < T) {
+            scratch[i] = f;
+            scratch[T + i] = f ? excl_push : (i - excl_push);
+        }
+        __syncthreads();
+        if (tid == 1023u) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t n_push = carry_s;
+        uint32_t head = ring[0], tail = ring[1];
+        if (tg.ring_size > 0) {          // clear.comp:5-9
+            head %= tg.ring_size;
+            tail %= tg.ring_size;
+        }
+        scratch[2 * T] = n_push;
+        scratch[2 * T + 1] = T - n_push;
+        scratch[2 * T + 2] = head;
+        scratch[2 * T + 3] = tail;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ nrc/prep_train_rays.comp
+// Phase A (k_prep_train): pop / trace / write train data; pushes are deferred into `pending` so that every pop sees the
+// ring as it was at frame start.  Phase B (k_ring_push): apply pushes in linear order, advance head/tail.
+__global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, TrainGrid tg, const float4* __restrict__ origin,
+                                                   const float4* __restrict__ dirs, const uint32_t* __restrict__ ring,
+                                                   const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
+                                                   float* __restrict__ train_target)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    if (tx >= tg.tw || ty >= tg.th) return;
+    const uint32_t T = tg.tw * tg.th;
+    const uint32_t i = ty * tg.tw + tx;
+    Ctx c{sc, 0.0f, 0u};
+    // seed from TRAIN coordinates over the render size (quirk Q6, prep_train_rays.comp:108); sharded: global column
+    const uint32_t gx = fr.x_offset + tx * fr.x_stride;
+    init_random(c, (float)gx * fr.inv_gw, (float)ty * fr.inv_gh, fr.random);
+    V3 ro = v3(0, 0, 0);
+    V3 rdir = normalize(v3(1.0f, 1.0f, 1.0f));
+    const bool scat = scratch[i] != 0u;
+    if (scat) {
+        const size_t p = (size_t)(ty * tg.y_dist) * fr.w + tx * tg.x_dist;
+        const float4 o = origin[p], d = dirs[p];
+        ro = v3(o.x, o.y, o.z);
+        rdir = v3(d.x, d.y, d.z);
+    } else if (tg.ring_size > 0) {
+        const uint32_t tail = scratch[2 * T + 3];
+        const float* r = reinterpret_cast<const float*>(ring + 2) + 6 * (size_t)((tail + scratch[T + i]) % tg.ring_size);
+        ro = v3(r[0], r[1], r[2]);
+        rdir = v3(r[3], r[4], r[5]);
+    }
+    V3 target = v3(0, 0, 0);
+    for (uint32_t s = 0; s < tg.spp; s++) {
+        V3 light = v3(0, 0, 0);
+        V3 en, ex;
+        find_entry_exit(sc, ro, rdir, &en, &ex);
+        V3 cur = en, dir = rdir;
+        float factor = 1.0f;
+        bool vexit = false;
+        for (uint32_t k = 0; k < tg.ray_length; k++) {
+            cur = delta_track(c, cur, dir, &vexit);
+            if (vexit) break;
+            factor *= 0.5f;
+            light = add(light, mul(trace_scene(c, cur, dir), factor));
+            dir = new_ray_dir(c, dir, true);
+        }
+        target = add(target, light);
+    }
+    const float fs = (float)tg.spp;
+    target = v3(target.x / fs, target.y / fs, target.z / fs);
+    if (tg.ring_size > 0) {
+        float q[5];
+        nrc_query(sc, ro, rdir, q);
+#pragma unroll
+        for (int k = 0; k < 5; k++) train_in[5 * (size_t)i + k] = q[k];
+        train_target[3 * (size_t)i + 0] = fminf(8.0f, target.x);
+        train_target[3 * (size_t)i + 1] = fminf(8.0f, target.y);
+        train_target[3 * (size_t)i + 2] = fminf(8.0f, target.z);
+    }
+}
+
+__global__ void k_ring_push(DevFrame fr, TrainGrid tg, const float4* __restrict__ origin, const float4* __restrict__ dirs,
+                            uint32_t* __restrict__ ring, const uint32_t* __restrict__ scratch)
+{
+    const uint32_t T = tg.tw * tg.th;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tg.ring_size == 0) return;
+    const uint32_t head = scratch[2 * T + 2];
+    if (i < T && scratch[i] != 0u) {
+        const uint32_t tx = i % tg.tw, ty = i / tg.tw;
+        const size_t p = (size_t)(ty * tg.y_dist) * fr.w + tx * tg.x_dist;
+        const float4 o = origin[p], d = dirs[p];
+        float* r = reinterpret_cast<float*>(ring + 2) + 6 * (size_t)((head + scratch[T + i]) % tg.ring_size);
+        r[0] = o.x; r[1] = o.y; r[2] = o.z;
+        r[3] = d.x; r[4] = d.y; r[5] = d.z;
+    }
+    if (i == 0) {
+        ring[0] = head + scratch[2 * T];         // un-wrapped, as atomicAdd leaves them; wrapped next frame (clear.comp)
+        ring[1] = scratch[2 * T + 3] + scratch[2 * T + 1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ nrc/render.comp
+__global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nrc, float blend_factor,
+                                                  const float4* __restrict__ primary, const float* __restrict__ info,
+                                                  const float* __restrict__ infer_out, float4* __restrict__ out_rgba)
+{
+    uint32_t lx, y;
+    if (!pixel_of_thread(fr, &lx, &y)) return;
+    const size_t pix = (size_t)y * fr.w + lx, lin = (size_t)lx * fr.h + y;
+    const float4 p = primary[pix];
+    float cr = p.x, cg = p.y, cb = p.z;
+    if (show_nrc == 1u && info[pix] == 1.0f) {
+        cr += fmaxf(0.0f, infer_out[3 * lin + 0]) * p.w;
+        cg += fmaxf(0.0f, infer_out[3 * lin + 1]) * p.w;
+        cb += fmaxf(0.0f, infer_out[3 * lin + 2]) * p.w;
+    }
+    const float4 prev = out_rgba[pix];
+    const float ib = 1.0f - blend_factor;
+    out_rgba[pix] = make_float4(blend_factor * cr + ib * prev.x, blend_factor * cg + ib * prev.y,
+                                blend_factor * cb + ib * prev.z, blend_factor * 1.0f + ib * prev.w);
+}
+
+// ------------------------------------------------------------------------------------------------ ref/cmp1, norm, cmp2
+// deterministic two-level reductions in fp64 instead of float atomics
+constexpr int CMP_BLOCKS = 256;
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// pass 1: per-block partials of {sq err, ref sum, own sum, valid count}; scratch[8 + 4*b + k]
+__global__ __launch_bounds__(256) void k_compare_1(const float4* __restrict__ ref, const float4* __restrict__ own, uint32_t n,
+                                                  double* __restrict__ scratch)
+{
+    __shared__ double sh[256];
+    double se = 0, rs = 0, os = 0, cnt = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += CMP_BLOCKS * 256u) {
+        const float4 r = ref[i], o = own[i];
+        if (r.w == 0.0f) continue;            // cmp1.comp:32
+        cnt += 1.0;
+        const double dx = (double)o.x - r.x, dy = (double)o.y - r.y, dz = (double)o.z - r.z;
+        se += dx * dx + dy * dy + dz * dz;
+        rs += (double)r.x + r.y + r.z;
+        os += (double)o.x + o.y + o.z;
+    }
+    se = block_sum(se, sh); rs = block_sum(rs, sh); os = block_sum(os, sh); cnt = block_sum(cnt, sh);
+    if (threadIdx.x == 0) {
+        double* p = scratch + 8 + 4 * blockIdx.x;
+        p[0] = se; p[1] = rs; p[2] = os; p[3] = cnt;
+    }
+}
+// norm.comp: fold partials -> scratch[0..3] = {mse, refMean, ownMean, count}
+__global__ void k_compare_norm(double* __restrict__ scratch)
+{
+    if (threadIdx.x != 0) return;
+    double se = 0, rs = 0, os = 0, cnt = 0;
+    for (int b = 0; b < CMP_BLOCKS; b++) {
+        const double* p = scratch + 8 + 4 * b;
+        se += p[0]; rs += p[1]; os += p[2]; cnt += p[3];
+    }
+    const double inv = cnt > 0 ? 1.0 / (cnt * 3.0) : 0.0;
+    scratch[0] = se * inv; scratch[1] = rs * inv; scratch[2] = os * inv; scratch[3] = cnt;
+}
+// cmp2.comp: variance of own around ownMean
+__global__ __launch_bounds__(256) void k_compare_2(const float4* __restrict__ ref, const float4* __restrict__ own, uint32_t n,
+                                                  double* __restrict__ scratch)
+{
+    __shared__ double sh[256];
+    const double mean = scratch[2];
+    double var = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += CMP_BLOCKS * 256u) {
+        const float4 r = ref[i], o = own[i];
+        if (r.w == 0.0f) continue;
+        const double dx = o.x - mean, dy = o.y - mean, dz = o.z - mean;
+        var += dx * dx + dy * dy + dz * dz;
+    }
+    var = block_sum(var, sh);
+    if (threadIdx.x == 0) scratch[8 + 4 * CMP_BLOCKS + blockIdx.x] = var;
+}
+__global__ void k_compare_final(const double* __restrict__ scratch, float* __restrict__ result5)
+{
+    if (threadIdx.x != 0) return;
+    double var = 0;
+    for (int b = 0; b < CMP_BLOCKS; b++) var += scratch[8 + 4 * CMP_BLOCKS + b];
+    const double cnt = scratch[3];
+    const double inv = cnt > 0 ? 1.0 / (cnt * 3.0) : 0.0;
+    result5[0] = (float)scratch[0];
+    result5[1] = (float)scratch[1];
+    result5[2] = (float)scratch[2];
+    result5[3] = (float)(var * inv);
+    result5[4] = (float)cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ test hooks
+__global__ void k_test_math(int fn, const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
+                            float* __restrict__ out, float* __restrict__ out2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f, c = 0.0f;
+    switch (fn) {
+    case 0: s = nrc_logf(a[i]); break;
+    case 1: nrc_sincosf(a[i], &s, &c); break;
+    case 2: s = nrc_acosf(a[i]); break;
+    case 3: s = nrc_asinf(a[i]); break;
+    case 4: s = nrc_atan2f(a[i], b[i]); break;
+    case 5: s = nrc_acosf_clamped(a[i]); break;
+    case 6: s = a[i] / b[i]; break;
+    case 7: s = sqrtf(a[i]); break;
+    case 8: s = (float)(_Float16)a[i]; break;
+    default: break;
+    }
+    out[i] = s;
+    if (out2) out2[i] = c;
+}
+
+__global__ void k_test_rng(float u, float v, float r0, float r1, float r2, float r3, uint32_t n, float* __restrict__ out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float fr[4] = {r0, r1, r2, r3};
+    float state = random2(random2(u, v), random4(fr));
+    out[0] = state;
+    for (uint32_t i = 0; i < n; i++) {
+        state = random1(state);
+        out[1 + i] = state * 1.0f;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ launchers
+static dim3 pixel_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(w, 16), ceil_div(h, 16)); }
+
+void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
+                     float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
+                     unsigned long long* fetch_counter, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gen_rays, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, primary_ray_length,
+                       primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in, fetch_counter);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
+                      float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mc_render, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, path_length, blend_factor,
+                       (float4*)out_rgba, info, fetch_counter);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& tg, const float* info, const float* origin,
+                       const float* dir, uint32_t* ring, uint32_t* scratch, float* train_in, float* train_target,
+                       hipStream_t s)
+{
+    const uint32_t T = tg.tw * tg.th;
+    hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(1024), 0, s, fr, tg, info, ring, scratch);
+    NRC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_prep_train, pixel_grid(tg.tw, tg.th), dim3(256), 0, s, sc, fr, tg, (const float4*)origin,
+                       (const float4*)dir, (const uint32_t*)ring, (const uint32_t*)scratch, train_in, train_target);
+    NRC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_ring_push, dim3(ceil_div(T, 256)), dim3(256), 0, s, fr, tg, (const float4*)origin,
+                       (const float4*)dir, ring, (const uint32_t*)scratch);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary, const float* info,
+                      const float* infer_out, float* out_rgba, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_composite, pixel_grid(fr.w, fr.h), dim3(256), 0, s, fr, show_nrc, blend_factor,
+                       (const float4*)primary, info, infer_out, (float4*)out_rgba);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_compare(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, float* d_result5,
+                    hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compare_1, dim3(CMP_BLOCKS), dim3(256), 0, s, (const float4*)ref_rgba, (const float4*)own_rgba,
+                       n_pixels, d_scratch);
+    hipLaunchKernelGGL(k_compare_norm, dim3(1), dim3(64), 0, s, d_scratch);
+    hipLaunchKernelGGL(k_compare_2, dim3(CMP_BLOCKS), dim3(256), 0, s, (const float4*)ref_rgba, (const float4*)own_rgba,
+                       n_pixels, d_scratch);
+    hipLaunchKernelGGL(k_compare_final, dim3(1), dim3(64), 0, s, (const double*)d_scratch, d_result5);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, float* out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_test_math, dim3(ceil_div(n, 256)), dim3(256), 0, s, fn, a, b, n, out, out2);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_test_rng(float u, float v, const float* fr, uint32_t n, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_test_rng, dim3(1), dim3(64), 0, s, u, v, fr[0], fr[1], fr[2], fr[3], n, out);
+    NRC_HIP(hipGetLastError());
+}
+
+}  // namespace nrc

@@ -1,0 +1,63 @@
+// nrc_integrator.hpp -- volumetric path integrator kernels (host launch interface).
+// HIP restatement of data/shader/nrc/{clear,gen_rays,prep_infer_rays,prep_train_rays,render}.comp,
+// data/shader/mc/render.comp and data/shader/include/{random,volume,dir_gen,path_trace}.glsl.
+#pragma once
+#include "nrc_common.hpp"
+
+namespace nrc {
+
+// device-resident scene constants (specialization constants + UBOs of the reference: nrc-constants.glsl:18-26,
+// nrc-descriptors.glsl:13-38)
+struct DevScene {
+    const uint8_t* density;       // R8, index i + nx*(j + ny*k)
+    uint32_t nx, ny, nz;
+    float fnx, fny, fnz;
+    float size[3], half_size[3], inv_size[3];
+    float len2size;               // length(2*skySize)
+    float density_factor, inv_max_density, g;
+    float dir_light_dir[3], dir_light_strength;
+    float point_light_pos[3], point_light_strength, point_light_color[3];
+    const float* env;             // RGBA32F
+    uint32_t env_w, env_h;
+    float env_strength;
+};
+
+struct DevCamera {
+    float m[16];                  // invProjView, column-major
+    float pos[3];
+};
+
+struct DevFrame {
+    float random[4];              // UniformData.random
+    uint32_t w, h;                // local image: w columns x h rows
+    uint32_t x_offset, x_stride;  // global x = x_offset + lx * x_stride
+    float inv_gw, inv_gh;         // 1/global width, 1/global height (ONE_OVER_RENDER_WIDTH/HEIGHT)
+};
+
+struct TrainGrid {
+    uint32_t tw, th, x_dist, y_dist, spp, ray_length, ring_size;
+};
+
+void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
+                     float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
+                     unsigned long long* fetch_counter, hipStream_t s);
+
+void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
+                      float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);
+
+// ring: {uint head, uint tail, RayInfo[ring_size]}; scratch: uint32[2*T + 4]
+void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& tg, const float* info,
+                       const float* origin, const float* dir, uint32_t* ring, uint32_t* scratch, float* train_in,
+                       float* train_target, hipStream_t s);
+
+void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary,
+                      const float* info, const float* infer_out, float* out_rgba, hipStream_t s);
+
+// Reference::Result; d_scratch: double[8 + 2048]
+void launch_compare(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, float* d_result5,
+                    hipStream_t s);
+
+void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, float* out2, hipStream_t s);
+void launch_test_rng(float u, float v, const float* frame_random4, uint32_t n, float* out, hipStream_t s);
+
+}  // namespace nrc

@@ -1,0 +1,705 @@
+// nrc_mlp.hip -- fused input encoding + fully fused MLP for gfx950 (CDNA4), hand-written MFMA kernels.
+//
+// Replaces tiny-cuda-nn v1.6 as used by src/NeuralRadianceCache.cu:16-39 (model config), :142 (inference),
+// :153-154 (training_step / loss).  Arithmetic spec: SURVEY.md App. B (Frequency / OneBlob encodings,
+// FullyFusedMLP with ReLU, RelativeL2Luminance, EMA{Adam}); precision: fp16 weights and activations,
+// fp32 MFMA accumulation (>= the reference's fp16 accumulation), fp32 I/O, fp32 gradients and optimizer.
+//
+// Kernel design (wave64, v_mfma_f32_32x32x16_f16):
+//   * orientation H^T = W * X^T: a wave owns 32 samples (MFMA columns = lanes), neurons run along the MFMA rows.
+//     The 32x32 fp32 accumulator of layer l, ReLU'd and rounded to fp16 in registers, IS the B operand of layer
+//     l+1 (the sum runs over the accumulator's row index), so activations never leave the register file.
+//   * weights are pre-swizzled into "fragment images" ([frag][lane][8 halfs] = one ds_read_b128 per lane per MFMA,
+//     conflict free) whose k-order matches the accumulator->operand permutation; each workgroup stages the image
+//     into LDS once (54 KB) and then streams sample tiles persistently.
+//   * the input encoding is computed straight into B-operand registers (v_fract/v_sin/v_cos hardware, argument
+//     reduced exactly), the fp32 RGB output is stored from the accumulator: 20 B in + 12 B out per sample.
+//   * training: same chain forward, loss, dgrad chain with W^T images; activations/deltas go to HBM once in
+//     neuron-major fp16 so that the weight gradients are split-K MFMA GEMMs with a fixed-order slab reduction
+//     (bitwise reproducible; no float atomics).
+#include "nrc_mlp.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace nrc {
+
+using half_t = _Float16;
+using half8 = _Float16 __attribute__((ext_vector_type(8)));
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int ENC = 80;          // Frequency-12 x 3 dims (72) + OneBlob-4 x 2 dims (8)
+constexpr int WIDTH = 64;
+constexpr int KS0 = ENC / 16;    // k-steps of layer 0
+constexpr int KSH = WIDTH / 16;  // k-steps of a hidden layer
+constexpr int MT = WIDTH / 32;   // 32-row M tiles per layer
+
+// canonical feature index held by (k-step s, lane half h, element j) of the layer-0 B operand.
+// s<4: natural order 16s+8h+j = four (sin,cos) pairs of one (dim, frequency quad);
+// s=4: both lane halves get two (sin,cos) pairs of dim 2 and the four OneBlob bins of ONE direction dim,
+//      so the two halves of a wave execute the same instruction stream.
+__host__ __device__ inline int fmap80(int s, int h, int j)
+{
+    if (s < 4) return 16 * s + 8 * h + j;
+    if (j < 4) return 64 + 4 * h + j;
+    return 72 + 4 * h + (j - 4);
+}
+// neuron index held by (k-step s, lane half h, element j) when a 32x32 accumulator pair is re-used as B operand
+__host__ __device__ inline int kperm(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+__device__ __forceinline__ half8 ld_frag(const uint4* lw, int frag, int lane)
+{
+    uint4 v = lw[frag * 64 + lane];
+    return __builtin_bit_cast(half8, v);
+}
+
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+
+// ReLU + round-to-nearest-even fp16: accumulator registers 0..7 -> lo, 8..15 -> hi
+__device__ __forceinline__ void relu_pack(const f32x16& acc, half8& lo, half8& hi)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        lo[j] = (half_t)fmaxf(acc[j], 0.0f);
+        hi[j] = (half_t)fmaxf(acc[8 + j], 0.0f);
+    }
+}
+
+// tiny-cuda-nn one_blob quartic kernel CDF (radius 1/4): fminf(fmaxf(.,0),1) maps NaN to 0
+__device__ __forceinline__ float quartic_cdf4(float x)
+{
+    float u = x * 4.0f;
+    float u2 = u * u;
+    float u4 = u2 * u2;
+    float p = (15.0f / 16.0f) * u * ((1.0f - (2.0f / 3.0f) * u2) + (1.0f / 5.0f) * u4) + 0.5f;
+    return fminf(fmaxf(p, 0.0f), 1.0f);
+}
+
+// Input encoding of one sample straight into the five layer-0 B-operand fragments of this lane.
+// Frequency: sin(2^f*pi*x + s*pi/2) = v_sin/v_cos(fract(x * 2^(f-1))) (hardware takes revolutions; the
+// reduction x*2^(f-1) -> fract is exact in fp32, which defines the value for the large arguments of quirk Q3).
+__device__ __forceinline__ void encode80(const float (&x)[5], int h, half8 (&b)[KS0])
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int g0 = 2 * s, g1 = 2 * s + 1;                       // feature groups of the two lane halves
+        const float xv = h ? x[g1 / 3] : x[g0 / 3];
+        const float sc = h ? (float)(1 << (4 * (g1 % 3))) * 0.5f : (float)(1 << (4 * (g0 % 3))) * 0.5f;
+        float t = xv * sc;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float rev = __builtin_amdgcn_fractf(t);
+            b[s][2 * i] = (half_t)__builtin_amdgcn_sinf(rev);
+            b[s][2 * i + 1] = (half_t)__builtin_amdgcn_cosf(rev);
+            t = t + t;
+        }
+    }
+    {
+        float t = x[2] * (h ? 512.0f : 128.0f);                     // f = 10,11 | 8,9
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float rev = __builtin_amdgcn_fractf(t);
+            b[4][2 * i] = (half_t)__builtin_amdgcn_sinf(rev);
+            b[4][2 * i + 1] = (half_t)__builtin_amdgcn_cosf(rev);
+            t = t + t;
+        }
+        const float xd = h ? x[4] : x[3];
+        float cdf[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            float bx = (float)k * 0.25f - xd;
+            cdf[k] = (quartic_cdf4(bx) + quartic_cdf4(bx - 1.0f)) + quartic_cdf4(bx + 1.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
+            b[4][4 + k] = (half_t)(right - cdf[k]);
+        }
+    }
+}
+
+// fragment bases inside the forward image
+constexpr int FRAG_L0 = 0;                       // [mt][s]      MT*KS0
+constexpr int FRAG_HID = MT * KS0;               // [l-1][mt][s] (depth-1)*MT*KSH
+__host__ __device__ constexpr int frag_out(int depth) { return FRAG_HID + (depth - 1) * MT * KSH; }   // [s] KSH
+__host__ __device__ constexpr int n_frag_fwd(int depth) { return frag_out(depth) + KSH; }
+// backward image: hidden l=1..depth-1 [l-1][mt][s], then out [mt]
+__host__ __device__ constexpr int n_frag_bwd(int depth) { return (depth - 1) * MT * KSH + MT; }
+
+template <int DEPTH, bool KEEP>
+struct FwdState {
+    half8 enc[KS0];
+    half8 act[KEEP ? DEPTH : 1][KSH];
+};
+
+// forward chain for one 32-sample tile; returns the output-layer accumulator (rows 0..2 = RGB on lanes h==0)
+template <int DEPTH, bool KEEP>
+__device__ __forceinline__ f32x16 forward_tile(const uint4* lw, int lane, FwdState<DEPTH, KEEP>& st)
+{
+    f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+    for (int s = 0; s < KS0; s++) {
+        acc0 = mfma(ld_frag(lw, FRAG_L0 + 0 * KS0 + s, lane), st.enc[s], acc0);
+        acc1 = mfma(ld_frag(lw, FRAG_L0 + 1 * KS0 + s, lane), st.enc[s], acc1);
+    }
+    half8 b[KSH];
+    relu_pack(acc0, b[0], b[1]);
+    relu_pack(acc1, b[2], b[3]);
+    if (KEEP) {
+#pragma unroll
+        for (int s = 0; s < KSH; s++) st.act[0][s] = b[s];
+    }
+#pragma unroll
+    for (int l = 1; l < DEPTH; l++) {
+        acc0 = zero16();
+        acc1 = zero16();
+        const int base = FRAG_HID + (l - 1) * MT * KSH;
+#pragma unroll
+        for (int s = 0; s < KSH; s++) {
+            acc0 = mfma(ld_frag(lw, base + s, lane), b[s], acc0);
+            acc1 = mfma(ld_frag(lw, base + KSH + s, lane), b[s], acc1);
+        }
+        relu_pack(acc0, b[0], b[1]);
+        relu_pack(acc1, b[2], b[3]);
+        if (KEEP) {
+#pragma unroll
+            for (int s = 0; s < KSH; s++) st.act[l][s] = b[s];
+        }
+    }
+    f32x16 y = zero16();
+#pragma unroll
+    for (int s = 0; s < KSH; s++) y = mfma(ld_frag(lw, frag_out(DEPTH) + s, lane), b[s], y);
+    return y;
+}
+
+__device__ __forceinline__ void stage_lds(uint4* dst, const uint4* src, int n16, int tid, int nthreads)
+{
+    for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ inference
+// persistent workgroups; one 32-sample tile per wave per iteration
+template <int DEPTH, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
+                                                  const uint4* __restrict__ image)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* lw = reinterpret_cast<uint4*>(smem);
+    stage_lds(lw, image, n_frag_fwd(DEPTH) * 64, threadIdx.x, THREADS);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = (n + 31u) >> 5;
+    const uint32_t stride = gridDim.x * (THREADS / 64);
+    for (uint32_t tile = blockIdx.x * (THREADS / 64) + wave; tile < n_tiles; tile += stride) {
+        // the weight image in LDS is loop invariant: keep hipcc from hoisting all 54 fragments (216 VGPRs) out of
+        // the tile loop -- fragments are meant to be re-read from LDS, one ds_read_b128 per MFMA
+        asm volatile("" ::: "memory");
+        const uint32_t sidx = tile * 32u + r;
+        const bool valid = sidx < n;
+        const float* p = in + (size_t)(valid ? sidx : n - 1u) * 5u;
+        float x[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) x[i] = p[i];
+        FwdState<DEPTH, false> st;
+        encode80(x, h, st.enc);
+        f32x16 y = forward_tile<DEPTH, false>(lw, lane, st);
+        if (valid && h == 0) {
+            float* o = out + (size_t)sidx * 3u;
+            o[0] = y[0];
+            o[1] = y[1];
+            o[2] = y[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ training: fwd + loss + dgrad
+struct TrainArgs {
+    const float* in;
+    const float* target;
+    uint32_t n;
+    float inv_n_total;    // 1 / (3 * n_norm)
+    uint32_t loss_id;
+    half_t* acts;         // [n/8][ENC + DEPTH*WIDTH][8]   (row = feature / neuron; 8 consecutive samples contiguous)
+    half_t* deltas;       // [n/8][DEPTH*WIDTH + 8][8]
+    float* loss_part;     // [n/32]
+};
+
+template <int DEPTH, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const uint4* __restrict__ img_fwd,
+                                                          const uint4* __restrict__ img_bwd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* lw = reinterpret_cast<uint4*>(smem);
+    uint4* lb = lw + n_frag_fwd(DEPTH) * 64;
+    stage_lds(lw, img_fwd, n_frag_fwd(DEPTH) * 64, threadIdx.x, THREADS);
+    stage_lds(lb, img_bwd, n_frag_bwd(DEPTH) * 64, threadIdx.x, THREADS);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = a.n >> 5;               // host guarantees n % 32 == 0
+    const uint32_t stride = gridDim.x * (THREADS / 64);
+    for (uint32_t tile = blockIdx.x * (THREADS / 64) + wave; tile < n_tiles; tile += stride) {
+        asm volatile("" ::: "memory");   // see k_infer: no hoisting of LDS fragment reads
+        const uint32_t sidx = tile * 32u + r;
+        const float* p = a.in + (size_t)sidx * 5u;
+        float x[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) x[i] = p[i];
+        FwdState<DEPTH, true> st;
+        encode80(x, h, st.enc);
+        f32x16 y = forward_tile<DEPTH, true>(lw, lane, st);
+
+        // ---- activations -> HBM in [sample/8][row][8] order: the 16-byte k-groups the weight-gradient GEMM reads;
+        //      row offsets are compile-time immediates on two per-lane bases (+8h / +4h rows)
+        constexpr int ROWS_A = ENC + DEPTH * WIDTH;
+        constexpr int ROWS_D = DEPTH * WIDTH + 8;
+        half_t* const pa = a.acts + ((size_t)(sidx >> 3) * ROWS_A) * 8 + (sidx & 7u);
+        half_t* const pa8 = pa + 64 * h;      // rows + 8h
+        half_t* const pa4 = pa + 32 * h;      // rows + 4h
+#pragma unroll
+        for (int s = 0; s < KS0; s++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (s < 4) pa8[(16 * s + j) * 8] = st.enc[s][j];
+                else pa4[(j < 4 ? 64 + j : 72 + (j - 4)) * 8] = st.enc[s][j];
+            }
+#pragma unroll
+        for (int l = 0; l < DEPTH; l++)
+#pragma unroll
+            for (int s = 0; s < KSH; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    pa4[(ENC + WIDTH * l + kperm(s, 0, j)) * 8] = st.act[l][s][j];
+        half_t* const pd = a.deltas + ((size_t)(sidx >> 3) * ROWS_D) * 8 + (sidx & 7u);
+        half_t* const pd4 = pd + 32 * h;
+
+        // ---- loss + dL/dy (lanes h==0 hold y); tiny-cuda-nn RelativeL2Luminance / L2 / RelativeL2
+        float loss_v = 0.0f;
+        half8 bo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
+        if (h == 0) {
+            const float* t = a.target + (size_t)sidx * 3u;
+            float yv[3] = {y[0], y[1], y[2]};
+            float den[3];
+            if (a.loss_id == 0u) {
+                float lum = (0.299f * yv[0] + 0.587f * yv[1]) + 0.114f * yv[2];
+                den[0] = den[1] = den[2] = lum * lum + 0.01f;
+            } else if (a.loss_id == 1u) {
+                den[0] = den[1] = den[2] = 1.0f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) den[c] = yv[c] * yv[c] + 0.01f;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float d = yv[c] - t[c];
+                loss_v += d * d / den[c] * a.inv_n_total;
+                float dy = Mlp::kLossScale * (2.0f * d / den[c] * a.inv_n_total);
+                bo[c] = (half_t)dy;
+                pd[(DEPTH * WIDTH + c) * 8] = bo[c];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
+        if (lane == 0) a.loss_part[tile] = loss_v;
+
+        // ---- dgrad chain: delta_{l-1} = relu'(a_{l-1}) * (W_l^T delta_l)
+        const int bout = (DEPTH - 1) * MT * KSH;
+        f32x16 d0 = mfma(ld_frag(lb, bout + 0, lane), bo, zero16());
+        f32x16 d1 = mfma(ld_frag(lb, bout + 1, lane), bo, zero16());
+#pragma unroll
+        for (int l = DEPTH - 1; l >= 0; l--) {
+            half8 dl[KSH];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                dl[0][j] = (st.act[l][0][j] > (half_t)0.0f) ? (half_t)d0[j] : (half_t)0.0f;
+                dl[1][j] = (st.act[l][1][j] > (half_t)0.0f) ? (half_t)d0[8 + j] : (half_t)0.0f;
+                dl[2][j] = (st.act[l][2][j] > (half_t)0.0f) ? (half_t)d1[j] : (half_t)0.0f;
+                dl[3][j] = (st.act[l][3][j] > (half_t)0.0f) ? (half_t)d1[8 + j] : (half_t)0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < KSH; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    pd4[(WIDTH * l + kperm(s, 0, j)) * 8] = dl[s][j];
+            if (l > 0) {
+                d0 = zero16();
+                d1 = zero16();
+                const int base = (l - 1) * MT * KSH;
+#pragma unroll
+                for (int s = 0; s < KSH; s++) {
+                    d0 = mfma(ld_frag(lb, base + s, lane), dl[s], d0);
+                    d1 = mfma(ld_frag(lb, base + KSH + s, lane), dl[s], d1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ training: weight gradients
+// dW_l = delta_l (rows: out neurons, k: samples) * a_{l-1}^T.  One workgroup per K-chunk of samples, one 32x32
+// output tile per wave iteration, partial result to this chunk's slab (fixed-order reduction afterwards).
+struct WgradTile {
+    uint32_t a_row0, b_row0, m_valid, n_valid, param_off, in_dim;
+};
+constexpr int WGRAD_WAVES = 7;
+constexpr uint32_t WGRAD_CHUNK = 128;
+
+__global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __restrict__ deltas,
+                                                           const half_t* __restrict__ acts, uint32_t n,
+                                                           uint32_t rows_d, uint32_t rows_a,
+                                                           const WgradTile* __restrict__ tiles, int n_tiles,
+                                                           float* __restrict__ slabs, uint32_t n_params)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t k0 = blockIdx.x * WGRAD_CHUNK;
+    const uint32_t left = n - k0;
+    const int ksteps = (int)((left < WGRAD_CHUNK ? left : WGRAD_CHUNK) >> 4);
+    float* slab = slabs + (size_t)blockIdx.x * n_params;
+    half8 zero;
+#pragma unroll
+    for (int j = 0; j < 8; j++) zero[j] = (half_t)0.0f;
+    for (int t = wave; t < n_tiles; t += WGRAD_WAVES) {
+        const WgradTile T = tiles[t];
+        const bool av = (uint32_t)r < T.m_valid, bv = (uint32_t)r < T.n_valid;
+        // operand k-groups: [sample/8][rows][8]; lane (r,h) reads row r of group 2s+h -> 512 contiguous bytes per half wave
+        const half_t* ap = deltas + ((size_t)((k0 >> 3) + h) * rows_d + T.a_row0 + (av ? r : 0)) * 8;
+        const half_t* bp = acts + ((size_t)((k0 >> 3) + h) * rows_a + T.b_row0 + (bv ? r : 0)) * 8;
+        f32x16 acc = zero16();
+#pragma unroll 4
+        for (int s = 0; s < ksteps; s++) {
+            half8 av8 = *reinterpret_cast<const half8*>(ap + (size_t)s * (16 * rows_d));
+            half8 bv8 = *reinterpret_cast<const half8*>(bp + (size_t)s * (16 * rows_a));
+            acc = mfma(av ? av8 : zero, bv ? bv8 : zero, acc);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const uint32_t row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < T.m_valid && bv) slab[T.param_off + row * T.in_dim + r] = acc[reg];
+        }
+    }
+}
+
+// grad[i] = sum over chunk slabs in chunk order (bitwise reproducible); block 0 also folds the loss partials
+__global__ void k_reduce_grads(const float* __restrict__ slabs, uint32_t n_chunks, uint32_t n_params,
+                               float* __restrict__ grad, const float* __restrict__ loss_part, uint32_t n_loss,
+                               float* __restrict__ loss)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_params) {
+        float s = 0.0f;
+        for (uint32_t c = 0; c < n_chunks; c++) s += slabs[(size_t)c * n_params + i];
+        grad[i] = s;
+    }
+    if (blockIdx.x == 0) {
+        __shared__ float red[256];
+        float s = 0.0f;
+        for (uint32_t k = threadIdx.x; k < n_loss; k += blockDim.x) s += loss_part[k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { loss[0] = red[0]; loss[1] = 0.0f; }
+    }
+}
+
+// EMA{Adam} (tiny-cuda-nn defaults: beta1 .9, beta2 .999, eps 1e-8, l2_reg 1e-8), SURVEY App. B
+struct AdamArgs {
+    float lr_t, inv_loss_scale, ema_old, ema_new, ema_div;
+};
+__global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
+                           float* __restrict__ v, const float* __restrict__ grad, uint32_t n, AdamArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, l2 = 1e-8f;
+    float wi = w[i];
+    float g = grad[i] * a.inv_loss_scale + l2 * wi;
+    float mi = b1 * m[i] + (1.0f - b1) * g;
+    float vi = b2 * v[i] + (1.0f - b2) * (g * g);
+    m[i] = mi;
+    v[i] = vi;
+    wi = wi - a.lr_t * mi / (sqrtf(vi) + eps);
+    w[i] = wi;
+    ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+}
+
+// fragment images from the canonical fp32 vectors
+__global__ void k_pack(const float* __restrict__ w, const float* __restrict__ ema, const int32_t* __restrict__ src_fwd,
+                       uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd, half_t* __restrict__ pk_infer,
+                       half_t* __restrict__ pk_fwd, half_t* __restrict__ pk_bwd)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_fwd) {
+        const int32_t s = src_fwd[i];
+        pk_infer[i] = s < 0 ? (half_t)0.0f : (half_t)ema[s];
+        pk_fwd[i] = s < 0 ? (half_t)0.0f : (half_t)w[s];
+    }
+    if (i < n_bwd) {
+        const int32_t s = src_bwd[i];
+        pk_bwd[i] = s < 0 ? (half_t)0.0f : (half_t)w[s];
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ host
+Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
+{
+    width_ = cfg.nn_width;
+    depth_ = cfg.nn_depth;
+    if (cfg.pos_id != 3 || cfg.dir_id != 0)
+        fail("this build fuses only the Frequency(12) + OneBlob(4) input encoding (posID 3, dirID 0)");
+    if (width_ != 64 || depth_ != 6) fail("this build supports nnWidth 64 / nnDepth 6 (got " + std::to_string(width_) + "/" + std::to_string(depth_) + ")");
+    if (std::strcmp(cfg.optimizer, "Adam") != 0) fail(std::string("unsupported optimizer ") + cfg.optimizer);
+    if (std::strcmp(cfg.loss_fn, "RelativeL2Luminance") == 0) loss_id_ = 0;
+    else if (std::strcmp(cfg.loss_fn, "L2") == 0) loss_id_ = 1;
+    else if (std::strcmp(cfg.loss_fn, "RelativeL2") == 0) loss_id_ = 2;
+    else fail(std::string("unsupported loss ") + cfg.loss_fn);
+    enc_dims_ = ENC;
+
+    uint32_t off = 0;
+    for (uint32_t l = 0; l <= depth_; l++) {
+        MlpLayer L;
+        L.in = l == 0 ? enc_dims_ : width_;
+        L.out = l == depth_ ? 3u : width_;
+        L.off = off;
+        off += L.in * L.out;
+        layers_.push_back(L);
+    }
+    n_params_ = off;
+
+    // Xavier-uniform init from pcg32(seed) -- same stream as the oracle's statement of the spec
+    std::vector<float> w(n_params_);
+    Pcg32 rng;
+    rng.seed(cfg.seed, 0);
+    for (const MlpLayer& L : layers_) {
+        const float scale = sqrtf(6.0f / (float)(L.in + L.out));
+        for (uint32_t i = 0; i < L.in * L.out; i++) w[L.off + i] = (rng.nextf() * 2.0f - 1.0f) * scale;
+    }
+
+    const size_t pb = (size_t)n_params_ * sizeof(float);
+    NRC_HIP(hipMalloc(&d_w_, pb));
+    NRC_HIP(hipMalloc(&d_ema_, pb));
+    NRC_HIP(hipMalloc(&d_m_, pb));
+    NRC_HIP(hipMalloc(&d_v_, pb));
+    NRC_HIP(hipMalloc(&d_grad_, pb));
+    NRC_HIP(hipMalloc(&d_loss_, 4 * sizeof(float)));
+    NRC_HIP(hipMemcpy(d_w_, w.data(), pb, hipMemcpyHostToDevice));
+    NRC_HIP(hipMemcpy(d_ema_, w.data(), pb, hipMemcpyHostToDevice));
+    NRC_HIP(hipMemset(d_m_, 0, pb));
+    NRC_HIP(hipMemset(d_v_, 0, pb));
+    NRC_HIP(hipMemset(d_grad_, 0, pb));
+    NRC_HIP(hipMemset(d_loss_, 0, 4 * sizeof(float)));
+
+    // fragment-image gather tables
+    const int D = (int)depth_;
+    n_frag_fwd_ = (uint32_t)n_frag_fwd(D);
+    n_frag_bwd_ = (uint32_t)n_frag_bwd(D);
+    std::vector<int32_t> sf((size_t)n_frag_fwd_ * 512, -1), sb((size_t)n_frag_bwd_ * 512, -1);
+    auto slot = [](int frag, int lane, int j) { return ((size_t)frag * 64 + lane) * 8 + j; };
+    for (int lane = 0; lane < 64; lane++) {
+        const int r = lane & 31, h = lane >> 5;
+        for (int j = 0; j < 8; j++) {
+            for (int mt = 0; mt < MT; mt++) {
+                for (int s = 0; s < KS0; s++)
+                    sf[slot(FRAG_L0 + mt * KS0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + r) * ENC + fmap80(s, h, j));
+                for (int l = 1; l < D; l++)
+                    for (int s = 0; s < KSH; s++) {
+                        sf[slot(FRAG_HID + (l - 1) * MT * KSH + mt * KSH + s, lane, j)] =
+                            (int32_t)(layers_[l].off + (32 * mt + r) * WIDTH + kperm(s, h, j));
+                        sb[slot((l - 1) * MT * KSH + mt * KSH + s, lane, j)] =
+                            (int32_t)(layers_[l].off + kperm(s, h, j) * WIDTH + (32 * mt + r));
+                    }
+                const int k = 8 * h + j;
+                if (k < 3) sb[slot((D - 1) * MT * KSH + mt, lane, j)] = (int32_t)(layers_[D].off + k * WIDTH + (32 * mt + r));
+            }
+            for (int s = 0; s < KSH; s++)
+                if (r < 3) sf[slot(frag_out(D) + s, lane, j)] = (int32_t)(layers_[D].off + r * WIDTH + kperm(s, h, j));
+        }
+    }
+    NRC_HIP(hipMalloc(&d_src_fwd_, sf.size() * 4));
+    NRC_HIP(hipMalloc(&d_src_bwd_, sb.size() * 4));
+    NRC_HIP(hipMemcpy(d_src_fwd_, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
+    NRC_HIP(hipMemcpy(d_src_bwd_, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
+    NRC_HIP(hipMalloc(&d_pk_infer_, sf.size() * 2));
+    NRC_HIP(hipMalloc(&d_pk_fwd_, sf.size() * 2));
+    NRC_HIP(hipMalloc(&d_pk_bwd_, sb.size() * 2));
+    repack(nullptr);
+    NRC_HIP(hipStreamSynchronize(nullptr));
+}
+
+Mlp::~Mlp()
+{
+    void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_loss_, d_pk_infer_, d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
+                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+float* Mlp::buffer(int which)
+{
+    switch (which) {
+    case 0: return d_w_;
+    case 1: return d_ema_;
+    case 2: return d_m_;
+    case 3: return d_v_;
+    case 4: return d_grad_;
+    default: fail("bad parameter buffer id");
+    }
+}
+
+void Mlp::repack(hipStream_t s)
+{
+    const uint32_t nf = n_frag_fwd_ * 512, nb = n_frag_bwd_ * 512;
+    const uint32_t nmax = nf > nb ? nf : nb;
+    hipLaunchKernelGGL(k_pack, dim3(ceil_div(nmax, 256)), dim3(256), 0, s, d_w_, d_ema_, d_src_fwd_, nf, d_src_bwd_, nb,
+                       (half_t*)d_pk_infer_, (half_t*)d_pk_fwd_, (half_t*)d_pk_bwd_);
+    NRC_HIP(hipGetLastError());
+}
+
+static int g_num_cus = 0;
+static int num_cus()
+{
+    if (g_num_cus == 0) {
+        int dev = 0;
+        NRC_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        NRC_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_num_cus;
+}
+
+void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s)
+{
+    if (n == 0) return;
+    constexpr int THREADS = 512;   // 8 waves share one 54 KB weight image; 2 workgroups per CU
+    const uint32_t n_tiles = ceil_div(n, 32);
+    const uint32_t max_blocks = (uint32_t)num_cus() * 2u;
+    uint32_t blocks = ceil_div(n_tiles, THREADS / 64);
+    if (blocks > max_blocks) blocks = max_blocks;
+    const size_t lds = (size_t)n_frag_fwd_ * 1024;
+    const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
+    hipLaunchKernelGGL((k_infer<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img);
+    NRC_HIP(hipGetLastError());
+}
+
+void Mlp::ensure_train_workspace(uint32_t n)
+{
+    if (n <= ws_n_) return;
+    if (d_acts_) (void)hipFree(d_acts_);
+    if (d_deltas_) (void)hipFree(d_deltas_);
+    if (d_slabs_) (void)hipFree(d_slabs_);
+    if (d_loss_part_) (void)hipFree(d_loss_part_);
+    d_acts_ = d_deltas_ = nullptr;
+    d_slabs_ = d_loss_part_ = nullptr;
+    const size_t rows_a = ENC + (size_t)depth_ * WIDTH, rows_d = (size_t)depth_ * WIDTH + 8;
+    NRC_HIP(hipMalloc(&d_acts_, rows_a * n * 2));
+    NRC_HIP(hipMalloc(&d_deltas_, rows_d * n * 2));
+    NRC_HIP(hipMemset(d_deltas_, 0, rows_d * n * 2));
+    NRC_HIP(hipMalloc(&d_slabs_, (size_t)ceil_div(n, WGRAD_CHUNK) * n_params_ * 4));
+    NRC_HIP(hipMalloc(&d_loss_part_, (size_t)(n / 32) * 4));
+    ws_n_ = n;
+    if (!d_tiles_) {
+        std::vector<WgradTile> tiles;
+        const uint32_t D = depth_;
+        for (uint32_t l = 0; l <= D; l++) {
+            const MlpLayer& L = layers_[l];
+            const uint32_t a_rows = l == D ? D * WIDTH : l * WIDTH;           // delta_l rows
+            const uint32_t b_rows = l == 0 ? 0 : ENC + (l - 1) * WIDTH;       // a_{l-1} rows (enc for l = 0)
+            for (uint32_t mt = 0; mt * 32 < L.out; mt++)
+                for (uint32_t nt = 0; nt * 32 < L.in; nt++) {
+                    WgradTile T;
+                    T.a_row0 = a_rows + 32 * mt;
+                    T.b_row0 = b_rows + 32 * nt;
+                    T.m_valid = L.out - 32 * mt < 32 ? L.out - 32 * mt : 32;
+                    T.n_valid = L.in - 32 * nt < 32 ? L.in - 32 * nt : 32;
+                    T.param_off = L.off + 32 * mt * L.in + 32 * nt;
+                    T.in_dim = L.in;
+                    tiles.push_back(T);
+                }
+        }
+        n_wgrad_tiles_ = (int)tiles.size();
+        NRC_HIP(hipMalloc(&d_tiles_, tiles.size() * sizeof(WgradTile)));
+        NRC_HIP(hipMemcpy(d_tiles_, tiles.data(), tiles.size() * sizeof(WgradTile), hipMemcpyHostToDevice));
+    }
+}
+
+void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s)
+{
+    if (n == 0 || n % 32 != 0) fail("training batch must be a non-zero multiple of 32 samples");
+    ensure_train_workspace(n);
+    constexpr int THREADS = 256;
+    TrainArgs a;
+    a.in = d_in;
+    a.target = d_target;
+    a.n = n;
+    a.inv_n_total = 1.0f / (float)(3u * n_norm);
+    a.loss_id = loss_id_;
+    a.acts = (half_t*)d_acts_;
+    a.deltas = (half_t*)d_deltas_;
+    a.loss_part = d_loss_part_;
+    const uint32_t n_tiles = n / 32;
+    uint32_t blocks = ceil_div(n_tiles, THREADS / 64);
+    if (blocks > (uint32_t)num_cus()) blocks = (uint32_t)num_cus();
+    const size_t lds = ((size_t)n_frag_fwd_ + n_frag_bwd_) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_fwd_bwd<6, THREADS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
+                       (const uint4*)d_pk_bwd_);
+    NRC_HIP(hipGetLastError());
+    const uint32_t n_chunks = ceil_div(n, WGRAD_CHUNK);
+    hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_,
+                       (const half_t*)d_acts_, n, depth_ * WIDTH + 8, ENC + depth_ * WIDTH, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_, n_params_);
+    NRC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_slabs_, n_chunks, n_params_,
+                       d_grad_, d_loss_part_, n_tiles, d_loss_);
+    NRC_HIP(hipGetLastError());
+}
+
+void Mlp::optimizer_step(hipStream_t s)
+{
+    step += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const double t = (double)step;
+    const double d = (double)cfg_.ema_decay;
+    AdamArgs a;
+    a.lr_t = cfg_.learning_rate * (float)(std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t)));
+    a.inv_loss_scale = 1.0f / kLossScale;
+    a.ema_old = (float)(d * (1.0 - std::pow(d, t - 1.0)));
+    a.ema_new = (float)(1.0 - d);
+    a.ema_div = (float)(1.0 - std::pow(d, t));
+    hipLaunchKernelGGL(k_adam_ema, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_,
+                       n_params_, a);
+    NRC_HIP(hipGetLastError());
+    repack(s);
+}
+
+}  // namespace nrc

@@ -1,0 +1,64 @@
+// nrc_mlp.hpp -- the neural radiance cache arithmetic on gfx950: fused input encoding + fully fused MLP
+// (inference), forward+loss+backward, split-K weight gradients, EMA{Adam}.  Replaces what the reference gets
+// from tiny-cuda-nn v1.6 through tcnn::create_from_config / network->inference / trainer->training_step
+// (src/NeuralRadianceCache.cu:16-39,142,153-154).
+#pragma once
+#include <vector>
+
+#include "nrc_common.hpp"
+
+namespace nrc {
+
+struct MlpLayer {
+    uint32_t out, in;
+    uint32_t off;   // offset into the canonical fp32 parameter vector ([out][in] row-major)
+};
+
+class Mlp {
+public:
+    explicit Mlp(const nrc_config& cfg);
+    ~Mlp();
+    Mlp(const Mlp&) = delete;
+    Mlp& operator=(const Mlp&) = delete;
+
+    // network->inference: y = MLP_ema(encode(x)); in [n][5], out [n][3] (device, fp32)
+    void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s);
+    // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
+    void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s);
+    // EMA{Adam} step + re-pack of the fp16 MFMA fragment images
+    void optimizer_step(hipStream_t s);
+    void repack(hipStream_t s);
+
+    uint32_t n_params() const { return n_params_; }
+    uint32_t enc_dims() const { return enc_dims_; }
+    float* grad_ptr() { return d_grad_; }
+    float* loss_ptr() { return d_loss_; }
+    float* buffer(int which);    // 0 w, 1 ema, 2 m, 3 v, 4 grad
+    uint32_t step = 0;
+    static constexpr float kLossScale = 128.0f;
+
+private:
+    void ensure_train_workspace(uint32_t n);
+
+    nrc_config cfg_;
+    uint32_t width_, depth_, enc_dims_, n_params_;
+    uint32_t loss_id_;
+    std::vector<MlpLayer> layers_;
+
+    float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
+    // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)
+    void *d_pk_infer_ = nullptr, *d_pk_fwd_ = nullptr, *d_pk_bwd_ = nullptr;
+    int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)
+    uint32_t n_frag_fwd_ = 0, n_frag_bwd_ = 0;
+
+    // training workspace
+    uint32_t ws_n_ = 0;
+    void* d_acts_ = nullptr;     // fp16 [enc + depth*width][n]   (transposed: neuron-major)
+    void* d_deltas_ = nullptr;   // fp16 [depth*width + 32][n]
+    float* d_slabs_ = nullptr;   // fp32 [n_chunks][n_params]
+    float* d_loss_part_ = nullptr;
+    void* d_tiles_ = nullptr;    // WgradTile[] (output tiles of the weight-gradient GEMMs)
+    int n_wgrad_tiles_ = 0;
+};
+
+}  // namespace nrc
