@@ -92,7 +92,8 @@ int nrc_cache_backward(nrc_cache_t* c, const float* d_input, const float* d_targ
 /* optimizer step (EMA{Adam}) from the gradient vector */
 int nrc_cache_optimizer_step(nrc_cache_t* c);
 /* device pointer / length of the fp32 gradient vector (sum over the local batch, times loss_scale 128) and of the
- * 2-float {loss, unused} cell: the multi-GPU driver all-reduces these between backward and optimizer_step */
+ * 2-float {loss, unused} cell, which directly follows the gradient vector in memory (loss_ptr == grad_ptr +
+ * param_count): the multi-GPU driver all-reduces param_count + 2 floats between backward and optimizer_step */
 float* nrc_cache_grad_ptr(nrc_cache_t* c);
 uint32_t nrc_cache_param_count(nrc_cache_t* c);
 float* nrc_cache_loss_ptr(nrc_cache_t* c);
@@ -168,6 +169,9 @@ int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
 /* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be
  * NULL or float[8] = {clear, gen_rays, prep_infer(0: fused), filter(0), prep_train, nrc(infer+train), render, total} */
 float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
+/* the same stage times averaged over every frame rendered since the last reset (HIP events on the render stream);
+ * *frames = number of frames covered */
+int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frames, int reset);
 /* NrcHpmRenderer::Destroy */
 int nrc_renderer_destroy(nrc_renderer_t* r);
 /* intermediate device buffers (tests / multi-GPU): 0 primary colour+throughput [h][w][4], 1 primary info [h][w],

@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "nrc_cache_get_step", "nrc_cache_set_step",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_export_exr",
-    "nrc_renderer_frame_time_ms", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
+    "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
     "nrc_renderer_train_grid",
     "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
     "nrc_mc_renderer_set_frame_random", "nrc_mc_renderer_framebuffer", "nrc_mc_renderer_export_exr",
@@ -390,6 +390,16 @@ class NrcHpmRenderer:
         self.L.nrc_renderer_frame_time_ms(self.h, st)
         names = ("clear", "gen_rays", "prep_infer", "filter", "prep_train", "nrc", "render", "total")
         return dict(zip(names, [float(x) for x in st]))
+
+    def StageStats(self, reset=True):
+        """average per-stage ms over all frames since the last reset (HIP events on the render stream)"""
+        st = (C.c_float * 8)()
+        n = C.c_uint32(0)
+        _check(self.L.nrc_renderer_stage_stats(self.h, st, C.byref(n), C.c_int(int(reset))))
+        names = ("clear", "gen_rays", "prep_infer", "filter", "prep_train", "nrc", "render", "total")
+        d = dict(zip(names, [float(x) for x in st]))
+        d["frames"] = n.value
+        return d
 
     def GetImage(self):
         """RGBA32F framebuffer as a torch CUDA tensor view [height, width, 4]."""

@@ -6,6 +6,7 @@
 //   nrc::McRenderer  <- en::McHpmRenderer         (src/McHpmRenderer.cpp:81-151,432-449)
 // One instance per GPU and stream; no hidden globals (SURVEY.md 8b "Threading").
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -246,18 +247,28 @@ public:
         std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
         for (size_t r = 0; r < ring_entries_; r++) { float one = 1.0f; std::memcpy(&ring[2 + 6 * r + 5], &one, 4); }
         NRC_HIP(hipMemcpy(d_ring_, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
-        for (auto& e : ev_) NRC_HIP(hipEventCreate(&e));
         cache_.init((uint32_t)px, (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_, (float*)d_train_target_, s);
     }
 
     ~Renderer()
     {
         for (void* p : allocs_) (void)hipFree(p);
-        for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+        for (auto& set : ev_pool_)
+            for (auto& e : set) if (e) (void)hipEventDestroy(e);
     }
 
     void render(bool train)      // NrcHpmRenderer::Render, :299-353
     {
+        // one event quintuple per frame since the last stats reset (the reference has 8 Vulkan timestamp queries, :495-515)
+        if (ev_used_ == ev_pool_.size()) {
+            if (ev_pool_.size() >= 4096) ev_used_ = 0;      // wrap: statistics then cover the most recent frames only
+            else {
+                std::array<hipEvent_t, 5> set{};
+                for (auto& e : set) NRC_HIP(hipEventCreate(&e));
+                ev_pool_.push_back(set);
+            }
+        }
+        hipEvent_t* ev_ = ev_pool_[ev_used_++].data();
         const float blend_factor = 1.0f / (float)blend_index_;
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
@@ -305,9 +316,31 @@ public:
         return v;
     }
 
+    // average stage times over the frames rendered since the last reset; returns the number of frames
+    uint32_t stage_stats(float* avg8, bool reset)
+    {
+        const size_t n = ev_used_;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n > 0) NRC_HIP(hipEventSynchronize(ev_pool_[n - 1][4]));
+        for (size_t f = 0; f < n; f++) {
+            hipEvent_t* e = ev_pool_[f].data();
+            float gen = 0, prep = 0, nrc = 0, comp = 0, total = 0;
+            NRC_HIP(hipEventElapsedTime(&gen, e[0], e[1]));
+            NRC_HIP(hipEventElapsedTime(&prep, e[1], e[2]));
+            NRC_HIP(hipEventElapsedTime(&nrc, e[2], e[3]));
+            NRC_HIP(hipEventElapsedTime(&comp, e[3], e[4]));
+            NRC_HIP(hipEventElapsedTime(&total, e[0], e[4]));
+            acc[1] += gen; acc[4] += prep; acc[5] += nrc; acc[6] += comp; acc[7] += total;
+        }
+        if (avg8) for (int k = 0; k < 8; k++) avg8[k] = n ? (float)(acc[k] / (double)n) : 0.0f;
+        if (reset) { ev_used_ = 0; timed_ = false; }
+        return (uint32_t)n;
+    }
+
     float frame_time_ms(float* stage)       // EvaluateTimestampQueries / GetFrameTimeMS, :495-530
     {
-        if (!timed_) return 0.0f;
+        if (!timed_ || ev_used_ == 0) return 0.0f;
+        hipEvent_t* ev_ = ev_pool_[ev_used_ - 1].data();
         NRC_HIP(hipEventSynchronize(ev_[4]));
         float gen = 0, prep = 0, nrc = 0, comp = 0, total = 0;
         NRC_HIP(hipEventElapsedTime(&gen, ev_[0], ev_[1]));
@@ -394,7 +427,8 @@ private:
     void *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
     void *d_ring_ = nullptr, *d_scratch_ = nullptr, *d_fetch_ = nullptr;
     std::vector<void*> allocs_;
-    hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::array<hipEvent_t, 5>> ev_pool_;
+    size_t ev_used_ = 0;
     bool timed_ = false;
     float pinned_random_[4] = {0, 0, 0, 0};
     bool have_pinned_random_ = false;
@@ -649,6 +683,11 @@ float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms)
     float v = -1.0f;
     if (r) guarded([&] { v = r->impl.frame_time_ms(stage_ms); });
     return v;
+}
+int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frames, int reset)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { uint32_t n = r->impl.stage_stats(avg_ms, reset != 0); if (frames) *frames = n; });
 }
 int nrc_renderer_destroy(nrc_renderer_t* r)
 {

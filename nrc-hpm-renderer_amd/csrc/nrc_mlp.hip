@@ -505,14 +505,14 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     NRC_HIP(hipMalloc(&d_ema_, pb));
     NRC_HIP(hipMalloc(&d_m_, pb));
     NRC_HIP(hipMalloc(&d_v_, pb));
-    NRC_HIP(hipMalloc(&d_grad_, pb));
-    NRC_HIP(hipMalloc(&d_loss_, 4 * sizeof(float)));
+    // gradient vector and the {loss, pad} cell share one allocation so that the multi-GPU driver all-reduces both at once
+    NRC_HIP(hipMalloc(&d_grad_, pb + 4 * sizeof(float)));
+    d_loss_ = d_grad_ + n_params_;
     NRC_HIP(hipMemcpy(d_w_, w.data(), pb, hipMemcpyHostToDevice));
     NRC_HIP(hipMemcpy(d_ema_, w.data(), pb, hipMemcpyHostToDevice));
     NRC_HIP(hipMemset(d_m_, 0, pb));
     NRC_HIP(hipMemset(d_v_, 0, pb));
-    NRC_HIP(hipMemset(d_grad_, 0, pb));
-    NRC_HIP(hipMemset(d_loss_, 0, 4 * sizeof(float)));
+    NRC_HIP(hipMemset(d_grad_, 0, pb + 4 * sizeof(float)));
 
     // fragment-image gather tables
     const int D = (int)depth_;
@@ -553,7 +553,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 
 Mlp::~Mlp()
 {
-    void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_loss_, d_pk_infer_, d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
+    void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_, d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of the NRC-HPM path (new; the reference is single-GPU -- SURVEY.md section 8e).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Pixels are independent (the RNG seed depends
+only on the global pixel coordinate and the per-frame random, data/shader/include/random.glsl:61-64), so a frame shards
+by pixel columns with NO data-path collective: rank r renders the global columns x = r, r+N, r+2N, ... (interleaved, so
+every rank sees the same mix of cloud and empty sky).  Training has one exchange step: every rank back-propagates its
+own train rays against the GLOBAL loss normaliser, the gradient vectors (25 792 fp32 + the loss cell = 103 KB:
+latency-bound, one small all-reduce) are summed, and every rank applies the identical optimizer step, so the weight
+replicas stay bit-identical.  The train ring buffer is per rank.
+"""
+
+
+def local_width(rank, world, global_w):
+    """number of columns x in [0, global_w) with x % world == rank"""
+    return (global_w - rank + world - 1) // world
+
+
+def column_tile(rank, world, global_w, global_h):
+    """nrc_tile of include/nrc_hpm.h: (x_offset, x_stride, global_w, global_h)"""
+    return (rank, world, global_w, global_h)
+
+
+def gather_columns(local_images, global_w):
+    """inverse of the sharding, for tests: list of [h, local_w, c] arrays (rank order) -> [h, global_w, c]"""
+    import numpy as np
+    world = len(local_images)
+    h, _, c = local_images[0].shape
+    out = np.zeros((h, global_w, c), local_images[0].dtype)
+    for r, img in enumerate(local_images):
+        out[:, r::world, :] = img
+    return out
+
+
+def shard_train_batch(n_global, rank, world):
+    """contiguous slice of a global train batch owned by `rank` (tests of the gradient all-reduce)"""
+    per = n_global // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def attach_gradient_allreduce(nrc, world, group=None):
+    """Installs the exchange step of the training path on a NeuralRadianceCache: the loss normaliser becomes the global
+    batch (3 * trainBatchSize * world) and the fp32 gradient vector + loss cell are all-reduced (sum) between backward and
+    the optimizer of every train batch, on the stream the kernels run on."""
+    import torch
+    import torch.distributed as dist
+    n = nrc.ParamCount()
+    from . import api
+    both = api._wrap_device(nrc.L.nrc_cache_grad_ptr(nrc.h), (n + 2) * 4, torch.float32, (n + 2,))
+    nrc.SetLossNormFactor(world)
+
+    def hook(_grad, _loss):
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+
+    nrc.SetGradHook(hook)
+    return both
