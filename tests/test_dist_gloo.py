@@ -1,0 +1,66 @@
+"""N > 1 path on CPU (gloo, world_size 2): the training exchange step.  Each rank back-propagates its shard of a global
+batch against the GLOBAL loss normaliser; the all-reduced (summed) gradient must equal the single-process gradient of the
+whole batch, and identical optimizer steps keep the replicas identical.  The oracle plays the role of the per-rank
+arithmetic (tests may use it as the checker); the product's hook does the same all-reduce on device tensors."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nrc_hpm_renderer_amd import parallel
+    from oracle import Oracle
+    orc = Oracle()
+    nn = orc.nn_create()
+    rng = np.random.default_rng(11)
+    n = 256
+    x = rng.random((n, 5), dtype=np.float32)
+    x[:, :3] += 31.0
+    t = rng.random((n, 3), dtype=np.float32)
+    sl = parallel.shard_train_batch(n, rank, world)
+    loss_local = nn.backward(x[sl], t[sl], n_norm=n)
+    both = torch.from_numpy(np.concatenate([np.array(nn.buffer(4)), [loss_local, 0.0]]).astype(np.float32))
+    dist.all_reduce(both, op=dist.ReduceOp.SUM)          # what parallel.attach_gradient_allreduce's hook does
+    nn.buffer(4)[:] = both[:-2].numpy()
+    nn.optimizer_step()
+    w = np.array(nn.buffer(0))
+    gathered = [torch.zeros(w.size) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(w))
+    if rank == 0:
+        full = orc.nn_create()
+        loss_full = full.backward(x, t)
+        g_full = np.array(full.buffer(4))
+        full.optimizer_step()
+        q.put(dict(g_err=float(np.linalg.norm(both[:-2].numpy() - g_full) / np.linalg.norm(g_full)),
+                   loss=float(both[-2]), loss_full=loss_full,
+                   replicas_equal=bool(all(torch.equal(gathered[0], g) for g in gathered)),
+                   w_err=float(np.linalg.norm(w - np.array(full.buffer(0))) / np.linalg.norm(w))))
+    dist.destroy_process_group()
+
+
+def test_sharded_gradient_allreduce_equals_full_batch():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["g_err"] < 1e-5
+    assert abs(res["loss"] - res["loss_full"]) < 1e-5 * max(1.0, abs(res["loss_full"]))
+    assert res["replicas_equal"]
+    assert res["w_err"] < 1e-5

@@ -1,0 +1,72 @@
+"""Bit parity of the integrator's math spec and RNG between the HIP device code (csrc/nrc_math.h) and the oracle's own
+statement (oracle/orc_math.h): this is what makes per-pixel control flow reproducible (DESIGN.md "math spec")."""
+import numpy as np
+import pytest
+
+from conftest import FRAME_RANDOM
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _inputs(kind, n=200000, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "log":          # 1 - u, u in [0,1)
+        u = rng.random(n, dtype=np.float32)
+        return np.concatenate([np.float32(1.0) - u, np.array([1.0, 2.0 ** -23, 0.5, 0.70710677, 0.7071068], np.float32)])
+    if kind == "angle":        # [0, 2pi] and a bit beyond
+        return np.concatenate([rng.random(n, dtype=np.float32) * np.float32(6.2831855),
+                               np.array([0.0, 3.1415927, 6.2831855, 1.5707964, 0.7853982, 100.5, -2.5], np.float32)])
+    if kind == "unit":         # [-1.2, 1.2]: includes out-of-domain (NaN) arguments of quirk Q5
+        return np.concatenate([rng.random(n, dtype=np.float32) * np.float32(2.4) - np.float32(1.2),
+                               np.array([-1.0, 1.0, 0.0, 0.5, -0.5, 1.0000001, np.nan], np.float32)])
+    if kind == "any":
+        return (rng.standard_normal(n) * 10).astype(np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("fn,kind", [(0, "log"), (1, "angle"), (2, "unit"), (3, "unit"), (5, "unit"), (7, "log"), (8, "any")])
+def test_unary_math_bit_exact(orc, api, torch_gpu, fn, kind):
+    a = _inputs(kind)
+    ref, ref2 = orc.math_eval(fn, a)
+    out, out2 = api.test_math(fn, torch_gpu.from_numpy(a).cuda())
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
+    if fn == 1:
+        assert np.array_equal(_bits(out2.cpu().numpy()), _bits(ref2))
+
+
+@pytest.mark.parametrize("fn", [4, 6])
+def test_binary_math_bit_exact(orc, api, torch_gpu, fn):
+    a, b = _inputs("any", seed=1), _inputs("any", seed=2)
+    a[:4] = [0.0, 1.0, -1.0, 0.0]
+    b[:4] = [0.0, 0.0, 0.0, -2.0]
+    if fn == 6:
+        b[b == 0] = 1.0
+    ref, _ = orc.math_eval(fn, a, b)
+    out, _ = api.test_math(fn, torch_gpu.from_numpy(a).cuda(), torch_gpu.from_numpy(b).cuda())
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
+
+
+def test_math_spec_accuracy(orc):
+    """the spec itself is a faithful log/sin/cos/acos/atan2 (GLSL precision requirements are far looser)"""
+    a = _inputs("log")
+    assert np.abs(orc.math_eval(0, a)[0] - np.log(a.astype(np.float64))).max() < 2e-6
+    ang = _inputs("angle")[:-2]
+    s, c = orc.math_eval(1, ang)
+    assert np.abs(s - np.sin(ang.astype(np.float64))).max() < 5e-7 and np.abs(c - np.cos(ang.astype(np.float64))).max() < 5e-7
+    u = np.linspace(-1, 1, 10001, dtype=np.float32)
+    assert np.abs(orc.math_eval(2, u)[0] - np.arccos(u.astype(np.float64))).max() < 1e-6
+    y, x = _inputs("any", seed=3), _inputs("any", seed=4)
+    assert np.abs(orc.math_eval(4, y, x)[0] - np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() < 1e-6
+
+
+def test_rng_stream_on_device(orc, api, torch_gpu):
+    for (u, v) in [(0.0, 0.0), (0.5, 0.5), (0.99947923, 0.99907404), (0.123, 0.877)]:
+        ref = orc.rng_kat(u, v, FRAME_RANDOM, 64)
+        out = api.test_rng(u, v, FRAME_RANDOM, 64).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(ref))
+    out = api.test_rng(0.0, 0.0, FRAME_RANDOM, 4).cpu().numpy()
+    assert [int(b) for b in _bits(out[1:])] == [0x3E0920B8, 0x3F6DA0F8, 0x3EEA5770, 0x3E845B2C]

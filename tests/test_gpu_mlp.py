@@ -1,0 +1,237 @@
+"""Parity of the fused encode+MLP HIP kernels (inference, backward, optimizer) against the oracle, through the C ABI.
+Tolerances: MLP fp16 path vs oracle fp16-storage mode: rel-L2 <= 2e-3 on outputs; gradients rel-L2 <= 1e-2;
+weights after a step rel-L2 <= 1e-3.  (fp32 MFMA accumulation order differs from the oracle's wide accumulate, and a
+1-ulp fp16 rounding flip of an activation propagates.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def queries(n, seed=0, nan_frac=0.1):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, 5), dtype=np.float32)
+    x[:, :3] += 31.0
+    x[:, 3] = x[:, 3] * 2.0 - 0.5
+    x[rng.random(n) < nan_frac, 4] = np.nan
+    return x
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture()
+def cache(api, torch_gpu):
+    c = api.NeuralRadianceCache(api.AppConfig(train_batch_count=1, log2_train_batch_size=10))
+    yield c
+    c.Destroy()
+
+
+def randomize(cache, onn, seed=5, scale=1.5):
+    """non-trivial asymmetric weights in both implementations (EMA != master)"""
+    rng = np.random.default_rng(seed)
+    w = np.array(onn.buffer(0)) * scale + (rng.standard_normal(onn.n_params) * 0.01).astype(np.float32)
+    e = w + (rng.standard_normal(onn.n_params) * 0.02).astype(np.float32)
+    onn.buffer(0)[:] = w
+    onn.buffer(1)[:] = e
+    cache.SetParams(0, w)
+    cache.SetParams(1, e)
+
+
+def test_initial_weights_match_oracle(cache, orc):
+    onn = orc.nn_create()
+    assert cache.ParamCount() == onn.n_params == 25792
+    assert np.array_equal(cache.GetParams(0), onn.buffer(0))
+    assert np.array_equal(cache.GetParams(1), onn.buffer(1))
+
+
+@pytest.mark.parametrize("use_ema", [True, False])
+def test_inference_matches_oracle(cache, orc, torch_gpu, use_ema):
+    onn = orc.nn_create()
+    randomize(cache, onn)
+    x = queries(8192)
+    d_in = torch_gpu.from_numpy(x).cuda()
+    d_out = torch_gpu.empty((x.shape[0], 3), device="cuda")
+    cache.Infer(d_in, d_out, useEma=use_ema)
+    got = d_out.cpu().numpy()
+    ref = onn.forward(x, use_ema=use_ema, mode=1)
+    assert np.isfinite(got).all()
+    assert rel(got, ref) < 2e-3
+    assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+    # and it tracks the fp32 network (precision >= the reference's fp16 accumulate)
+    assert rel(got, onn.forward(x, use_ema=use_ema, mode=0)) < 1e-2
+
+
+@pytest.mark.parametrize("n", [1, 16, 31, 32, 33, 100, 1000, 4097])
+def test_inference_ragged_sizes(cache, orc, torch_gpu, n):
+    onn = orc.nn_create()
+    x = queries(n, seed=n)
+    d_in = torch_gpu.from_numpy(x).cuda()
+    d_out = torch_gpu.full((n + 8, 3), -7.0, device="cuda")
+    cache.Infer(d_in, d_out[:n], True)
+    out = d_out.cpu().numpy()
+    assert (out[n:] == -7.0).all()                       # nothing written past the tail
+    assert rel(out[:n], onn.forward(x, True, 1)) < 2e-3
+
+
+def test_sample_independence_and_determinism(cache, torch_gpu):
+    x = queries(2048, seed=3)
+    d_in = torch_gpu.from_numpy(x).cuda()
+    a, b = torch_gpu.empty((2048, 3), device="cuda"), torch_gpu.empty((2048, 3), device="cuda")
+    cache.Infer(d_in, a, True)
+    perm = torch_gpu.randperm(2048, device="cuda")
+    cache.Infer(d_in[perm].contiguous(), b, True)
+    assert torch_gpu.equal(a[perm], b)                   # a sample's result does not depend on its tile / lane
+
+
+def test_infer_and_train_batch_slicing_and_filter(api, orc, torch_gpu):
+    """Init/InferAndTrain (src/NeuralRadianceCache.cu:42-103): batches of 2^log2InferBatchSize + remainder, host filter"""
+    cfg = api.AppConfig(log2_infer_batch_size=10, log2_train_batch_size=8, train_batch_count=2)
+    c = api.NeuralRadianceCache(cfg)
+    n = 2560 + 512
+    x = queries(n, seed=9, nan_frac=0.0)
+    d_in = torch_gpu.from_numpy(x).cuda()
+    d_out = torch_gpu.zeros((n, 3), device="cuda")
+    d_tin = torch_gpu.from_numpy(queries(512, seed=10, nan_frac=0.0)).cuda()
+    d_tt = torch_gpu.rand((512, 3), device="cuda")
+    c.Init(n, d_in, d_out, d_tin, d_tt)
+    assert c.GetInferBatchSize() == 1024 and c.GetTrainBatchSize() == 256
+    assert c.GetInferBatchCount() == 3 + 0 and c.GetTrainBatchCount() == 2        # 3072 = 3 x 1024
+    c.InferAndTrain(np.array([1, 0, 1], np.uint32), False)
+    out = d_out.cpu().numpy()
+    ref = orc.nn_create().forward(x, True, 1)
+    assert rel(out[:1024], ref[:1024]) < 2e-3 and rel(out[2048:], ref[2048:]) < 2e-3
+    assert (out[1024:2048] == 0).all()                   # filtered batch untouched
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        c.Init(1001, d_in, d_out, d_tin, d_tt)
+    c.InferAndTrain(None, True)                          # two train batches -> two optimizer steps
+    assert c.GetStep() == 2 and np.isfinite(c.GetLoss())
+    c.Destroy()
+
+
+@pytest.mark.parametrize("loss_fn,loss_id", [("RelativeL2Luminance", 0), ("L2", 1), ("RelativeL2", 2)])
+def test_backward_matches_oracle(api, orc, torch_gpu, loss_fn, loss_id):
+    c = api.NeuralRadianceCache(api.AppConfig(loss_fn=loss_fn))
+    onn = orc.nn_create(loss_id=loss_id)
+    randomize(c, onn, seed=7, scale=1.0)
+    n = 2048
+    x = queries(n, seed=21)
+    rng = np.random.default_rng(22)
+    t = (rng.random((n, 3), dtype=np.float32) * 2).astype(np.float32)
+    c.Backward(torch_gpu.from_numpy(x).cuda(), torch_gpu.from_numpy(t).cuda())
+    loss_ref = onn.backward(x, t)
+    g = c.GetParams(4) / 128.0                            # the device vector carries loss_scale
+    g_ref = np.array(onn.buffer(4))
+    assert abs(c.GetLoss() - loss_ref) < 2e-3 * abs(loss_ref)
+    assert rel(g, g_ref) < 1e-2
+    # per-layer check: a transposed or permuted weight-gradient tile would show up as O(1) error in one layer
+    off = 0
+    for o, i in [(64, 80)] + [(64, 64)] * 5 + [(3, 64)]:
+        assert rel(g[off:off + o * i], g_ref[off:off + o * i]) < 2e-2
+        off += o * i
+    c.Destroy()
+
+
+def test_backward_is_bitwise_reproducible(cache, torch_gpu):
+    x = torch_gpu.from_numpy(queries(4096, seed=4, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((4096, 3), device="cuda")
+    cache.Backward(x, t)
+    g1 = cache.GetParams(4)
+    cache.Backward(x, t)
+    assert np.array_equal(g1, cache.GetParams(4))         # fixed-order slab reduction, no float atomics
+
+
+def test_training_steps_match_oracle(cache, orc, torch_gpu):
+    onn = orc.nn_create()
+    n = 1024
+    x = queries(n, seed=31, nan_frac=0.05)
+    rng = np.random.default_rng(32)
+    d_x = torch_gpu.from_numpy(x).cuda()
+    for step in range(3):
+        t = rng.random((n, 3), dtype=np.float32)
+        cache.Backward(d_x, torch_gpu.from_numpy(t).cuda())
+        cache.OptimizerStep()
+        loss_ref = onn.backward(x, t)
+        onn.optimizer_step()
+        assert abs(cache.GetLoss() - loss_ref) < 5e-3 * abs(loss_ref)
+    assert cache.GetStep() == 3
+    assert rel(cache.GetParams(0), onn.buffer(0)) < 1e-3
+    assert rel(cache.GetParams(1), onn.buffer(1)) < 1e-3
+    assert rel(cache.GetParams(2), onn.buffer(2)) < 2e-2 and rel(cache.GetParams(3), onn.buffer(3)) < 4e-2
+    # inference now uses the updated EMA weights
+    out = torch_gpu.empty((n, 3), device="cuda")
+    cache.Infer(d_x, out, True)
+    assert rel(out.cpu().numpy(), onn.forward(x, True, 1)) < 5e-3
+
+
+def test_sharded_backward_sums_to_full_batch(api, torch_gpu):
+    """multi-GPU exchange step on one device: two half batches against the global normaliser sum to the full gradient"""
+    c = api.NeuralRadianceCache(api.AppConfig())
+    n = 2048
+    x = torch_gpu.from_numpy(queries(n, seed=41, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((n, 3), device="cuda")
+    c.Backward(x, t)
+    full, loss_full = c.GetParams(4), c.GetLoss()
+    c.Backward(x[:1024].contiguous(), t[:1024].contiguous(), nNorm=n)
+    a, la = c.GetParams(4), c.GetLoss()
+    c.Backward(x[1024:].contiguous(), t[1024:].contiguous(), nNorm=n)
+    b, lb = c.GetParams(4), c.GetLoss()
+    assert rel(a + b, full) < 1e-5 and abs(la + lb - loss_full) < 1e-5 * abs(loss_full)
+    c.Destroy()
+
+
+def test_loss_decreases_when_training_on_device(api, torch_gpu):
+    c = api.NeuralRadianceCache(api.AppConfig())
+    x = queries(4096, seed=51, nan_frac=0.0)
+    t = np.stack([np.sin(x[:, 0] * 7) * 0.5 + 0.5, x[:, 3] * 0.3 + 0.2, np.full(4096, 0.4, np.float32)], axis=1).astype(np.float32)
+    d_x, d_t = torch_gpu.from_numpy(x).cuda(), torch_gpu.from_numpy(t).cuda()
+    losses = []
+    for _ in range(40):
+        c.Backward(d_x, d_t)
+        c.OptimizerStep()
+        losses.append(c.GetLoss())
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0]
+    c.Destroy()
+
+
+def test_checkpoint_roundtrip(api, torch_gpu):
+    a = api.NeuralRadianceCache(api.AppConfig())
+    x = torch_gpu.from_numpy(queries(1024, seed=61, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((1024, 3), device="cuda")
+    for _ in range(2):
+        a.Backward(x, t)
+        a.OptimizerStep()
+    sd = a.state_dict()
+    b = api.NeuralRadianceCache(api.AppConfig(seed=99))
+    b.load_state_dict(sd)
+    for c in (a, b):
+        c.Backward(x, t)
+        c.OptimizerStep()
+    assert np.array_equal(a.GetParams(0), b.GetParams(0)) and np.array_equal(a.GetParams(1), b.GetParams(1))
+    oa, ob = torch_gpu.empty((1024, 3), device="cuda"), torch_gpu.empty((1024, 3), device="cuda")
+    a.Infer(x, oa, True)
+    b.Infer(x, ob, True)
+    assert torch_gpu.equal(oa, ob)
+    a.Destroy()
+    b.Destroy()
+
+
+def test_unsupported_configurations_fail_loudly(api, torch_gpu):
+    for kw in (dict(pos_id=0), dict(nn_width=128), dict(optimizer="SGD"), dict(loss_fn="Huber")):
+        with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
+            api.NeuralRadianceCache(api.AppConfig(**kw))
+
+
+def test_full_size_inference_properties(cache, orc, torch_gpu):
+    """BASELINE size (1920x1080 queries): finite everywhere, spot-checked against the oracle"""
+    n = 1920 * 1080
+    g = torch_gpu.Generator(device="cuda").manual_seed(1)
+    x = torch_gpu.rand((n, 5), device="cuda", generator=g)
+    x[:, :3] += 31.0
+    out = torch_gpu.empty((n, 3), device="cuda")
+    cache.Infer(x, out, True)
+    assert bool(torch_gpu.isfinite(out).all())
+    idx = torch_gpu.randint(0, n, (2048,), device="cuda", generator=g)
+    ref = orc.nn_create().forward(x[idx].cpu().numpy(), True, 1)
+    assert rel(out[idx].cpu().numpy(), ref) < 2e-3

@@ -1,0 +1,74 @@
+"""Host-side logic of the package (no GPU): config surface, scene inputs, sharding helpers."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_appconfig_defaults_and_argv(api):
+    c = api.AppConfig()
+    assert (c.loss_fn, c.optimizer) == ("RelativeL2Luminance", "Adam")
+    assert abs(c.learning_rate - 0.01) < 1e-9 and abs(c.ema_decay - 0.99) < 1e-7
+    assert (c.pos_id, c.dir_id, c.nn_width, c.nn_depth) == (3, 0, 64, 6)
+    assert (c.log2_infer_batch_size, c.log2_train_batch_size, c.train_batch_count) == (21, 14, 4)
+    assert (c.scene_id, c.train_spp, c.primary_ray_length, c.train_ray_length) == (4, 1, 1, 32)
+    # the reference's 18-entry argv (src/main.cu:432-439)
+    argv = ["NRC-HPM-Renderer", "RelativeL2Luminance", "Adam", "0.01", "0.99", "3", "0", "64", "6", "21", "14", "4",
+            "4", "1.0", "1", "1", "0.0", "32"]
+    a = api.AppConfig(argv)
+    assert a.GetName() == "RelativeL2Luminance_Adam_0.010000_0.990000_3_0_64_6_21_14_4_4_1.000000_1_1_0.000000_32"
+    with pytest.raises(RuntimeError, match="Argument count"):
+        api.AppConfig(argv[:-1])
+
+
+def test_scene_presets_and_volume_size(sc):
+    assert sc.SCENE_PRESETS[4] == (8.0, 0.0, 0.1, 0.6) and sc.SCENE_PRESETS[0][0] == 16.0
+    s = sc.volume_size((126, 86, 154))
+    assert np.allclose(s, [62.486, 42.649, 76.372], atol=2e-3)
+    d = sc.dir_light_dir()
+    assert abs(d[0]) < 1e-7 and abs(d[1] - 7.963e-4) < 1e-6 and abs(d[2] + 1.0) < 1e-6
+
+
+def test_camera_matrix_unprojects_centre_ray(sc):
+    cam = sc.make_camera(aspect=16 / 9)
+    m = cam["inv_proj_view"].reshape(4, 4).T.astype(np.float64)           # column-major -> math
+    p = m @ np.array([0.0, 0.0, 0.0, 1.0])
+    p = p[:3] / p[3]
+    d = p - np.array([64.0, 0, 0])
+    d /= np.linalg.norm(d)
+    assert np.allclose(d, [-1, 0, 0], atol=1e-6)
+    # top of the image (ndc y = +1) is 30 degrees up
+    p = m @ np.array([0.0, 1.0, 0.0, 1.0])
+    p = p[:3] / p[3]
+    d = p - np.array([64.0, 0, 0])
+    d /= np.linalg.norm(d)
+    assert abs(math.degrees(math.asin(d[1])) - 30.0) < 1e-3
+
+
+def test_quantize_density_truncates(sc):
+    v = np.zeros((2, 3, 4), np.float32)
+    v[1, 2, 3] = 1.0
+    v[0, 0, 0] = 0.999
+    q = sc.quantize_density(v)
+    assert q.shape == (4, 3, 2) and q[3, 2, 1] == 255 and q[0, 0, 0] == 254      # uint8(0.999*255) = 254
+
+
+def test_column_tiles_partition_the_frame():
+    from nrc_hpm_renderer_amd import parallel
+    for world in (1, 2, 3, 4, 8):
+        for gw in (16, 1920, 3841):
+            cols = []
+            for r in range(world):
+                x0, st, w_, h_ = parallel.column_tile(r, world, gw, 4)
+                lw = parallel.local_width(r, world, gw)
+                cols += list(range(x0, gw, st))[:lw]
+                assert x0 + (lw - 1) * st < gw
+            assert sorted(cols) == list(range(gw))
+    imgs = [np.full((2, parallel.local_width(r, 2, 5), 1), r, np.float32) for r in range(2)]
+    g = parallel.gather_columns(imgs, 5)
+    assert g[0, :, 0].tolist() == [0, 1, 0, 1, 0]
+
+
+def test_frame_randoms_deterministic(sc):
+    a, b = sc.frame_randoms(5), sc.frame_randoms(5)
+    assert np.array_equal(a, b) and a.shape == (5, 4) and (a >= 0).all() and (a < 1).all()

@@ -1,0 +1,154 @@
+"""The oracle's NN arithmetic (tiny-cuda-nn v1.6 semantics; PARITY UNPINNED against the reference --
+the submodule is absent) checked for internal consistency against a plain PyTorch fp32 statement of the same maths."""
+import numpy as np
+import pytest
+import torch
+
+
+def queries(n, seed=0, nan_frac=0.1):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, 5), dtype=np.float32)
+    x[:, :3] += 31.0                                   # quirk Q3: positions land around size/2
+    x[:, 3] = x[:, 3] * 2.0 - 0.5                      # quirk Q4: theta in [-0.5, 1.5]
+    x[rng.random(n) < nan_frac, 4] = np.nan            # quirk Q5: NaN phi
+    return x
+
+
+def test_param_count_and_init(orc):
+    nn = orc.nn_create()
+    assert nn.enc_dims == 80
+    assert nn.n_params == 64 * 80 + 5 * 64 * 64 + 3 * 64
+    w = nn.buffer(0)
+    s0 = np.sqrt(6.0 / (80 + 64))
+    assert np.abs(w[:64 * 80]).max() <= s0 + 1e-6 and np.abs(w[:64 * 80]).max() > 0.9 * s0
+    assert np.array_equal(w, nn.buffer(1))             # EMA starts at the weights
+    assert np.array_equal(orc.nn_create().buffer(0), w)    # seed 1337 is deterministic
+
+
+def test_frequency_encoding(orc):
+    nn = orc.nn_create()
+    x = np.zeros((3, 5), np.float32)
+    x[0, :3] = [0.25, 0.5, 31.3]
+    x[1, :3] = [0.25 + 2.0, 0.5 + 4.0, 31.3]           # period 2 at f = 0
+    e = nn.encode(x)
+    # out[d*24 + 2f + s] = sin(2^f*pi*x_d + s*pi/2)
+    assert abs(e[0, 0] - np.sin(np.pi * 0.25)) < 1e-3 and abs(e[0, 1] - np.cos(np.pi * 0.25)) < 1e-3
+    assert abs(e[0, 24 + 2] - np.sin(2 * np.pi * 0.5)) < 1e-3
+    assert np.allclose(e[0, :72], e[1, :72], atol=1e-3)
+    t = np.float32(31.3) * np.float32(2.0 ** 11)
+    r = float(t - 2.0 * np.floor(t / 2.0))
+    assert abs(e[0, 48 + 22] - np.sin(np.pi * r)) < 1e-3          # exact argument reduction defines the value (Q3)
+
+
+def test_oneblob_encoding(orc):
+    nn = orc.nn_create()
+    x = np.zeros((5, 5), np.float32)
+    x[:, 3] = [0.0, 0.125, 0.5, 0.99, np.nan]
+    x[:, 4] = [0.3, 0.3, 0.3, 0.3, 0.3]
+    e = nn.encode(x)[:, 72:]
+    assert np.allclose(e[:4, :4].sum(axis=1), 1.0, atol=2e-3)      # the periodic quartic kernel integrates to 1
+    assert np.allclose(e[:, 4:].sum(axis=1), 1.0, atol=2e-3)
+    assert e[1, 0] == e[1, :4].max()                               # x = 0.125 is the centre of bin 0
+    assert np.array_equal(e[4, :4], np.array([0, 0, 0, 1], np.float32))     # NaN -> (0,0,0,1) (fminf/fmaxf swallow NaN)
+    # periodic: x = 0 spreads equally into bins 0 and 3
+    assert abs(e[0, 0] - e[0, 3]) < 1e-3 and e[0, 1] < 1e-3
+
+
+def torch_mlp(nn, enc, use_ema, quant):
+    w = torch.from_numpy(np.array(nn.buffer(1 if use_ema else 0)))
+    if quant:
+        w = w.half().float()
+    dims = [(64, 80)] + [(64, 64)] * 5 + [(3, 64)]
+    mats, off = [], 0
+    for o, i in dims:
+        mats.append(w[off:off + o * i].view(o, i).clone().requires_grad_(True))
+        off += o * i
+    h = torch.from_numpy(enc)
+    for m in mats[:-1]:
+        h = torch.relu(h @ m.t())
+        if quant:
+            h = (h.half().float() - h).detach() + h        # straight-through fp16 rounding
+    return h @ mats[-1].t(), mats
+
+
+def test_forward_matches_torch(orc):
+    nn = orc.nn_create()
+    x = queries(512)
+    enc = nn.encode(x)
+    y32 = nn.forward(x, use_ema=True, mode=0)
+    ref32, _ = torch_mlp(nn, enc, True, False)
+    assert np.allclose(y32, ref32.detach().numpy(), atol=2e-5, rtol=1e-4)
+    y16 = nn.forward(x, use_ema=True, mode=1)
+    ref16, _ = torch_mlp(nn, enc, True, True)
+    assert np.linalg.norm(y16 - ref16.detach().numpy()) / np.linalg.norm(y16) < 2e-3
+    assert np.linalg.norm(y16 - y32) / np.linalg.norm(y32) < 1e-2      # fp16 storage stays close to fp32
+
+
+@pytest.mark.parametrize("loss_id", [0, 1, 2])
+def test_backward_matches_autograd(orc, loss_id):
+    nn = orc.nn_create(loss_id=loss_id)
+    n = 256
+    x = queries(n, seed=1)
+    rng = np.random.default_rng(2)
+    t = rng.random((n, 3), dtype=np.float32) * 2.0
+    loss = nn.backward(x, t)
+    y, mats = torch_mlp(nn, nn.encode(x), False, True)
+    tt = torch.from_numpy(t)
+    N = 3 * n
+    if loss_id == 0:
+        lum = 0.299 * y[:, 0] + 0.587 * y[:, 1] + 0.114 * y[:, 2]
+        den = (lum * lum + 0.01).detach()[:, None]       # tiny-cuda-nn treats the normaliser as a constant
+    elif loss_id == 1:
+        den = torch.ones_like(y)
+    else:
+        den = (y * y + 0.01).detach()
+    lt = ((y - tt) ** 2 / den / N).sum()
+    lt.backward()
+    g_ref = torch.cat([m.grad.reshape(-1) for m in mats]).numpy()
+    g = np.array(nn.buffer(4))
+    assert abs(loss - float(lt.detach())) < 1e-4 * max(1.0, abs(float(lt.detach())))
+    assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 2e-2      # fp16 deltas (loss_scale 128) vs fp32 autograd
+
+
+def test_optimizer_matches_torch_adam(orc):
+    """EMA{Adam}: against torch.optim.Adam where eps is negligible (tiny-cuda-nn folds the bias correction into the
+    learning rate without rescaling eps, so the two differ by O(eps/sqrt(v)) per update), and against the SURVEY App. B
+    formulas evaluated in float64 everywhere."""
+    nn = orc.nn_create(lr=0.01, ema_decay=0.99)
+    w0 = np.array(nn.buffer(0))
+    p = torch.from_numpy(w0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    rng = np.random.default_rng(3)
+    big = np.ones(nn.n_params, bool)
+    w64, m64, v64, ema64 = w0.astype(np.float64), 0.0, 0.0, w0.astype(np.float64)
+    for step in range(1, 4):
+        g = (rng.standard_normal(nn.n_params) * 1e-2).astype(np.float32)
+        big &= np.abs(g) > 5e-3
+        nn.buffer(4)[:] = g
+        nn.optimizer_step()
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        gg = g.astype(np.float64) + 1e-8 * w64
+        m64 = 0.9 * m64 + 0.1 * gg
+        v64 = 0.999 * v64 + 0.001 * gg * gg
+        lr_t = 0.01 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        w64 = w64 - lr_t * m64 / (np.sqrt(v64) + 1e-8)
+        d = 0.99
+        ema64 = (ema64 * d * (1 - d ** (step - 1)) + w64 * (1 - d)) / (1 - d ** step)
+        assert np.allclose(nn.buffer(0), w64, atol=1e-6, rtol=0)
+        assert np.allclose(nn.buffer(1), ema64, atol=1e-6, rtol=0)
+    assert big.sum() > 1000
+    assert np.allclose(nn.buffer(0)[big], p.detach().numpy()[big], atol=3e-6, rtol=0)
+    assert not np.array_equal(nn.buffer(0), w0)
+
+
+def test_training_reduces_loss(orc):
+    nn = orc.nn_create(lr=0.01)
+    x = queries(256, seed=5, nan_frac=0.0)
+    t = np.stack([np.sin(x[:, 0] * 7) * 0.5 + 0.5, x[:, 3] * 0.3 + 0.2, np.full(256, 0.4, np.float32)], axis=1).astype(np.float32)
+    first = last = None
+    for _ in range(30):
+        last = nn.backward(x, t)
+        first = last if first is None else first
+        nn.optimizer_step()
+    assert last < 0.5 * first
