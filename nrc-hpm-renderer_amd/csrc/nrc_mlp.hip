@@ -19,7 +19,10 @@
 //     (bitwise reproducible; no float atomics).
 #include "nrc_mlp.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace nrc {
@@ -68,14 +71,33 @@ __device__ __forceinline__ f32x16 zero16()
     return z;
 }
 
-// ReLU + round-to-nearest-even fp16: accumulator registers 0..7 -> lo, 8..15 -> hi
+// ReLU + round-to-nearest-even fp16: accumulator registers 0..7 -> lo, 8..15 -> hi.
+// One v_cvt_pk_f16_f32 per two values, then ReLU on the packed halfs as a signed 16-bit integer max with 0
+// (v_pk_max_i16: negative halfs have the sign bit set; -0 -> +0).  fmaxf() on fp32 would cost two v_max_f32 per value
+// (hipcc canonicalises MFMA outputs first); rounding commutes with ReLU, so the result is identical.
+using float2v = float __attribute__((ext_vector_type(2)));
+using half2v = _Float16 __attribute__((ext_vector_type(2)));
+using short2v = short __attribute__((ext_vector_type(2)));
+using uint4v = uint32_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t relu_pk(float a, float b)
+{
+    float2v f = {a, b};
+    half2v h = __builtin_convertvector(f, half2v);       // v_cvt_pk_f16_f32 (RNE)
+    short2v s = __builtin_bit_cast(short2v, h);
+    short2v z = {0, 0};
+    s = __builtin_elementwise_max(s, z);                  // v_pk_max_i16
+    return __builtin_bit_cast(uint32_t, s);
+}
 __device__ __forceinline__ void relu_pack(const f32x16& acc, half8& lo, half8& hi)
 {
+    uint4v l, h;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        lo[j] = (half_t)fmaxf(acc[j], 0.0f);
-        hi[j] = (half_t)fmaxf(acc[8 + j], 0.0f);
+    for (int j = 0; j < 4; j++) {
+        l[j] = relu_pk(acc[2 * j], acc[2 * j + 1]);
+        h[j] = relu_pk(acc[8 + 2 * j], acc[8 + 2 * j + 1]);
     }
+    lo = __builtin_bit_cast(half8, l);
+    hi = __builtin_bit_cast(half8, h);
 }
 
 // tiny-cuda-nn one_blob quartic kernel CDF (radius 1/4): fminf(fmaxf(.,0),1) maps NaN to 0
@@ -93,40 +115,55 @@ __device__ __forceinline__ float quartic_cdf4(float x)
 // reduction x*2^(f-1) -> fract is exact in fp32, which defines the value for the large arguments of quirk Q3).
 __device__ __forceinline__ void encode80(const float (&x)[5], int h, half8 (&b)[KS0])
 {
+    // per (dim, frequency quad): one exact (sin, cos) from the hardware units, the next three octaves by angle doubling
+    // sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a (3 VALU ops instead of fract + 2 quarter-rate transcendentals; the
+    // error grows 2x per octave, i.e. 8x the hardware's ~1e-6, far below fp16 resolution)
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int g0 = 2 * s, g1 = 2 * s + 1;                       // feature groups of the two lane halves
         const float xv = h ? x[g1 / 3] : x[g0 / 3];
         const float sc = h ? (float)(1 << (4 * (g1 % 3))) * 0.5f : (float)(1 << (4 * (g0 % 3))) * 0.5f;
-        float t = xv * sc;
+        const float rev = __builtin_amdgcn_fractf(xv * sc);
+        float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        b[s][0] = (half_t)sn;
+        b[s][1] = (half_t)cs;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float rev = __builtin_amdgcn_fractf(t);
-            b[s][2 * i] = (half_t)__builtin_amdgcn_sinf(rev);
-            b[s][2 * i + 1] = (half_t)__builtin_amdgcn_cosf(rev);
-            t = t + t;
+        for (int i = 1; i < 4; i++) {
+            const float t2 = sn + sn;
+            const float s2 = t2 * cs;
+            cs = __builtin_fmaf(-t2, sn, 1.0f);
+            sn = s2;
+            b[s][2 * i] = (half_t)sn;
+            b[s][2 * i + 1] = (half_t)cs;
         }
     }
     {
-        float t = x[2] * (h ? 512.0f : 128.0f);                     // f = 10,11 | 8,9
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            float rev = __builtin_amdgcn_fractf(t);
-            b[4][2 * i] = (half_t)__builtin_amdgcn_sinf(rev);
-            b[4][2 * i + 1] = (half_t)__builtin_amdgcn_cosf(rev);
-            t = t + t;
-        }
+        const float rev = __builtin_amdgcn_fractf(x[2] * (h ? 512.0f : 128.0f));      // f = 10,11 | 8,9
+        float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        b[4][0] = (half_t)sn;
+        b[4][1] = (half_t)cs;
+        const float t2 = sn + sn;
+        b[4][2] = (half_t)(t2 * cs);
+        b[4][3] = (half_t)__builtin_fmaf(-t2, sn, 1.0f);
+        // OneBlob(4 bins, periodic): C(b) = cdf(b-x) + cdf(b-x-1) + cdf(b-x+1).  The kernel radius is 1/4, so with
+        // k = rint(b-x), w = (b-x) - k only the m = 0 term of {w+k-1, w+k, w+k+1} can be unsaturated; the others are
+        // exactly 0 or 1:  C(b) = clamp(k+1, 0, 3) + (|k| <= 1 ? cdf(w) : 0).  One polynomial per bin edge instead of 3.
         const float xd = h ? x[4] : x[3];
         float cdf[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            float bx = (float)k * 0.25f - xd;
-            cdf[k] = (quartic_cdf4(bx) + quartic_cdf4(bx - 1.0f)) + quartic_cdf4(bx + 1.0f);
+            const float bx = (float)k * 0.25f - xd;
+            const float kk = __builtin_rintf(bx);
+            const float w = bx - kk;
+            const float sat = __builtin_amdgcn_fmed3f(kk + 1.0f, 0.0f, 3.0f);
+            cdf[k] = sat + (__builtin_fabsf(kk) <= 1.0f ? quartic_cdf4(w) : 0.0f);
         }
+        const bool bad = !(xd == xd);          // NaN (quirk Q5): tiny-cuda-nn's fminf/fmaxf clamps give (0,0,0,1)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
-            b[4][4 + k] = (half_t)(right - cdf[k]);
+            const float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
+            const float v = right - cdf[k];
+            b[4][4 + k] = (half_t)(bad ? (k == 3 ? 1.0f : 0.0f) : v);
         }
     }
 }
@@ -191,39 +228,143 @@ __device__ __forceinline__ void stage_lds(uint4* dst, const uint4* src, int n16,
 }
 
 // ------------------------------------------------------------------------------------------------ inference
-// persistent workgroups; one 32-sample tile per wave per iteration
-template <int DEPTH, int THREADS>
+// forward chain for NT independent 32-sample tiles of one wave: every weight fragment read from LDS feeds NT MFMAs, and
+// the ReLU/convert VALU work of one tile overlaps the MFMAs of the other inside the wave (in-order issue needs the ILP).
+// ABL (diagnostic builds only, never the default): bit 0 = trivial encoding, bit 1 = no ReLU/convert work
+template <int ABL>
+__device__ __forceinline__ void relu_pack_abl(const f32x16& acc, half8& lo, half8& hi)
+{
+    if constexpr ((ABL & 2) != 0) {
+        uint4v l = {__builtin_bit_cast(uint32_t, acc[0]), __builtin_bit_cast(uint32_t, acc[1]),
+                    __builtin_bit_cast(uint32_t, acc[2]), __builtin_bit_cast(uint32_t, acc[3])};
+        uint4v h = {__builtin_bit_cast(uint32_t, acc[8]), __builtin_bit_cast(uint32_t, acc[9]),
+                    __builtin_bit_cast(uint32_t, acc[10]), __builtin_bit_cast(uint32_t, acc[11])};
+        lo = __builtin_bit_cast(half8, l);
+        hi = __builtin_bit_cast(half8, h);
+    } else {
+        relu_pack(acc, lo, hi);
+    }
+}
+
+// forward chain for NT independent 32-sample tiles of one wave: every weight fragment read from LDS feeds NT MFMAs, and
+// the ReLU/convert VALU work of one tile can overlap the MFMAs of the other inside the wave (in-order issue needs the ILP).
+template <int DEPTH, int NT, int ABL = 0>
+__device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, half8 (&enc)[NT][KS0], f32x16 (&y)[NT])
+{
+    f32x16 acc0[NT], acc1[NT];
+    half8 b[NT][KSH];
+#pragma unroll
+    for (int l = 0; l < DEPTH; l++) {
+        const int ks = l == 0 ? KS0 : KSH;
+        const int base = l == 0 ? FRAG_L0 : FRAG_HID + (l - 1) * MT * KSH;
+#pragma unroll
+        for (int t = 0; t < NT; t++) { acc0[t] = zero16(); acc1[t] = zero16(); }
+#pragma unroll
+        for (int s = 0; s < ks; s++) {
+            const half8 a0 = ld_frag(lw, base + s, lane);
+            const half8 a1 = ld_frag(lw, base + ks + s, lane);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const half8 bs = l == 0 ? enc[t][s] : b[t][s];
+                acc0[t] = mfma(a0, bs, acc0[t]);
+                acc1[t] = mfma(a1, bs, acc1[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            relu_pack_abl<ABL>(acc0[t], b[t][0], b[t][1]);
+            relu_pack_abl<ABL>(acc1[t], b[t][2], b[t][3]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) y[t] = zero16();
+#pragma unroll
+    for (int s = 0; s < KSH; s++) {
+        const half8 a = ld_frag(lw, frag_out(DEPTH) + s, lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) y[t] = mfma(a, b[t][s], y[t]);
+    }
+}
+
+// persistent workgroups; NT 32-sample tiles per wave per iteration; the next iteration's queries are loaded (20 B per
+// sample, straight from HBM/L2 into registers) before the current tiles are computed, so their latency is hidden.
+template <int DEPTH, int THREADS, int NT, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
-                                                  const uint4* __restrict__ image)
+                                                  const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
+    unsigned long long t0 = 0, r0 = 0;
+    if constexpr ((ABL & 4) != 0) {     // diagnostic: shader clock vs 100 MHz wall clock (MI355X_MICROARCH.md DVFS item 6)
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
     stage_lds(lw, image, n_frag_fwd(DEPTH) * 64, threadIdx.x, THREADS);
-    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = (n + 31u) >> 5;
-    const uint32_t stride = gridDim.x * (THREADS / 64);
-    for (uint32_t tile = blockIdx.x * (THREADS / 64) + wave; tile < n_tiles; tile += stride) {
-        // the weight image in LDS is loop invariant: keep hipcc from hoisting all 54 fragments (216 VGPRs) out of
-        // the tile loop -- fragments are meant to be re-read from LDS, one ds_read_b128 per MFMA
-        asm volatile("" ::: "memory");
-        const uint32_t sidx = tile * 32u + r;
-        const bool valid = sidx < n;
-        const float* p = in + (size_t)(valid ? sidx : n - 1u) * 5u;
-        float x[5];
+    const uint32_t stride = gridDim.x * (THREADS / 64) * NT;
+    uint32_t tile = (blockIdx.x * (THREADS / 64) + wave) * NT;
+    float x[NT][5];
 #pragma unroll
-        for (int i = 0; i < 5; i++) x[i] = p[i];
-        FwdState<DEPTH, false> st;
-        encode80(x, h, st.enc);
-        f32x16 y = forward_tile<DEPTH, false>(lw, lane, st);
-        if (valid && h == 0) {
-            float* o = out + (size_t)sidx * 3u;
-            o[0] = y[0];
-            o[1] = y[1];
-            o[2] = y[2];
+    for (int t = 0; t < NT; t++) {
+        const uint32_t sidx = (tile + t) * 32u + r;
+        const float* p = in + (size_t)(sidx < n ? sidx : n - 1u) * 5u;
+#pragma unroll
+        for (int i = 0; i < 5; i++) x[t][i] = __builtin_nontemporal_load(p + i);
+    }
+    __syncthreads();
+    for (; tile < n_tiles; tile += stride) {
+        // the weight image in LDS is loop invariant: keep hipcc from hoisting all 54 fragments (216 VGPRs) out of
+        // the tile loop -- fragments are meant to be re-read from LDS, one ds_read_b128 per NT MFMAs
+        asm volatile("" ::: "memory");
+        float xn[NT][5];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint32_t sidx = (tile + stride + t) * 32u + r;
+            const float* p = in + (size_t)(sidx < n ? sidx : n - 1u) * 5u;
+#pragma unroll
+            for (int i = 0; i < 5; i++) xn[t][i] = __builtin_nontemporal_load(p + i);
+        }
+        half8 enc[NT][KS0];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+                for (int s2 = 0; s2 < KS0; s2++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) enc[t][s2][j] = (half_t)x[t][(s2 + j) % 5];
+            } else {
+                encode80(x[t], h, enc[t]);
+            }
+        }
+        f32x16 y[NT];
+        forward_tiles<DEPTH, NT, ABL>(lw, lane, enc, y);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint32_t sidx = (tile + t) * 32u + r;
+            if (sidx < n && h == 0 && ((ABL & 8) == 0 || sidx < 64u)) {
+                // streamed once: non-temporal, so the 12 B/sample leave the L2 while the kernel runs instead of in the
+                // end-of-kernel write-back
+                float* o = out + (size_t)sidx * 3u;
+                __builtin_nontemporal_store(y[t][0], o);
+                __builtin_nontemporal_store(y[t][1], o + 1);
+                __builtin_nontemporal_store(y[t][2], o + 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++) x[t][i] = xn[t][i];
+        }
+    }
+    if constexpr ((ABL & 4) != 0) {
+        if (threadIdx.x == 0) {
+            stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+            stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+            stamps[4 * blockIdx.x + 2] = r0;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            stamps[4 * blockIdx.x + 3] = xcc;
         }
     }
 }
@@ -593,17 +734,85 @@ static int num_cus()
     return g_num_cus;
 }
 
+template <int THREADS, int NT>
+static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n, const uint4* img)
+{
+    hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img);
+}
+
 void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s)
 {
     if (n == 0) return;
-    constexpr int THREADS = 512;   // 8 waves share one 54 KB weight image; 2 workgroups per CU
+    // persistent workgroups sharing one 54 KB weight image in LDS.  Tunables (env, read once): workgroup size,
+    // tiles per wave iteration, workgroups per CU.
+    static const int threads = [] { const char* e = getenv("NRC_INFER_THREADS"); return e ? atoi(e) : 512; }();
+    static const int nt = [] { const char* e = getenv("NRC_INFER_NT"); return e ? atoi(e) : 2; }();
+    static const int bpc = [] { const char* e = getenv("NRC_INFER_BPC"); return e ? atoi(e) : 2; }();
     const uint32_t n_tiles = ceil_div(n, 32);
-    const uint32_t max_blocks = (uint32_t)num_cus() * 2u;
-    uint32_t blocks = ceil_div(n_tiles, THREADS / 64);
+    const uint32_t max_blocks = (uint32_t)num_cus() * (uint32_t)bpc;
+    uint32_t blocks = ceil_div(n_tiles, (uint32_t)(threads / 64) * (uint32_t)nt);
     if (blocks > max_blocks) blocks = max_blocks;
     const size_t lds = (size_t)n_frag_fwd_ * 1024;
     const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
-    hipLaunchKernelGGL((k_infer<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img);
+    static const bool diag = [&] {
+        if (!getenv("NRC_DIAG")) return false;
+        int nb512 = -1, nb1024 = -1, nb256 = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb512, k_infer<6, 512, 1, 0>, 512, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1024, k_infer<6, 1024, 1, 0>, 1024, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb256, k_infer<6, 256, 1, 0>, 256, lds);
+        hipDeviceProp_t prop;
+        (void)hipGetDeviceProperties(&prop, 0);
+        fprintf(stderr, "[nrc diag] occupancy API blocks/CU: 256thr %d, 512thr %d, 1024thr %d (lds %zu B); sharedMemPerMultiprocessor %zu, "
+                        "sharedMemPerBlock %zu, maxSharedMemoryPerMultiProcessor %zu\n", nb256, nb512, nb1024, lds,
+                (size_t)prop.sharedMemPerMultiprocessor, (size_t)prop.sharedMemPerBlock, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+        return true;
+    }();
+    (void)diag;
+    if (threads == 1024 && nt == 1) launch_infer<1024, 1>(blocks, lds, s, d_in, d_out, n, img);
+    else if (threads == 256 && nt == 1) launch_infer<256, 1>(blocks, lds, s, d_in, d_out, n, img);
+    else if (threads == 256 && nt == 2) launch_infer<256, 2>(blocks, lds, s, d_in, d_out, n, img);
+    else if (threads == 512 && nt == 2) launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img);
+    else if (threads == 1024 && nt == 2) launch_infer<1024, 2>(blocks, lds, s, d_in, d_out, n, img);
+    else {
+        static const int abl = [] { const char* e = getenv("NRC_INFER_ABL"); return e ? atoi(e) : 0; }();
+        if (abl == 4) {       // diagnostic only: in-kernel clock / residency / inter-kernel gaps printed to stderr
+            static unsigned long long* d_st = nullptr;
+            constexpr int SLOTS = 16;
+            if (!d_st) NRC_HIP(hipMalloc(&d_st, (size_t)SLOTS * 4 * 2048 * sizeof(unsigned long long)));
+            static int count = 0;
+            const int slot = count % SLOTS;
+            static const bool nostore = getenv("NRC_INFER_NOSTORE") != nullptr;
+            if (nostore) hipLaunchKernelGGL((k_infer<6, 512, 1, 12>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
+            else hipLaunchKernelGGL((k_infer<6, 512, 1, 4>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
+            if (++count % 64 == 0) {
+                std::vector<unsigned long long> h((size_t)SLOTS * 4 * 2048);
+                NRC_HIP(hipStreamSynchronize(s));
+                NRC_HIP(hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
+                std::vector<std::pair<unsigned long long, unsigned long long>> span;
+                std::vector<double> clk;
+                for (int k = 0; k < SLOTS; k++) {
+                    unsigned long long first = ~0ull, last = 0;
+                    for (uint32_t b = 0; b < blocks; b++) {
+                        const unsigned long long* e = &h[((size_t)k * 2048 + b) * 4];
+                        first = std::min(first, e[2]);
+                        last = std::max(last, e[2] + e[1]);
+                        clk.push_back((double)e[0] / (double)e[1] * 100.0);
+                    }
+                    span.push_back({first, last});
+                }
+                std::sort(span.begin(), span.end());
+                std::sort(clk.begin(), clk.end());
+                fprintf(stderr, "[nrc diag] clock MHz med %.0f | per launch (span us, gap to next us):", clk[clk.size() / 2]);
+                for (int k = 0; k + 1 < SLOTS; k++)
+                    fprintf(stderr, " (%.1f, %.1f)", (double)(span[k].second - span[k].first) / 100.0,
+                            (double)(span[k + 1].first - span[k].second) / 100.0);
+                fprintf(stderr, "\n");
+            }
+        } else if (abl == 1) hipLaunchKernelGGL((k_infer<6, 512, 1, 1>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
+        else if (abl == 2) hipLaunchKernelGGL((k_infer<6, 512, 1, 2>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
+        else if (abl == 3) hipLaunchKernelGGL((k_infer<6, 512, 1, 3>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
+        else launch_infer<512, 1>(blocks, lds, s, d_in, d_out, n, img);
+    }
     NRC_HIP(hipGetLastError());
 }
 
