@@ -204,7 +204,7 @@ def main():
                                    "train=%d (16384 train rays + 1 Adam step per sub-frame)" % (W, H, gw, gh, args.volume, spp, args.train),
                        "width": W, "height": H, "spp": spp, "volume": args.volume, "train": args.train,
                        "parallelism": "pixel-column tiles x%d%s" % (world, " + RCCL grad all-reduce" if world > 1 and args.train else "")},
-            "stage_ms": {k: stats[k] for k in ("gen_rays", "prep_train", "nrc", "render", "total")},
+            "stage_ms": {k: stats[k] for k in ("gen_rays", "prep_train", "train", "infer", "render", "total")},
             "loss": loss,
             "roofline": roof_gen if dominant_is_gen else roof_mlp,
             "roofline_mlp": roof_mlp,

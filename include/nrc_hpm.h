@@ -101,8 +101,9 @@ float* nrc_cache_loss_ptr(nrc_cache_t* c);
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor);
 /* move the cache's work to another hipStream_t (Init binds the first one) */
 int nrc_cache_set_stream(nrc_cache_t* c, void* stream);
-/* hook called by InferAndTrain between backward and the optimizer of every train batch (NULL = none) */
-typedef void (*nrc_grad_hook)(void* user, float* d_grad, uint32_t n_params, float* d_loss);
+/* hook called between backward and the optimizer of every train batch (NULL = none); `stream` is the hipStream_t the
+ * training kernels are ordered on -- the exchange (all-reduce) must be issued on it */
+typedef void (*nrc_grad_hook)(void* user, float* d_grad, uint32_t n_params, float* d_loss, void* stream);
 int nrc_cache_set_grad_hook(nrc_cache_t* c, nrc_grad_hook hook, void* user);
 /* checkpointing: which = 0 master weights, 1 EMA weights, 2 Adam m, 3 Adam v, 4 gradient (host fp32 arrays) */
 int nrc_cache_get_params(nrc_cache_t* c, int which, float* host_out);
@@ -167,7 +168,9 @@ const float* nrc_renderer_framebuffer(nrc_renderer_t* r);
 /* ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493): scan-line EXR, FLOAT RGBA */
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
 /* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be
- * NULL or float[8] = {clear, gen_rays, prep_infer(0: fused), filter(0), prep_train, nrc(infer+train), render, total} */
+ * NULL or float[8] = {clear(0), gen_rays, prep_infer(0: fused into gen_rays), train, prep_train, inference, composite,
+ * total}.  train-ray generation and training run on a second stream concurrently with inference + compositing, so the
+ * stages overlap and do not add up to total. */
 float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
 /* the same stage times averaged over every frame rendered since the last reset (HIP events on the render stream);
  * *frames = number of frames covered */

@@ -53,7 +53,7 @@ class NrcTile(C.Structure):
     _fields_ = [("x_offset", C.c_uint32), ("x_stride", C.c_uint32), ("global_w", C.c_uint32), ("global_h", C.c_uint32)]
 
 
-GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)
+GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)
 
 # every symbol include/nrc_hpm.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
@@ -295,15 +295,19 @@ class NeuralRadianceCache:
         _check(self.L.nrc_cache_set_loss_norm_factor(self.h, C.c_uint32(factor)))
 
     def SetGradHook(self, fn):
-        """fn(grad_tensor, loss_tensor) is called between backward and the optimizer of every train batch."""
+        """fn(grad_tensor, loss_tensor) is called between backward and the optimizer of every train batch, with torch's
+        current stream switched to the stream the training kernels are ordered on."""
         if fn is None:
             self._hook_keep = None
             _check(self.L.nrc_cache_set_grad_hook(self.h, None, None))
             return
         g, lo = self.GradTensor(), self.LossTensor()
 
-        def tramp(_user, _g, _n, _l):
-            fn(g, lo)
+        import torch
+
+        def tramp(_user, _g, _n, _l, stream):
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+                fn(g, lo)
 
         self._hook_keep = GRAD_HOOK(tramp)
         _check(self.L.nrc_cache_set_grad_hook(self.h, self._hook_keep, None))
@@ -388,7 +392,7 @@ class NrcHpmRenderer:
     def EvaluateTimestampQueries(self):
         st = (C.c_float * 8)()
         self.L.nrc_renderer_frame_time_ms(self.h, st)
-        names = ("clear", "gen_rays", "prep_infer", "filter", "prep_train", "nrc", "render", "total")
+        names = ("clear", "gen_rays", "prep_infer", "train", "prep_train", "infer", "render", "total")
         return dict(zip(names, [float(x) for x in st]))
 
     def StageStats(self, reset=True):
@@ -396,7 +400,7 @@ class NrcHpmRenderer:
         st = (C.c_float * 8)()
         n = C.c_uint32(0)
         _check(self.L.nrc_renderer_stage_stats(self.h, st, C.byref(n), C.c_int(int(reset))))
-        names = ("clear", "gen_rays", "prep_infer", "filter", "prep_train", "nrc", "render", "total")
+        names = ("clear", "gen_rays", "prep_infer", "train", "prep_train", "infer", "render", "total")
         d = dict(zip(names, [float(x) for x in st]))
         d["frames"] = n.value
         return d

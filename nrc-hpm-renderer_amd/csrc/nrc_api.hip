@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -53,29 +54,41 @@ public:
 
     void infer_and_train(const uint32_t* filter, bool train)       // :97-103
     {
+        infer_all(filter, stream_);
+        if (train) train_all(stream_, nullptr);
+    }
+
+    void infer_all(const uint32_t* filter, hipStream_t s)          // Inference, :134-145
+    {
         if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
-        for (size_t i = 0; i < infer_batches_.size(); i++) {       // Inference, :134-145
+        for (size_t i = 0; i < infer_batches_.size(); i++) {
             if (filter != nullptr && filter[i] == 0) continue;
             const auto& b = infer_batches_[i];
-            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, stream_);
+            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, s);
         }
-        if (train) {                                               // Train, :147-156
-            for (uint32_t b = 0; b < train_batch_count_; b++) {
-                const size_t o = (size_t)b * train_batch_size_;
-                mlp_->backward(d_train_in_ + o * 5, d_train_target_ + o * 3, train_batch_size_,
-                               train_batch_size_ * loss_norm_factor_, stream_);
-                if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr());
-                mlp_->optimizer_step(stream_);
-            }
-            loss_dirty_ = true;
+    }
+
+    // Train, :147-156, on stream `st` (backward, gradient hook, optimizer).  When `st` is not the stream inference runs on,
+    // the optimizer additionally waits for ev_infer_done: it rewrites the fp16 weight image inference reads.
+    void train_all(hipStream_t st, hipEvent_t ev_infer_done)
+    {
+        if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
+        for (uint32_t b = 0; b < train_batch_count_; b++) {
+            const size_t o = (size_t)b * train_batch_size_;
+            mlp_->backward(d_train_in_ + o * 5, d_train_target_ + o * 3, train_batch_size_,
+                           train_batch_size_ * loss_norm_factor_, st);
+            if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
+            if (b == 0 && ev_infer_done) NRC_HIP(hipStreamWaitEvent(st, ev_infer_done, 0));
+            mlp_->optimizer_step(st);
         }
+        loss_dirty_ = true;
     }
 
     float get_loss()
     {
         if (loss_dirty_) {
-            NRC_HIP(hipMemcpyAsync(&loss_, mlp_->loss_ptr(), sizeof(float), hipMemcpyDeviceToHost, stream_));
-            NRC_HIP(hipStreamSynchronize(stream_));
+            NRC_HIP(hipDeviceSynchronize());      // training may run on the renderer's second stream
+            NRC_HIP(hipMemcpy(&loss_, mlp_->loss_ptr(), sizeof(float), hipMemcpyDeviceToHost));
             loss_dirty_ = false;
         }
         return loss_;
@@ -236,13 +249,20 @@ public:
         tg_.ray_length = (cfg.compat_fix & NRC_FIX_Q2_TRAIN_RAY_LEN) ? cfg.train_ray_length : 1u;
         tg_.ring_size = (uint32_t)(cfg.train_ring_buf_size * (float)(tg_.tw * tg_.th));   // :253
         const size_t px = (size_t)w * h, T = (size_t)tg_.tw * tg_.th;
-        alloc(&d_primary_, px * 16); alloc(&d_info_, px * 4); alloc(&d_origin_, px * 16); alloc(&d_dir_, px * 16);
+        alloc(&d_primary_, px * 16);
+        // didScatter / NRC vertex images are double-buffered: frame N's train-ray generation (second stream) reads them while
+        // frame N+1's gen_rays already writes the other set
+        for (int k = 0; k < 2; k++) { alloc(&d_info2_[k], px * 4); alloc(&d_origin2_[k], px * 16); alloc(&d_dir2_[k], px * 16); }
+        d_info_ = d_info2_[0]; d_origin_ = d_origin2_[0]; d_dir_ = d_dir2_[0];
+        for (auto& e : ev_train_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         alloc(&d_out_, px * 16); alloc(&d_infer_in_, px * 20); alloc(&d_infer_out_, px * 12);
         alloc(&d_train_in_, T * 20); alloc(&d_train_target_, T * 12);
         ring_entries_ = std::max<size_t>(T, tg_.ring_size);
         alloc(&d_ring_, 8 + ring_entries_ * 24);
         alloc(&d_scratch_, (2 * T + 4) * 4);
         alloc(&d_fetch_, 8);
+        // train-ray generation + backward overlap inference + compositing on a second stream (NRC_SINGLE_STREAM=1 disables)
+        if (!getenv("NRC_SINGLE_STREAM")) NRC_HIP(hipStreamCreateWithFlags(&stream_b_, hipStreamNonBlocking));
         // CreateNrcTrainRingBuffer: head = tail = 0, pos = 0, dir = (0,0,1)  (:866-875)
         std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
         for (size_t r = 0; r < ring_entries_; r++) { float one = 1.0f; std::memcpy(&ring[2 + 6 * r + 5], &one, 4); }
@@ -252,9 +272,12 @@ public:
 
     ~Renderer()
     {
+        (void)hipDeviceSynchronize();
         for (void* p : allocs_) (void)hipFree(p);
         for (auto& set : ev_pool_)
             for (auto& e : set) if (e) (void)hipEventDestroy(e);
+        if (stream_b_) (void)hipStreamDestroy(stream_b_);
+        for (auto& e : ev_train_done_) if (e) (void)hipEventDestroy(e);
     }
 
     void render(bool train)      // NrcHpmRenderer::Render, :299-353
@@ -263,7 +286,7 @@ public:
         if (ev_used_ == ev_pool_.size()) {
             if (ev_pool_.size() >= 4096) ev_used_ = 0;      // wrap: statistics then cover the most recent frames only
             else {
-                std::array<hipEvent_t, 5> set{};
+                std::array<hipEvent_t, 10> set{};
                 for (auto& e : set) NRC_HIP(hipEventCreate(&e));
                 ev_pool_.push_back(set);
             }
@@ -273,32 +296,51 @@ public:
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
         if (blend_) blend_index_++;
-        NRC_HIP(hipEventRecord(ev_[0], stream_));
+        // Frame graph on two streams, pipelined across frames (no host sync anywhere):
+        //   A: gen_rays(N) -> [wait train(N-1)] inference(N) -> composite(N)
+        //   B: [wait gen_rays(N)] train-ray generation(N) -> backward(N) -> (all-reduce hook) -> [wait inference(N)] optimizer(N)
+        // so frame N's training overlaps frame N's inference AND frame N+1's gen_rays; inference(N+1) still sees the weights
+        // after frame N's training (quirk Q13 ordering).
+        // events: 0 frame start, 1 gen_rays done, 2 prep_train done (B), 3 inference done, 4 composite done, 5 training done (B)
+        hipStream_t A = stream_, B = stream_b_ ? stream_b_ : stream_;
+        const int pp = (int)(frame_index_ & 1u);
+        d_info_ = d_info2_[pp]; d_origin_ = d_origin2_[pp]; d_dir_ = d_dir2_[pp];
+        NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
-                        count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
-        NRC_HIP(hipEventRecord(ev_[1], stream_));
+                        count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, A);
+        NRC_HIP(hipEventRecord(ev_[1], A));
+        if (B != A) NRC_HIP(hipStreamWaitEvent(B, ev_[1], 0));
         // the reference records prep_train_rays into every frame's pre-CUDA command buffer (:2039-2040), trained or not
         launch_prep_train(scene_.d, frame_, tg_, (const float*)d_info_, (const float*)d_origin_, (const float*)d_dir_,
-                          (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, stream_);
-        NRC_HIP(hipEventRecord(ev_[2], stream_));
-        cache_.set_stream(stream_);
-        cache_.infer_and_train(nullptr, train);      // no host read-back of the batch filter: every batch runs
-        NRC_HIP(hipEventRecord(ev_[3], stream_));
+                          (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, B);
+        NRC_HIP(hipEventRecord(ev_[2], B));
+        if (B != A && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(A, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
+        cache_.set_stream(A);
+        cache_.infer_all(nullptr, A);                // no host read-back of the batch filter: every batch runs
+        NRC_HIP(hipEventRecord(ev_[3], A));
+        if (train) cache_.train_all(B, B != A ? ev_[3] : nullptr);
+        NRC_HIP(hipEventRecord(ev_[5], B));
+        NRC_HIP(hipEventRecord(ev_train_done_[pp], B));
         launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
-                         (const float*)d_infer_out_, (float*)d_out_, stream_);
-        NRC_HIP(hipEventRecord(ev_[4], stream_));
+                         (const float*)d_infer_out_, (float*)d_out_, A);
+        NRC_HIP(hipEventRecord(ev_[4], A));
+        frame_index_++;
         timed_ = true;
     }
 
+    // everything this renderer has enqueued (both streams) is complete
+    void sync() { NRC_HIP(hipStreamSynchronize(stream_)); if (stream_b_) NRC_HIP(hipStreamSynchronize(stream_b_)); }
+
     void set_camera(const nrc_camera& c)       // SetCamera, :561-604: reset blending, clear the accumulation images
     {
+        sync();
         cam_ = to_dev(c);
         blend_index_ = 1;
         const size_t px = (size_t)w_ * h_;
         NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
         NRC_HIP(hipMemsetAsync(d_primary_, 0, px * 16, stream_));
-        NRC_HIP(hipMemsetAsync(d_info_, 0, px * 4, stream_));
+        for (int k = 0; k < 2; k++) NRC_HIP(hipMemsetAsync(d_info2_[k], 0, px * 4, stream_));
     }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }      // :606-610
     void set_show_nrc(bool s) { show_nrc_ = s ? 1u : 0u; }
@@ -321,16 +363,11 @@ public:
     {
         const size_t n = ev_used_;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (n > 0) NRC_HIP(hipEventSynchronize(ev_pool_[n - 1][4]));
+        if (n > 0) { NRC_HIP(hipEventSynchronize(ev_pool_[n - 1][4])); NRC_HIP(hipEventSynchronize(ev_pool_[n - 1][5])); }
         for (size_t f = 0; f < n; f++) {
-            hipEvent_t* e = ev_pool_[f].data();
-            float gen = 0, prep = 0, nrc = 0, comp = 0, total = 0;
-            NRC_HIP(hipEventElapsedTime(&gen, e[0], e[1]));
-            NRC_HIP(hipEventElapsedTime(&prep, e[1], e[2]));
-            NRC_HIP(hipEventElapsedTime(&nrc, e[2], e[3]));
-            NRC_HIP(hipEventElapsedTime(&comp, e[3], e[4]));
-            NRC_HIP(hipEventElapsedTime(&total, e[0], e[4]));
-            acc[1] += gen; acc[4] += prep; acc[5] += nrc; acc[6] += comp; acc[7] += total;
+            float st[8];
+            stage_times(ev_pool_[f].data(), st);
+            for (int k = 0; k < 8; k++) acc[k] += st[k];
         }
         if (avg8) for (int k = 0; k < 8; k++) avg8[k] = n ? (float)(acc[k] / (double)n) : 0.0f;
         if (reset) { ev_used_ = 0; timed_ = false; }
@@ -342,14 +379,28 @@ public:
         if (!timed_ || ev_used_ == 0) return 0.0f;
         hipEvent_t* ev_ = ev_pool_[ev_used_ - 1].data();
         NRC_HIP(hipEventSynchronize(ev_[4]));
-        float gen = 0, prep = 0, nrc = 0, comp = 0, total = 0;
-        NRC_HIP(hipEventElapsedTime(&gen, ev_[0], ev_[1]));
-        NRC_HIP(hipEventElapsedTime(&prep, ev_[1], ev_[2]));
-        NRC_HIP(hipEventElapsedTime(&nrc, ev_[2], ev_[3]));
-        NRC_HIP(hipEventElapsedTime(&comp, ev_[3], ev_[4]));
-        NRC_HIP(hipEventElapsedTime(&total, ev_[0], ev_[4]));
-        if (stage) { stage[0] = 0; stage[1] = gen; stage[2] = 0; stage[3] = 0; stage[4] = prep; stage[5] = nrc; stage[6] = comp; stage[7] = total; }
-        return total;
+        NRC_HIP(hipEventSynchronize(ev_[5]));
+        float st[8];
+        stage_times(ev_, st);
+        if (stage) for (int k = 0; k < 8; k++) stage[k] = st[k];
+        return st[7];
+    }
+
+    // {clear(0), gen_rays, prep_infer(0: fused into gen_rays), train (second stream), prep_train (second stream),
+    //  inference, composite, total}
+    static void stage_times(hipEvent_t* e, float* st)
+    {
+        float gen = 0, prep = 0, inf = 0, trn = 0, comp = 0, total = 0;
+        NRC_HIP(hipEventElapsedTime(&gen, e[0], e[1]));
+        NRC_HIP(hipEventElapsedTime(&prep, e[1], e[2]));
+        NRC_HIP(hipEventElapsedTime(&inf, e[1], e[3]));
+        NRC_HIP(hipEventElapsedTime(&trn, e[2], e[5]));
+        NRC_HIP(hipEventElapsedTime(&comp, e[3], e[4]));
+        float ta = 0, tb = 0;
+        NRC_HIP(hipEventElapsedTime(&ta, e[0], e[4]));
+        NRC_HIP(hipEventElapsedTime(&tb, e[0], e[5]));
+        total = ta > tb ? ta : tb;       // latency of this frame; throughput is higher (frames are pipelined)
+        st[0] = 0; st[1] = gen; st[2] = 0; st[3] = trn; st[4] = prep; st[5] = inf; st[6] = comp; st[7] = total;
     }
 
     void export_exr(const char* path)
@@ -362,6 +413,7 @@ public:
 
     void* buffer(int which, size_t* bytes)
     {
+        sync();      // intermediate buffers are produced on both streams
         const size_t px = (size_t)w_ * h_, T = (size_t)tg_.tw * tg_.th;
         void* p = nullptr; size_t b = 0;
         switch (which) {
@@ -424,10 +476,14 @@ private:
     TrainGrid tg_{};
     size_t ring_entries_ = 0;
     void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
+    void *d_info2_[2] = {nullptr, nullptr}, *d_origin2_[2] = {nullptr, nullptr}, *d_dir2_[2] = {nullptr, nullptr};
+    hipEvent_t ev_train_done_[2] = {nullptr, nullptr};
+    uint64_t frame_index_ = 0;
     void *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
     void *d_ring_ = nullptr, *d_scratch_ = nullptr, *d_fetch_ = nullptr;
     std::vector<void*> allocs_;
-    std::vector<std::array<hipEvent_t, 5>> ev_pool_;
+    std::vector<std::array<hipEvent_t, 10>> ev_pool_;
+    hipStream_t stream_b_ = nullptr;
     size_t ev_used_ = 0;
     bool timed_ = false;
     float pinned_random_[4] = {0, 0, 0, 0};
@@ -692,7 +748,7 @@ int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frame
 int nrc_renderer_destroy(nrc_renderer_t* r)
 {
     if (!r) return NRC_OK;
-    return guarded([&] { (void)hipStreamSynchronize(r->impl.stream()); delete r; });
+    return guarded([&] { r->impl.sync(); delete r; });
 }
 void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes)
 {

@@ -1,6 +1,7 @@
 // nrc_integrator.hip -- headless HIP path integrator for gfx950: one lane per pixel path, density grid as R8 in HBM
-// (served from L2 / Infinity Cache), HDR framebuffer out.  Compiled with -ffp-contract=off: together with
-// nrc_math.h this makes every per-pixel branch decision reproducible against the CPU oracle.
+// (served from L2 / Infinity Cache), HDR framebuffer out.  Compiled with -ffp-contract=off and with every fused
+// multiply-add written explicitly (nrc_fmaf_): together with nrc_math.h this makes every per-pixel branch decision
+// reproducible against the CPU oracle.
 //
 // Restates (paths relative to the reference checkout):
 //   data/shader/include/random.glsl      hash RNG                         -> Rng
@@ -26,13 +27,14 @@ __device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, 
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 mul(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return nrc_fmaf_(a.z, b.z, nrc_fmaf_(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ V3 normalize(V3 a)
 {
-    float l = length(a);
-    return v3(a.x / l, a.y / l, a.z / l);
+    float inv = 1.0f / length(a);
+    return v3(a.x * inv, a.y * inv, a.z * inv);
 }
+__device__ __forceinline__ V3 madd(V3 d, float t, V3 o) { return v3(nrc_fmaf_(d.x, t, o.x), nrc_fmaf_(d.y, t, o.y), nrc_fmaf_(d.z, t, o.z)); }   // o + d*t
 
 // ---- include/random.glsl:24-70
 __device__ __forceinline__ uint32_t hash1(uint32_t x)
@@ -81,14 +83,14 @@ __device__ __forceinline__ void find_entry_exit(const DevScene& s, V3 ro, V3 rd,
     float dist;
     do {
         dist = sky_sdf(s, ro);
-        ro = add(ro, mul(rd, dist));
+        ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
     *entry = ro;
-    ro = add(ro, mul(rd, s.len2size));
+    ro = madd(rd, s.len2size, ro);
     rd = neg(rd);
     do {
         dist = sky_sdf(s, ro);
-        ro = add(ro, mul(rd, dist));
+        ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
     *exit_ = ro;
 }
@@ -97,9 +99,9 @@ __device__ __forceinline__ void find_entry_exit(const DevScene& s, V3 ro, V3 rd,
 __device__ __forceinline__ float get_density(Ctx& c, V3 p)
 {
     const DevScene& s = c.sc;
-    float u = p.x * s.inv_size[0] + 0.5f;
-    float v = p.y * s.inv_size[1] + 0.5f;
-    float w = p.z * s.inv_size[2] + 0.5f;
+    float u = nrc_fmaf_(p.x, s.inv_size[0], 0.5f);
+    float v = nrc_fmaf_(p.y, s.inv_size[1], 0.5f);
+    float w = nrc_fmaf_(p.z, s.inv_size[2], 0.5f);
     float fx = u * s.fnx, fy = v * s.fny, fz = w * s.fnz;
     c.fetches++;
     if (!(fx >= 0.0f && fx < s.fnx && fy >= 0.0f && fy < s.fny && fz >= 0.0f && fz < s.fnz)) return 0.0f;
@@ -113,7 +115,7 @@ __device__ __forceinline__ float hg_phase(const DevScene& s, float cos_theta)
 {
     float g = s.g;
     float g2 = g * g;
-    float x = (1.0f + g2) - (2.0f * g) * cos_theta;
+    float x = nrc_fmaf_(-(2.0f * g), cos_theta, 1.0f + g2);
     return (0.5f * (1.0f - g2)) / (x * sqrtf(x));
 }
 
@@ -123,11 +125,13 @@ __device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
     float s, co;
     nrc_sincosf(angle, &s, &co);
     float oc = 1.0f - co;
-    V3 c0 = v3(oc * axis.x * axis.x + co, oc * axis.x * axis.y - axis.z * s, oc * axis.z * axis.x + axis.y * s);
-    V3 c1 = v3(oc * axis.x * axis.y + axis.z * s, oc * axis.y * axis.y + co, oc * axis.y * axis.z - axis.x * s);
-    V3 c2 = v3(oc * axis.z * axis.x - axis.y * s, oc * axis.y * axis.z + axis.x * s, oc * axis.z * axis.z + co);
-    return v3((c0.x * v.x + c1.x * v.y) + c2.x * v.z, (c0.y * v.x + c1.y * v.y) + c2.y * v.z,
-              (c0.z * v.x + c1.z * v.y) + c2.z * v.z);
+    const float ox = oc * axis.x, oy = oc * axis.y, oz = oc * axis.z;
+    V3 c0 = v3(nrc_fmaf_(ox, axis.x, co), nrc_fmaf_(ox, axis.y, -(axis.z * s)), nrc_fmaf_(oz, axis.x, axis.y * s));
+    V3 c1 = v3(nrc_fmaf_(ox, axis.y, axis.z * s), nrc_fmaf_(oy, axis.y, co), nrc_fmaf_(oy, axis.z, -(axis.x * s)));
+    V3 c2 = v3(nrc_fmaf_(oz, axis.x, -(axis.y * s)), nrc_fmaf_(oy, axis.z, axis.x * s), nrc_fmaf_(oz, axis.z, co));
+    return v3(nrc_fmaf_(c2.x, v.z, nrc_fmaf_(c1.x, v.y, c0.x * v.x)),
+              nrc_fmaf_(c2.y, v.z, nrc_fmaf_(c1.y, v.y, c0.y * v.x)),
+              nrc_fmaf_(c2.z, v.z, nrc_fmaf_(c1.z, v.y, c0.z * v.x)));
 }
 
 __device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_sampling)
@@ -143,8 +147,8 @@ __device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_samplin
         if (fabsf(g) < 0.001f) {
             cos_theta = 1.0f - 2.0f * c.rand(1.0f);
         } else {
-            float sqr_term = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * c.rand(1.0f));
-            cos_theta = ((1.0f + g * g) - sqr_term * sqr_term) / (2.0f * g);
+            float sqr_term = (1.0f - g * g) / nrc_fmaf_(2.0f * g, c.rand(1.0f), 1.0f - g);
+            cos_theta = nrc_fmaf_(-sqr_term, sqr_term, 1.0f + g * g) / (2.0f * g);
         }
         angle = nrc_acosf_clamped(cos_theta);
     } else {
@@ -164,10 +168,10 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
     float t_max = length(d);
     float tr = 1.0f, t = 0.0f;
     for (uint32_t i = 0; i < 128; i++) {
-        t -= nrc_logf(1.0f - c.rand(1.0f)) * c.sc.inv_max_density;
+        t = nrc_fmaf_(-nrc_logf(1.0f - c.rand(1.0f)), c.sc.inv_max_density, t);
         if (t >= t_max) break;
-        V3 p = add(start, mul(dir, t));
-        tr *= 1.0f - get_density(c, p) * c.sc.inv_max_density;
+        V3 p = madd(dir, t, start);
+        tr *= nrc_fmaf_(-get_density(c, p), c.sc.inv_max_density, 1.0f);
     }
     return tr;
 }
@@ -216,9 +220,9 @@ __device__ __forceinline__ V3 env_lookup(const DevScene& s, float u, float v)
     float r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float a = p00[k] + wx * (p10[k] - p00[k]);
-        float b = p01[k] + wx * (p11[k] - p01[k]);
-        r[k] = (a + wy * (b - a)) * s.env_strength;
+        float a = nrc_fmaf_(wx, p10[k] - p00[k], p00[k]);
+        float b = nrc_fmaf_(wx, p11[k] - p01[k], p01[k]);
+        r[k] = nrc_fmaf_(wy, b - a, a) * s.env_strength;
     }
     return v3(r[0], r[1], r[2]);
 }
@@ -227,7 +231,7 @@ __device__ __forceinline__ V3 sample_env_dir(const DevScene& s, V3 dir)
 {
     float phi = nrc_atan2f(dir.z, dir.x);
     float theta = nrc_asinf(dir.y);
-    return env_lookup(s, phi * 0.1591f + 0.5f, theta * 0.3183f + 0.5f);
+    return env_lookup(s, nrc_fmaf_(phi, 0.1591f, 0.5f), nrc_fmaf_(theta, 0.3183f, 0.5f));
 }
 
 __device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir)
@@ -258,26 +262,26 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
     float t_max = length(sub(ex, ro));
     float t = 0.0f;
     for (uint32_t i = 0; i < 128; i++) {
-        t -= nrc_logf(1.0f - c.rand(1.0f)) * c.sc.inv_max_density;
+        t = nrc_fmaf_(-nrc_logf(1.0f - c.rand(1.0f)), c.sc.inv_max_density, t);
         if (t >= t_max) {
             *volume_exit = true;
             break;
         }
-        V3 p = add(ro, mul(rd, t));
+        V3 p = madd(rd, t, ro);
         if (get_density(c, p) * c.sc.inv_max_density > c.rand(1.0f)) return p;
     }
-    return add(ro, mul(rd, c.rand(t_max)));
+    return madd(rd, c.rand(t_max), ro);
 }
 
 // camera ray: mc/render.comp:42-60, nrc/gen_rays.comp:53-72 (no half-pixel offset, no y flip)
 __device__ __forceinline__ void camera_ray(const DevCamera& cam, float u, float v, V3* ro, V3* rd)
 {
-    float sx = u * 2.0f - 1.0f, sy = v * 2.0f - 1.0f;
+    float sx = nrc_fmaf_(u, 2.0f, -1.0f), sy = nrc_fmaf_(v, 2.0f, -1.0f);
     const float* m = cam.m;
-    float wx = ((m[0] * sx + m[4] * sy) + m[8] * 0.0f) + m[12];
-    float wy = ((m[1] * sx + m[5] * sy) + m[9] * 0.0f) + m[13];
-    float wz = ((m[2] * sx + m[6] * sy) + m[10] * 0.0f) + m[14];
-    float ww = ((m[3] * sx + m[7] * sy) + m[11] * 0.0f) + m[15];
+    float wx = nrc_fmaf_(m[4], sy, nrc_fmaf_(m[0], sx, m[12]));
+    float wy = nrc_fmaf_(m[5], sy, nrc_fmaf_(m[1], sx, m[13]));
+    float wz = nrc_fmaf_(m[6], sy, nrc_fmaf_(m[2], sx, m[14]));
+    float ww = nrc_fmaf_(m[7], sy, nrc_fmaf_(m[3], sx, m[15]));
     V3 p = v3(wx / ww, wy / ww, wz / ww);
     *ro = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
     *rd = normalize(sub(p, *ro));
@@ -432,49 +436,46 @@ __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, 
                                                     uint32_t* __restrict__ ring, uint32_t* __restrict__ scratch)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
     const uint32_t T = tg.tw * tg.th;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < T; base += 1024u) {
-        const uint32_t i = base + tid;
-        uint32_t f = 0;
-        if (i < T) {
-            const uint32_t tx = i % tg.tw, ty = i / tg.tw;
-            const uint32_t rx = tx * tg.x_dist, ry = ty * tg.y_dist;
-            f = (rx < fr.w && ry < fr.h) ? (info[(size_t)ry * fr.w + rx] == 1.0f ? 1u : 0u) : 0u;   // OOB imageLoad -> 0 (Q1)
-        }
-        // wave-inclusive scan of f
-        uint32_t incl = f;
+    // each thread owns a contiguous run of train indices: local count -> block-wide exclusive scan -> ranks
+    const uint32_t per = (T + 1023u) / 1024u;
+    const uint32_t i0 = tid * per, i1 = min(i0 + per, T);
+    uint32_t cnt = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t tx = i % tg.tw, ty = i / tg.tw;
+        const uint32_t rx = tx * tg.x_dist, ry = ty * tg.y_dist;
+        const uint32_t f = (rx < fr.w && ry < fr.h) ? (info[(size_t)ry * fr.w + rx] == 1.0f ? 1u : 0u) : 0u;   // OOB imageLoad -> 0 (Q1)
+        scratch[i] = f;
+        cnt += f;
+    }
+    uint32_t incl = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(incl, off);
-            if ((int)lane >= off) incl += t;
-        }
-        if (lane == 63u) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl_push = carry + woff + incl - f;      // scattered entries before i
-        if (i < T) {
-            scratch[i] = f;
-            scratch[T + i] = f ? excl_push : (i - excl_push);
-        }
-        __syncthreads();
-        if (tid == 1023u) carry_s = carry + woff + incl;
-        __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += t;
+    }
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; w++) {
+        if (w < wave) woff += wsum[w];
+        total += wsum[w];
+    }
+    uint32_t push_rank = woff + incl - cnt;        // scattered entries before i0
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t f = scratch[i];
+        scratch[T + i] = f ? push_rank : (i - push_rank);
+        push_rank += f;
     }
     if (tid == 0) {
-        const uint32_t n_push = carry_s;
         uint32_t head = ring[0], tail = ring[1];
         if (tg.ring_size > 0) {          // clear.comp:5-9
             head %= tg.ring_size;
             tail %= tg.ring_size;
         }
-        scratch[2 * T] = n_push;
-        scratch[2 * T + 1] = T - n_push;
+        scratch[2 * T] = total;
+        scratch[2 * T + 1] = T - total;
         scratch[2 * T + 2] = head;
         scratch[2 * T + 3] = tail;
     }

@@ -4,9 +4,9 @@
  * The reference calls GLSL built-ins (log, sin, cos, acos, asin, atan: data/shader/include/path_trace.glsl:36,163,
  * dir_gen.glsl:11-12,49, path_trace.glsl:83, nrc/prep_infer_rays.comp:13-15) whose results are implementation
  * defined.  To make per-pixel control flow reproducible between the CPU oracle and the HIP kernels this build
- * defines them: Cephes-style single-precision polynomials evaluated with plain fp32 mul/add (translation units
- * that include this header are compiled with -ffp-contract=off; hipcc's default correctly rounded fp32 / and sqrt
- * are relied upon).  tests/test_math_parity.py checks these bit-for-bit against the oracle's own statement.
+ * defines them: Cephes-style single-precision polynomials whose Horner steps are explicit single-rounding fused
+ * multiply-adds (v_fma_f32 == fmaf on the host); translation units that include this header are compiled with
+ * -ffp-contract=off so that nothing else is contracted; hipcc's default correctly rounded fp32 / and sqrt are relied upon.  tests/test_math_parity.py checks these bit-for-bit against the oracle's own statement.
  */
 #ifndef NRC_MATH_H
 #define NRC_MATH_H
@@ -25,6 +25,10 @@
 #define NRC_HALF_PI 1.57079637050628662f
 #define NRC_QUARTER_PI 0.785398185253143311f
 
+
+/* single-rounding multiply-add: fmaf on the host, v_fma_f32 on the device -- both IEEE, hence bit-identical */
+NRC_HD static inline float nrc_fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 NRC_HD static inline uint32_t nrc_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 NRC_HD static inline float nrc_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
@@ -38,21 +42,21 @@ NRC_HD static inline float nrc_logf(float x)
     else { m = m - 1.0f; }
     float z = m * m;
     float y = 7.0376836292E-2f;
-    y = y * m + -1.1514610310E-1f;
-    y = y * m + 1.1676998740E-1f;
-    y = y * m + -1.2420140846E-1f;
-    y = y * m + 1.4249322787E-1f;
-    y = y * m + -1.6668057665E-1f;
-    y = y * m + 2.0000714765E-1f;
-    y = y * m + -2.4999993993E-1f;
-    y = y * m + 3.3333331174E-1f;
+    y = nrc_fmaf_(y, m, -1.1514610310E-1f);
+    y = nrc_fmaf_(y, m, 1.1676998740E-1f);
+    y = nrc_fmaf_(y, m, -1.2420140846E-1f);
+    y = nrc_fmaf_(y, m, 1.4249322787E-1f);
+    y = nrc_fmaf_(y, m, -1.6668057665E-1f);
+    y = nrc_fmaf_(y, m, 2.0000714765E-1f);
+    y = nrc_fmaf_(y, m, -2.4999993993E-1f);
+    y = nrc_fmaf_(y, m, 3.3333331174E-1f);
     y = y * m;
     y = y * z;
     float fe = (float)e;
-    y = y + -2.12194440e-4f * fe;
-    y = y + -0.5f * z;
+    y = nrc_fmaf_(-2.12194440e-4f, fe, y);
+    y = nrc_fmaf_(-0.5f, z, y);
     z = m + y;
-    z = z + 0.693359375f * fe;
+    z = nrc_fmaf_(0.693359375f, fe, z);
     return z;
 }
 
@@ -63,21 +67,21 @@ NRC_HD static inline void nrc_sincosf(float x, float* s_out, float* c_out)
     uint32_t j = (uint32_t)(ax * 1.27323949337005615f); /* 4/pi */
     j = (j + 1u) & ~1u;
     float y = (float)j;
-    float r = ax - y * 0.78515625f;
-    r = r - y * 2.4187564849853515625e-4f;
-    r = r - y * 3.77489497744594108e-8f;
+    float r = nrc_fmaf_(-y, 0.78515625f, ax);
+    r = nrc_fmaf_(-y, 2.4187564849853515625e-4f, r);
+    r = nrc_fmaf_(-y, 3.77489497744594108e-8f, r);
     float z = r * r;
     float ps = -1.9515295891E-4f;
-    ps = ps * z + 8.3321608736E-3f;
-    ps = ps * z + -1.6666654611E-1f;
+    ps = nrc_fmaf_(ps, z, 8.3321608736E-3f);
+    ps = nrc_fmaf_(ps, z, -1.6666654611E-1f);
     ps = ps * z;
-    ps = ps * r + r;
+    ps = nrc_fmaf_(ps, r, r);
     float pc = 2.443315711809948E-005f;
-    pc = pc * z + -1.388731625493765E-003f;
-    pc = pc * z + 4.166664568298827E-002f;
+    pc = nrc_fmaf_(pc, z, -1.388731625493765E-003f);
+    pc = nrc_fmaf_(pc, z, 4.166664568298827E-002f);
     pc = pc * z;
     pc = pc * z;
-    pc = pc - 0.5f * z;
+    pc = nrc_fmaf_(-0.5f, z, pc);
     pc = pc + 1.0f;
     uint32_t q = (j >> 1) & 3u;
     float s, c;
@@ -100,12 +104,12 @@ NRC_HD static inline float nrc_asinf(float x)
     if (big) { z = 0.5f * (1.0f - a); w = sqrtf(z); }
     else { w = a; z = a * a; }
     float p = 4.2163199048E-2f;
-    p = p * z + 2.4181311049E-2f;
-    p = p * z + 4.5470025998E-2f;
-    p = p * z + 7.4953002686E-2f;
-    p = p * z + 1.6666752422E-1f;
+    p = nrc_fmaf_(p, z, 2.4181311049E-2f);
+    p = nrc_fmaf_(p, z, 4.5470025998E-2f);
+    p = nrc_fmaf_(p, z, 7.4953002686E-2f);
+    p = nrc_fmaf_(p, z, 1.6666752422E-1f);
     p = p * z;
-    p = p * w + w;
+    p = nrc_fmaf_(p, w, w);
     if (big) { p = p + p; p = NRC_HALF_PI - p; }
     return x < 0.0f ? -p : p;
 }
@@ -136,11 +140,11 @@ NRC_HD static inline float nrc_atanf(float x)
     else { y = 0.0f; }
     float z = x * x;
     float p = 8.05374449538e-2f;
-    p = p * z + -1.38776856032E-1f;
-    p = p * z + 1.99777106478E-1f;
-    p = p * z + -3.33329491539E-1f;
+    p = nrc_fmaf_(p, z, -1.38776856032E-1f);
+    p = nrc_fmaf_(p, z, 1.99777106478E-1f);
+    p = nrc_fmaf_(p, z, -3.33329491539E-1f);
     p = p * z;
-    p = p * x + x;
+    p = nrc_fmaf_(p, x, x);
     y = y + p;
     return sgn * y;
 }

@@ -541,22 +541,29 @@ __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __rest
     }
 }
 
-// grad[i] = sum over chunk slabs in chunk order (bitwise reproducible); block 0 also folds the loss partials
-__global__ void k_reduce_grads(const float* __restrict__ slabs, uint32_t n_chunks, uint32_t n_params,
-                               float* __restrict__ grad, const float* __restrict__ loss_part, uint32_t n_loss,
-                               float* __restrict__ loss)
+// grad[i] = sum over chunk slabs in a fixed order (bitwise reproducible): a 256-thread block owns 64 parameters, four
+// thread groups each add a contiguous quarter of the slabs in chunk order, the four partials are combined in group order.
+// Block 0 also folds the loss partials.
+__global__ __launch_bounds__(256) void k_reduce_grads(const float* __restrict__ slabs, uint32_t n_chunks, uint32_t n_params,
+                                                     float* __restrict__ grad, const float* __restrict__ loss_part,
+                                                     uint32_t n_loss, float* __restrict__ loss)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_params) {
-        float s = 0.0f;
-        for (uint32_t c = 0; c < n_chunks; c++) s += slabs[(size_t)c * n_params + i];
-        grad[i] = s;
-    }
+    __shared__ float part[4][64];
+    __shared__ float red[256];
+    const uint32_t p = threadIdx.x & 63u, g = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64u + p;
+    const uint32_t per = (n_chunks + 3u) / 4u;
+    const uint32_t c0 = g * per, c1 = min(c0 + per, n_chunks);
+    float s = 0.0f;
+    if (i < n_params)
+        for (uint32_t c = c0; c < c1; c++) s += slabs[(size_t)c * n_params + i];
+    part[g][p] = s;
+    __syncthreads();
+    if (g == 0 && i < n_params) grad[i] = ((part[0][p] + part[1][p]) + part[2][p]) + part[3][p];
     if (blockIdx.x == 0) {
-        __shared__ float red[256];
-        float s = 0.0f;
-        for (uint32_t k = threadIdx.x; k < n_loss; k += blockDim.x) s += loss_part[k];
-        red[threadIdx.x] = s;
+        float l = 0.0f;
+        for (uint32_t k = threadIdx.x; k < n_loss; k += 256u) l += loss_part[k];
+        red[threadIdx.x] = l;
         __syncthreads();
         for (int off = 128; off >= 1; off >>= 1) {
             if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
@@ -888,7 +895,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
     hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_,
                        (const half_t*)d_acts_, n, depth_ * WIDTH + 8, ENC + depth_ * WIDTH, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_, n_params_);
     NRC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_slabs_, n_chunks, n_params_,
+    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_params_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_params_,
                        d_grad_, d_loss_part_, n_tiles, d_loss_);
     NRC_HIP(hipGetLastError());
 }

@@ -24,9 +24,10 @@ static inline V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline V3 mul(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 static inline V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
-static inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float dot(V3 a, V3 b) { return orc_fmaf_(a.z, b.z, orc_fmaf_(a.y, b.y, a.x * b.x)); }
 static inline float length(V3 a) { return sqrtf(dot(a, a)); }
-static inline V3 normalize(V3 a) { float l = length(a); return v3(a.x / l, a.y / l, a.z / l); }
+static inline V3 normalize(V3 a) { float inv = 1.0f / length(a); return v3(a.x * inv, a.y * inv, a.z * inv); }
+static inline V3 madd(V3 d, float t, V3 o) { return v3(orc_fmaf_(d.x, t, o.x), orc_fmaf_(d.y, t, o.y), orc_fmaf_(d.z, t, o.z)); }   /* o + d*t */
 
 /* ------------------------------------------------------------------ RNG: include/random.glsl */
 static inline uint32_t hash1(uint32_t x)               /* random.glsl:24-32 */
@@ -87,14 +88,14 @@ static inline void find_entry_exit(const Ctx& c, V3 ro, V3 rd, V3* entry, V3* ex
     float dist;
     do {
         dist = sky_sdf(c, ro);
-        ro = add(ro, mul(rd, dist));
+        ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
     *entry = ro;
-    ro = add(ro, mul(rd, c.len2size));
+    ro = madd(rd, c.len2size, ro);
     rd = neg(rd);
     do {
         dist = sky_sdf(c, ro);
-        ro = add(ro, mul(rd, dist));
+        ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
     *exit_ = ro;
 }
@@ -103,9 +104,9 @@ static inline void find_entry_exit(const Ctx& c, V3 ro, V3 rd, V3* entry, V3* ex
  * uvw = pos/size + 0.5 is evaluated as pos*(1/size) + 0.5 (DESIGN.md "math spec"). */
 static inline float get_density(Ctx& c, V3 p)
 {
-    float u = p.x * c.inv_size.x + 0.5f;
-    float v = p.y * c.inv_size.y + 0.5f;
-    float w = p.z * c.inv_size.z + 0.5f;
+    float u = orc_fmaf_(p.x, c.inv_size.x, 0.5f);
+    float v = orc_fmaf_(p.y, c.inv_size.y, 0.5f);
+    float w = orc_fmaf_(p.z, c.inv_size.z, 0.5f);
     float fx = u * c.fnx, fy = v * c.fny, fz = w * c.fnz;
     c.fetches++;
     if (!(fx >= 0.0f && fx < c.fnx && fy >= 0.0f && fy < c.fny && fz >= 0.0f && fz < c.fnz)) return 0.0f;
@@ -119,7 +120,7 @@ static inline float hg_phase(const Ctx& c, float cos_theta)      /* dir_gen.glsl
 {
     float g = c.sc->g;
     float g2 = g * g;
-    float x = (1.0f + g2) - (2.0f * g) * cos_theta;
+    float x = orc_fmaf_(-(2.0f * g), cos_theta, 1.0f + g2);
     return (0.5f * (1.0f - g2)) / (x * sqrtf(x));
 }
 
@@ -131,12 +132,13 @@ static inline V3 rotate(V3 axis, float angle, V3 v)
     orc_sincosf(angle, &s, &co);
     float oc = 1.0f - co;
     /* columns of the mat4 as written in the shader */
-    V3 c0 = v3(oc * axis.x * axis.x + co, oc * axis.x * axis.y - axis.z * s, oc * axis.z * axis.x + axis.y * s);
-    V3 c1 = v3(oc * axis.x * axis.y + axis.z * s, oc * axis.y * axis.y + co, oc * axis.y * axis.z - axis.x * s);
-    V3 c2 = v3(oc * axis.z * axis.x - axis.y * s, oc * axis.y * axis.z + axis.x * s, oc * axis.z * axis.z + co);
-    return v3((c0.x * v.x + c1.x * v.y) + c2.x * v.z,
-              (c0.y * v.x + c1.y * v.y) + c2.y * v.z,
-              (c0.z * v.x + c1.z * v.y) + c2.z * v.z);
+    const float ox = oc * axis.x, oy = oc * axis.y, oz = oc * axis.z;
+    V3 c0 = v3(orc_fmaf_(ox, axis.x, co), orc_fmaf_(ox, axis.y, -(axis.z * s)), orc_fmaf_(oz, axis.x, axis.y * s));
+    V3 c1 = v3(orc_fmaf_(ox, axis.y, axis.z * s), orc_fmaf_(oy, axis.y, co), orc_fmaf_(oy, axis.z, -(axis.x * s)));
+    V3 c2 = v3(orc_fmaf_(oz, axis.x, -(axis.y * s)), orc_fmaf_(oy, axis.z, axis.x * s), orc_fmaf_(oz, axis.z, co));
+    return v3(orc_fmaf_(c2.x, v.z, orc_fmaf_(c1.x, v.y, c0.x * v.x)),
+              orc_fmaf_(c2.y, v.z, orc_fmaf_(c1.y, v.y, c0.y * v.x)),
+              orc_fmaf_(c2.z, v.z, orc_fmaf_(c1.z, v.y, c0.z * v.x)));
 }
 
 static inline V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_sampling)    /* dir_gen.glsl:22-64 */
@@ -154,8 +156,8 @@ static inline V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_sampling)    /* dir_
         if (fabsf(g) < 0.001f) {
             cos_theta = 1.0f - 2.0f * c.rand(1.0f);
         } else {
-            float sqr_term = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * c.rand(1.0f));
-            cos_theta = ((1.0f + g * g) - sqr_term * sqr_term) / (2.0f * g);
+            float sqr_term = (1.0f - g * g) / orc_fmaf_(2.0f * g, c.rand(1.0f), 1.0f - g);
+            cos_theta = orc_fmaf_(-sqr_term, sqr_term, 1.0f + g * g) / (2.0f * g);
         }
         angle = orc_acosf_clamped(cos_theta);
     } else {
@@ -175,10 +177,10 @@ static inline float ratio_track(Ctx& c, V3 start, V3 end)       /* path_trace.gl
     float t_max = length(d);
     float tr = 1.0f, t = 0.0f;
     for (uint32_t i = 0; i < 128; i++) {
-        t -= orc_logf(1.0f - c.rand(1.0f)) * c.inv_max_density;
+        t = orc_fmaf_(-orc_logf(1.0f - c.rand(1.0f)), c.inv_max_density, t);
         if (t >= t_max) break;
-        V3 p = add(start, mul(dir, t));
-        tr *= 1.0f - get_density(c, p) * c.inv_max_density;
+        V3 p = madd(dir, t, start);
+        tr *= orc_fmaf_(-get_density(c, p), c.inv_max_density, 1.0f);
     }
     return tr;
 }
@@ -227,9 +229,9 @@ static inline V3 env_lookup(const Ctx& c, float u, float v)
     const float* p11 = s->env + 4 * ((size_t)y1 * s->env_w + x1);
     float r[3];
     for (int k = 0; k < 3; k++) {
-        float a = p00[k] + wx * (p10[k] - p00[k]);
-        float b = p01[k] + wx * (p11[k] - p01[k]);
-        r[k] = (a + wy * (b - a)) * s->env_strength;
+        float a = orc_fmaf_(wx, p10[k] - p00[k], p00[k]);
+        float b = orc_fmaf_(wx, p11[k] - p01[k], p01[k]);
+        r[k] = orc_fmaf_(wy, b - a, a) * s->env_strength;
     }
     return v3(r[0], r[1], r[2]);
 }
@@ -238,7 +240,7 @@ static inline V3 sample_env_dir(const Ctx& c, V3 dir)           /* path_trace.gl
 {
     float phi = orc_atan2f(dir.z, dir.x);
     float theta = orc_asinf(dir.y);
-    return env_lookup(c, phi * 0.1591f + 0.5f, theta * 0.3183f + 0.5f);
+    return env_lookup(c, orc_fmaf_(phi, 0.1591f, 0.5f), orc_fmaf_(theta, 0.3183f, 0.5f));
 }
 
 static inline V3 sample_env(Ctx& c, V3 pos, V3 dir)             /* path_trace.glsl:88-131, sampleCount 1 */
@@ -269,12 +271,12 @@ static inline V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)    /* path
     float t_max = length(sub(ex, ro));
     float t = 0.0f;
     for (uint32_t i = 0; i < 128; i++) {
-        t -= orc_logf(1.0f - c.rand(1.0f)) * c.inv_max_density;
+        t = orc_fmaf_(-orc_logf(1.0f - c.rand(1.0f)), c.inv_max_density, t);
         if (t >= t_max) { *volume_exit = true; break; }
-        V3 p = add(ro, mul(rd, t));
+        V3 p = madd(rd, t, ro);
         if (get_density(c, p) * c.inv_max_density > c.rand(1.0f)) return p;
     }
-    return add(ro, mul(rd, c.rand(t_max)));
+    return madd(rd, c.rand(t_max), ro);
 }
 
 /* ------------------------------------------------------------------ camera ray (mc/render.comp:42-60, nrc/gen_rays.comp:53-72) */
@@ -283,12 +285,12 @@ static inline void camera_ray(const orc_camera* cam, uint32_t W, uint32_t H, uin
 {
     float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
     float u = (float)x * inv_w, v = (float)y * inv_h;
-    float sx = u * 2.0f - 1.0f, sy = v * 2.0f - 1.0f;
+    float sx = orc_fmaf_(u, 2.0f, -1.0f), sy = orc_fmaf_(v, 2.0f, -1.0f);
     const float* m = cam->inv_proj_view;      /* column-major: m[4*col+row]; screen = (sx, sy, 0, 1) */
-    float wx = ((m[0] * sx + m[4] * sy) + m[8] * 0.0f) + m[12];
-    float wy = ((m[1] * sx + m[5] * sy) + m[9] * 0.0f) + m[13];
-    float wz = ((m[2] * sx + m[6] * sy) + m[10] * 0.0f) + m[14];
-    float ww = ((m[3] * sx + m[7] * sy) + m[11] * 0.0f) + m[15];
+    float wx = orc_fmaf_(m[4], sy, orc_fmaf_(m[0], sx, m[12]));
+    float wy = orc_fmaf_(m[5], sy, orc_fmaf_(m[1], sx, m[13]));
+    float wz = orc_fmaf_(m[6], sy, orc_fmaf_(m[2], sx, m[14]));
+    float ww = orc_fmaf_(m[7], sy, orc_fmaf_(m[3], sx, m[15]));
     V3 p = v3(wx / ww, wy / ww, wz / ww);
     *ro = v3(cam->pos[0], cam->pos[1], cam->pos[2]);
     *rd = normalize(sub(p, *ro));

@@ -6,8 +6,8 @@
  * dir_gen.glsl:11-12,49; path_trace.glsl:83; nrc/prep_infer_rays.comp:13-15).
  *
  * GLSL built-ins are implementation defined (no bit-exact spec), so this build *defines* them:
- * Cephes-style single-precision polynomials, evaluated with plain fp32 mul/add (no FMA
- * contraction, correctly rounded / and sqrt).  The HIP product carries its own statement of
+ * Cephes-style single-precision polynomials whose Horner steps are explicit single-rounding
+ * fused multiply-adds (fmaf on the host == v_fma_f32 on the device), correctly rounded / and sqrt.  The HIP product carries its own statement of
  * the same polynomials (nrc-hpm-renderer_amd/csrc/nrc_math.h); tests/test_math_parity.py checks
  * the two bit-for-bit on the GPU.  Compile with -ffp-contract=off.
  */
@@ -22,6 +22,10 @@
 #define ORC_HALF_PI 1.57079637050628662f
 #define ORC_QUARTER_PI 0.785398185253143311f
 
+
+/* single-rounding multiply-add: fmaf on the host, v_fma_f32 on the device -- both IEEE, hence bit-identical */
+static inline float orc_fmaf_(float a, float b, float c) { return fmaf(a, b, c); }
+
 static inline uint32_t orc_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float orc_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -35,21 +39,21 @@ static inline float orc_logf(float x)
     else { m = m - 1.0f; }
     float z = m * m;
     float y = 7.0376836292E-2f;
-    y = y * m + -1.1514610310E-1f;
-    y = y * m + 1.1676998740E-1f;
-    y = y * m + -1.2420140846E-1f;
-    y = y * m + 1.4249322787E-1f;
-    y = y * m + -1.6668057665E-1f;
-    y = y * m + 2.0000714765E-1f;
-    y = y * m + -2.4999993993E-1f;
-    y = y * m + 3.3333331174E-1f;
+    y = orc_fmaf_(y, m, -1.1514610310E-1f);
+    y = orc_fmaf_(y, m, 1.1676998740E-1f);
+    y = orc_fmaf_(y, m, -1.2420140846E-1f);
+    y = orc_fmaf_(y, m, 1.4249322787E-1f);
+    y = orc_fmaf_(y, m, -1.6668057665E-1f);
+    y = orc_fmaf_(y, m, 2.0000714765E-1f);
+    y = orc_fmaf_(y, m, -2.4999993993E-1f);
+    y = orc_fmaf_(y, m, 3.3333331174E-1f);
     y = y * m;
     y = y * z;
     float fe = (float)e;
-    y = y + -2.12194440e-4f * fe;
-    y = y + -0.5f * z;
+    y = orc_fmaf_(-2.12194440e-4f, fe, y);
+    y = orc_fmaf_(-0.5f, z, y);
     z = m + y;
-    z = z + 0.693359375f * fe;
+    z = orc_fmaf_(0.693359375f, fe, z);
     return z;
 }
 
@@ -60,21 +64,21 @@ static inline void orc_sincosf(float x, float* s_out, float* c_out)
     uint32_t j = (uint32_t)(ax * 1.27323949337005615f); /* 4/pi */
     j = (j + 1u) & ~1u;
     float y = (float)j;
-    float r = ax - y * 0.78515625f;
-    r = r - y * 2.4187564849853515625e-4f;
-    r = r - y * 3.77489497744594108e-8f;
+    float r = orc_fmaf_(-y, 0.78515625f, ax);
+    r = orc_fmaf_(-y, 2.4187564849853515625e-4f, r);
+    r = orc_fmaf_(-y, 3.77489497744594108e-8f, r);
     float z = r * r;
     float ps = -1.9515295891E-4f;
-    ps = ps * z + 8.3321608736E-3f;
-    ps = ps * z + -1.6666654611E-1f;
+    ps = orc_fmaf_(ps, z, 8.3321608736E-3f);
+    ps = orc_fmaf_(ps, z, -1.6666654611E-1f);
     ps = ps * z;
-    ps = ps * r + r;
+    ps = orc_fmaf_(ps, r, r);
     float pc = 2.443315711809948E-005f;
-    pc = pc * z + -1.388731625493765E-003f;
-    pc = pc * z + 4.166664568298827E-002f;
+    pc = orc_fmaf_(pc, z, -1.388731625493765E-003f);
+    pc = orc_fmaf_(pc, z, 4.166664568298827E-002f);
     pc = pc * z;
     pc = pc * z;
-    pc = pc - 0.5f * z;
+    pc = orc_fmaf_(-0.5f, z, pc);
     pc = pc + 1.0f;
     uint32_t q = (j >> 1) & 3u;
     float s, c;
@@ -97,12 +101,12 @@ static inline float orc_asinf(float x)
     if (big) { z = 0.5f * (1.0f - a); w = sqrtf(z); }
     else { w = a; z = a * a; }
     float p = 4.2163199048E-2f;
-    p = p * z + 2.4181311049E-2f;
-    p = p * z + 4.5470025998E-2f;
-    p = p * z + 7.4953002686E-2f;
-    p = p * z + 1.6666752422E-1f;
+    p = orc_fmaf_(p, z, 2.4181311049E-2f);
+    p = orc_fmaf_(p, z, 4.5470025998E-2f);
+    p = orc_fmaf_(p, z, 7.4953002686E-2f);
+    p = orc_fmaf_(p, z, 1.6666752422E-1f);
     p = p * z;
-    p = p * w + w;
+    p = orc_fmaf_(p, w, w);
     if (big) { p = p + p; p = ORC_HALF_PI - p; }
     return x < 0.0f ? -p : p;
 }
@@ -133,11 +137,11 @@ static inline float orc_atanf(float x)
     else { y = 0.0f; }
     float z = x * x;
     float p = 8.05374449538e-2f;
-    p = p * z + -1.38776856032E-1f;
-    p = p * z + 1.99777106478E-1f;
-    p = p * z + -3.33329491539E-1f;
+    p = orc_fmaf_(p, z, -1.38776856032E-1f);
+    p = orc_fmaf_(p, z, 1.99777106478E-1f);
+    p = orc_fmaf_(p, z, -3.33329491539E-1f);
     p = p * z;
-    p = p * x + x;
+    p = orc_fmaf_(p, x, x);
     y = y + p;
     return sgn * y;
 }

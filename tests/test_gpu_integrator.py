@@ -168,7 +168,7 @@ def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu
     # Adam normalises every element to +-lr: elements whose gradient is ~0 +- fp16 noise may flip sign, hence the slack
     assert rel(nrc.GetParams(1), onn.buffer(1)) < 3e-3
     st = ren.EvaluateTimestampQueries()
-    assert st["total"] > 0 and st["gen_rays"] > 0 and st["nrc"] > 0
+    assert st["total"] > 0 and st["gen_rays"] > 0 and st["infer"] > 0 and st["train"] > 0
     # showNrc = 0 -> primary radiance only
     ren.SetBlend(False)
     ren.SetShowNrc(False)
