@@ -14,6 +14,10 @@
 //   data/shader/nrc/render.comp                                           -> k_composite
 //   data/shader/ref/{cmp1,norm,cmp2}.comp                                 -> k_compare_*
 #include "nrc_integrator.hpp"
+
+#include <cstdlib>
+#include <string>
+
 #include "nrc_math.h"
 
 namespace nrc {
@@ -95,7 +99,9 @@ __device__ __forceinline__ void find_entry_exit(const DevScene& s, V3 ro, V3 rd,
     *exit_ = ro;
 }
 
-// volume.glsl:31-39; sampler: R8 UNORM, NEAREST, CLAMP_TO_BORDER black (src/Texture3D.cpp:79-81,221)
+// volume.glsl:31-39; sampler: R8 UNORM, NEAREST, CLAMP_TO_BORDER black (src/Texture3D.cpp:79-81,221).
+// One byte per voxel, fetched with a 32-bit voxel index (24-bit mads); the per-axis border test is branch-free and
+// out-of-range lanes read voxel 0 and discard it.
 __device__ __forceinline__ float get_density(Ctx& c, V3 p)
 {
     const DevScene& s = c.sc;
@@ -104,10 +110,14 @@ __device__ __forceinline__ float get_density(Ctx& c, V3 p)
     float w = nrc_fmaf_(p.z, s.inv_size[2], 0.5f);
     float fx = u * s.fnx, fy = v * s.fny, fz = w * s.fnz;
     c.fetches++;
-    if (!(fx >= 0.0f && fx < s.fnx && fy >= 0.0f && fy < s.fny && fz >= 0.0f && fz < s.fnz)) return 0.0f;
-    uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
-    uint8_t t = s.density[(size_t)ix + (size_t)s.nx * ((size_t)iy + (size_t)s.ny * (size_t)iz)];
-    return s.density_factor * ((float)t * (1.0f / 255.0f));
+    const bool inb = (fx >= 0.0f) & (fx < s.fnx) & (fy >= 0.0f) & (fy < s.fny) & (fz >= 0.0f) & (fz < s.fnz);
+    const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
+    uint32_t idx = __umul24(iz, s.ny) + iy;
+    idx = idx * s.nx + ix;
+    idx = inb ? idx : 0u;
+    const uint8_t t = s.density[idx];
+    const float d = s.density_factor * ((float)t * (1.0f / 255.0f));
+    return inb ? d : 0.0f;
 }
 
 // ---- include/dir_gen.glsl
@@ -428,6 +438,267 @@ __global__ __launch_bounds__(256) void k_mc_render(DevScene sc, DevCamera cam, D
     count_fetches(fetch_counter, c.fetches);
 }
 
+// ------------------------------------------------------------------------------------------------ path engine
+// Per-lane state machine over the same per-pixel operation sequence as k_gen_rays / k_mc_render (identical arithmetic and
+// RNG draw order, hence identical results), restructured for wave64 utilisation:
+//   * every tracking loop of the shaders (DeltaTrack, the RatioTrack of each light) becomes the SAME one-step body, so lanes
+//     that are in different tracks -- or at different vertices -- still execute together;
+//   * the work between two tracks (finish a track, accumulate a light, NewRayDir, find_entry_exit, set up the next track)
+//     is served for many lanes at once: a service round runs when >= SERVICE_MIN lanes wait (or nobody can step);
+//   * a lane whose path is complete stores its pixel and takes the next pixel of the wave's range (persistent lanes), so
+//     cheap pixels (empty sky) do not leave lanes idle while expensive neighbours finish.
+enum : int { ST_DELTA = 0, ST_RDIR = 1, ST_RPOINT = 2, ST_RENV = 3, ST_IDLE = 4 };
+enum : int { NX_NONE = 0, NX_RDIR, NX_RPOINT, NX_RENV, NX_AFTER, NX_DELTA, NX_DONE };
+constexpr int PATH_MODE_NRC = 0, PATH_MODE_MC = 1;
+constexpr uint32_t ENGINE_SLOTS_PER_WAVE = 128;      // 2 tiles of 8x8 pixels per wave
+constexpr int SERVICE_MIN = 64;
+
+struct EngineOut {
+    float4* primary;       // NRC: colour + throughput | MC: framebuffer (blend)
+    float* info;
+    float4* origin;
+    float4* dirs;
+    float* infer_in;
+    float blend_factor;    // MC
+    uint32_t limit;        // NRC: PRIMARY_RAY_LENGTH | MC: PATH_LENGTH
+    float prob;            // NRC: PRIMARY_RAY_PROB
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_paths(DevScene sc, DevCamera cam, DevFrame fr, EngineOut o,
+                                              unsigned long long* fetch_counter, int service_num)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
+    const uint32_t total_slots = tiles_x * tiles_y * 64u;
+    uint32_t next_slot = wave_global * ENGINE_SLOTS_PER_WAVE;                 // wave-uniform
+    const uint32_t end_slot = min(next_slot + ENGINE_SLOTS_PER_WAVE, total_slots);
+
+    Ctx c{sc, 0.0f, 0u};
+    // ---- per-lane path state
+    int stage = ST_IDLE;
+    uint32_t lx = 0, y = 0;
+    V3 rd_cam = v3(0, 0, 0);
+    V3 cur = v3(0, 0, 0), dir = v3(0, 0, 0), light = v3(0, 0, 0);
+    float factor = 1.0f;
+    int vi = 0;
+    bool did_scatter = false;
+    float la = 0.0f;                       // dir-light term (equal components)
+    V3 lb = v3(0, 0, 0);                   // point-light term
+    V3 env_rdir = v3(0, 0, 0);
+    float env_phase = 0.0f;
+    // ---- current track
+    V3 S = v3(0, 0, 0), D = v3(0, 0, 0), P = v3(0, 0, 0);
+    float t = 0.0f, tmax = 0.0f, tr = 1.0f;
+    uint32_t iter = 0;
+    bool trk_done = false, hit = false, exitf = false;
+
+    const bool has_dir = sc.dir_light_strength != 0.0f, has_point = sc.point_light_strength != 0.0f,
+               has_env = sc.env_strength != 0.0f;
+    const V3 ld = v3(sc.dir_light_dir[0], sc.dir_light_dir[1], sc.dir_light_dir[2]);
+    const V3 lp = v3(sc.point_light_pos[0], sc.point_light_pos[1], sc.point_light_pos[2]);
+
+    for (;;) {
+        const bool idle = stage == ST_IDLE;
+        const unsigned long long idle_m = __ballot(idle);
+        const unsigned long long wait_m = __ballot(!idle && trk_done);
+        const unsigned long long act_m = __ballot(!idle && !trk_done);
+        const bool work_left = next_slot < end_slot;
+        const int n_need = __popcll(wait_m) + (work_left ? __popcll(idle_m) : 0);
+        if (n_need == 0 && act_m == 0ull) break;
+
+        // serve when a quarter of the lanes that still have something to do are waiting (at most SERVICE_MIN)
+        const int n_busy = __popcll(act_m) + n_need;
+        static_assert(SERVICE_MIN >= 1, "");
+        const int thresh = max(1, min(SERVICE_MIN, (n_busy * service_num) >> 3));
+        if (n_need > 0 && (n_need >= thresh || act_m == 0ull)) {
+            // ================================================================ service round
+            int next = NX_NONE;
+            bool need_fee = false;
+            V3 fee_o = v3(0, 0, 0), fee_d = v3(1, 0, 0);
+            bool path_done = false, miss = false;
+
+            // ---- (0) persistent lanes: take the next pixels of this wave's range
+            if (work_left) {
+                const uint32_t rank = __popcll(idle_m & ((1ull << lane) - 1ull));
+                const uint32_t slot = next_slot + rank;
+                if (idle && slot < end_slot) {
+                    const uint32_t tile = slot >> 6, within = slot & 63u;
+                    lx = (tile % tiles_x) * 8u + (within & 7u);
+                    y = (tile / tiles_x) * 8u + (within >> 3);
+                    if (lx < fr.w && y < fr.h) {
+                        const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+                        const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+                        V3 ro;
+                        camera_ray(cam, u, v, &ro, &rd_cam);
+                        init_random(c, u, v, fr.random);
+                        V3 entry, ex;
+                        find_entry_exit(sc, ro, rd_cam, &entry, &ex);
+                        light = v3(0, 0, 0);
+                        factor = 1.0f;
+                        vi = 0;
+                        did_scatter = false;
+                        if (sky_sdf(sc, entry) > 100000.0f) {
+                            miss = true;
+                            path_done = true;
+                        } else {
+                            cur = entry;
+                            dir = rd_cam;
+                            next = NX_DELTA;
+                        }
+                        stage = ST_DELTA;      // owns a pixel now (track set up below, or finished right away)
+                        trk_done = true;
+                    }
+                }
+                next_slot = min(next_slot + (uint32_t)__popcll(idle_m), end_slot);
+            }
+
+            // ---- (a) finish the track that just ended
+            if (!idle && trk_done && next == NX_NONE && !path_done) {
+                V3 le = v3(0, 0, 0);
+                if (stage == ST_DELTA) {
+                    if (!hit) P = madd(D, c.rand(tmax), S);        // path_trace.glsl:173 (also after 128 null collisions)
+                    cur = P;
+                    if (exitf) {
+                        path_done = true;
+                        next = NX_DONE;
+                    } else {
+                        did_scatter = true;
+                        factor *= 0.5f;
+                        la = 0.0f;
+                        lb = v3(0, 0, 0);
+                        next = has_dir ? NX_RDIR : (has_point ? NX_RPOINT : (has_env ? NX_RENV : NX_AFTER));
+                    }
+                } else if (stage == ST_RDIR) {
+                    const float phase = hg_phase(sc, dot(ld, neg(dir)));
+                    la = (1.0f * tr) * sc.dir_light_strength * phase;
+                    next = has_point ? NX_RPOINT : (has_env ? NX_RENV : NX_AFTER);
+                } else if (stage == ST_RPOINT) {
+                    const float phase = hg_phase(sc, dot(normalize(sub(lp, cur)), neg(dir)));
+                    lb = v3(((sc.point_light_color[0] * sc.point_light_strength) * tr) * phase,
+                            ((sc.point_light_color[1] * sc.point_light_strength) * tr) * phase,
+                            ((sc.point_light_color[2] * sc.point_light_strength) * tr) * phase);
+                    next = has_env ? NX_RENV : NX_AFTER;
+                } else {   // ST_RENV
+                    const V3 e = sample_env_dir(sc, env_rdir);
+                    le = v3((e.x * env_phase) * tr, (e.y * env_phase) * tr, (e.z * env_phase) * tr);
+                    next = NX_AFTER;
+                }
+                if (next == NX_AFTER) {            // TraceScene = dir + point + env, then * factor (gen_rays.comp:32-33)
+                    const V3 tot = add(add(v3(la, la, la), lb), le);
+                    light = add(light, mul(tot, factor));
+                }
+            }
+
+            // ---- (b) NewRayDir, shared: phase-function sampling after a vertex, uniform angle for the env estimator
+            if (next == NX_AFTER || next == NX_RENV) {
+                const V3 nd = new_ray_dir(c, dir, next == NX_AFTER);
+                if (next == NX_AFTER) {
+                    dir = nd;
+                    if (MODE == PATH_MODE_NRC) {          // gen_rays.comp:39-42
+                        if ((uint32_t)vi >= o.limit) {
+                            if (c.rand(1.0f) >= o.prob || vi == 128) path_done = true;
+                        }
+                        vi++;
+                    } else {                              // mc/render.comp:23
+                        vi++;
+                        if ((uint32_t)vi >= o.limit) path_done = true;
+                    }
+                    next = path_done ? NX_DONE : NX_DELTA;
+                } else {
+                    env_rdir = nd;
+                    env_phase = hg_phase(sc, dot(nd, neg(dir)));
+                }
+            }
+
+            // ---- (c) find_entry_exit, shared by every track that needs the volume exit
+            if (next == NX_DELTA) { need_fee = true; fee_o = cur; fee_d = dir; }
+            else if (next == NX_RDIR) { need_fee = true; fee_o = cur; fee_d = neg(normalize(ld)); }
+            else if (next == NX_RENV) { need_fee = true; fee_o = cur; fee_d = env_rdir; }
+            if (need_fee) {
+                V3 en, ex;
+                find_entry_exit(sc, fee_o, fee_d, &en, &ex);
+                // ---- (d) set up the next track
+                if (next == NX_DELTA) {            // DeltaTrack: unnormalised path direction, tMax = |exit - origin|
+                    S = cur; D = dir;
+                    tmax = length(sub(ex, cur));
+                    stage = ST_DELTA;
+                } else {                           // RatioTrack(pos, exit)
+                    const V3 d = sub(ex, cur);
+                    S = cur; D = normalize(d);
+                    tmax = length(d);
+                    stage = next == NX_RDIR ? ST_RDIR : ST_RENV;
+                }
+                t = 0.0f; tr = 1.0f; iter = 0; trk_done = false; hit = false; exitf = false;
+            } else if (next == NX_RPOINT) {        // RatioTrack(pointLight.pos, pos)
+                const V3 d = sub(cur, lp);
+                S = lp; D = normalize(d);
+                tmax = length(d);
+                stage = ST_RPOINT;
+                t = 0.0f; tr = 1.0f; iter = 0; trk_done = false; hit = false; exitf = false;
+            }
+
+            // ---- (e) completed paths: store the pixel, lane becomes idle
+            if (path_done) {
+                const size_t pix = (size_t)y * fr.w + lx;
+                V3 col = light;
+                float thr = factor;
+                if (!did_scatter) {
+                    col = sample_env_dir(sc, rd_cam);
+                    thr = 1.0f;
+                }
+                if (MODE == PATH_MODE_NRC) {
+                    float q[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    if (!miss) {
+                        o.origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
+                        o.dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+                        if (did_scatter) nrc_query(sc, cur, dir, q);
+                    }
+                    o.primary[pix] = make_float4(col.x, col.y, col.z, thr);
+                    o.info[pix] = did_scatter ? 1.0f : 0.0f;
+                    float* qo = o.infer_in + ((size_t)lx * fr.h + y) * 5u;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) qo[k] = q[k];
+                } else {
+                    const float a = did_scatter ? 1.0f : 0.0f;
+                    const float4 prev = o.primary[pix];
+                    const float bf = o.blend_factor, ib = 1.0f - bf;
+                    o.primary[pix] = make_float4(bf * col.x + ib * prev.x, bf * col.y + ib * prev.y,
+                                                 bf * col.z + ib * prev.z, bf * a + ib * prev.w);
+                    if (o.info) o.info[pix] = a;
+                }
+                stage = ST_IDLE;
+                trk_done = false;
+            }
+            continue;
+        }
+
+        // ================================================================ one tracking step for every lane that has a live track
+        if (!idle && !trk_done) {
+            t = nrc_fmaf_(-nrc_logf(1.0f - c.rand(1.0f)), sc.inv_max_density, t);
+            if (t >= tmax) {
+                exitf = true;
+                trk_done = true;
+            } else {
+                const V3 p = madd(D, t, S);
+                const float dens = get_density(c, p);
+                if (stage == ST_DELTA) {
+                    if (dens * sc.inv_max_density > c.rand(1.0f)) {
+                        hit = true;
+                        P = p;
+                        trk_done = true;
+                    }
+                } else {
+                    tr *= nrc_fmaf_(-dens, sc.inv_max_density, 1.0f);
+                }
+                if (++iter == 128u) trk_done = true;
+            }
+        }
+    }
+    count_fetches(fetch_counter, c.fetches);
+}
+
 // ------------------------------------------------------------------------------------------------ nrc/clear.comp + ring ordering
 // scratch layout: [0..T) scatter flag, [T..2T) exclusive rank among its kind (push rank if scattered, pop rank otherwise),
 // [2T] n_push, [2T+1] n_pop, [2T+2] head (wrapped), [2T+3] tail (wrapped).
@@ -705,20 +976,50 @@ __global__ void k_test_rng(float u, float v, float r0, float r1, float r2, float
 // ================================================================================================ launchers
 static dim3 pixel_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(w, 16), ceil_div(h, 16)); }
 
+// The per-lane state-machine engine (k_paths) is bit-identical to the straightforward kernels but measured 2.3x SLOWER on
+// MI355X (a mixed service round executes every transition branch, ~4x the transition instructions of
+// the lock-step kernels, which outweighs the utilisation gained in the tracking loops).  It stays selectable for
+// experiments (NRC_INTEGRATOR=engine); the lock-step kernels are the product path.
+static bool use_simple_integrator()
+{
+    static const bool simple = [] { const char* e = getenv("NRC_INTEGRATOR"); return !(e && std::string(e) == "engine"); }();
+    return simple;
+}
+static int service_eighths()
+{
+    static const int v = [] { const char* e = getenv("NRC_ENGINE_SERVICE"); return e ? atoi(e) : 6; }();
+    return v;
+}
+static uint32_t engine_blocks(const DevFrame& fr)
+{
+    const uint32_t slots = ceil_div(fr.w, 8) * ceil_div(fr.h, 8) * 64u;
+    return ceil_div(ceil_div(slots, ENGINE_SLOTS_PER_WAVE), 4);
+}
+
 void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
                      unsigned long long* fetch_counter, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gen_rays, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, primary_ray_length,
-                       primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in, fetch_counter);
+    if (use_simple_integrator()) {
+        hipLaunchKernelGGL(k_gen_rays, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, primary_ray_length,
+                           primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in, fetch_counter);
+    } else {
+        EngineOut o{(float4*)primary, info, (float4*)origin, (float4*)dir, infer_in, 1.0f, primary_ray_length, primary_ray_prob};
+        hipLaunchKernelGGL(k_paths<PATH_MODE_NRC>, dim3(engine_blocks(fr)), dim3(256), 0, s, sc, cam, fr, o, fetch_counter, service_eighths());
+    }
     NRC_HIP(hipGetLastError());
 }
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mc_render, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, path_length, blend_factor,
-                       (float4*)out_rgba, info, fetch_counter);
+    if (use_simple_integrator() || path_length == 0) {
+        hipLaunchKernelGGL(k_mc_render, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, path_length, blend_factor,
+                           (float4*)out_rgba, info, fetch_counter);
+    } else {
+        EngineOut o{(float4*)out_rgba, info, nullptr, nullptr, nullptr, blend_factor, path_length, 0.0f};
+        hipLaunchKernelGGL(k_paths<PATH_MODE_MC>, dim3(engine_blocks(fr)), dim3(256), 0, s, sc, cam, fr, o, fetch_counter, service_eighths());
+    }
     NRC_HIP(hipGetLastError());
 }
 
