@@ -496,6 +496,287 @@ __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const ui
     }
 }
 
+// ================================================================================================ generic path
+// Any supported encoding, width 64 or 128, any depth: the encoding is a separate kernel writing fp16 features [n][E16]
+// (E16 = encoded dims padded to a multiple of 16 with 1.0, as tiny-cuda-nn does), the MLP kernels read layer-0 B operands
+// from there and weight fragments straight from the L2-resident images (an 8x128 network's 250 KB do not fit the LDS
+// budget of resident workgroups).  Same accumulator-as-operand chain, same numerics as the fused 6x64 kernels.
+__device__ __forceinline__ float tri_wave(float x, int f)      // TriangleWave: |((2^f x) mod 2) - 1|
+{
+    const float t = x * (float)(1 << f);
+    const float r = t - 2.0f * floorf(t * 0.5f);
+    return fabsf(r - 1.0f);
+}
+
+__device__ __forceinline__ void oneblob4(float xd, float (&out)[4])
+{
+    float cdf[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const float bx = (float)k * 0.25f - xd;
+        const float kk = __builtin_rintf(bx);
+        const float w = bx - kk;
+        const float sat = __builtin_amdgcn_fmed3f(kk + 1.0f, 0.0f, 3.0f);
+        cdf[k] = sat + (__builtin_fabsf(kk) <= 1.0f ? quartic_cdf4(w) : 0.0f);
+    }
+    const bool bad = !(xd == xd);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
+        out[k] = bad ? (k == 3 ? 1.0f : 0.0f) : right - cdf[k];
+    }
+}
+
+// one thread per sample; features in tiny-cuda-nn order: position encoding (dims 0-2) then direction encoding (dims 3-4).
+// POS / DIR are compile-time so that every feature has a static slot.
+template <int POS, int DIR>
+__global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, half_t* __restrict__ feat, uint32_t n)
+{
+    constexpr int NP = POS == 3 ? 72 : (POS == 1 ? 3 : 36);
+    constexpr int ND = DIR == 1 ? 2 : 8;
+    constexpr int E16 = (NP + ND + 15) / 16 * 16;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float x[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) x[d] = in[(size_t)i * 5u + d];
+    half_t* o = feat + (size_t)i * E16;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        if (POS == 3) {
+            float t = x[d] * 0.5f;
+#pragma unroll
+            for (int f = 0; f < 12; f++) {
+                const float rev = __builtin_amdgcn_fractf(t);
+                o[d * 24 + 2 * f] = (half_t)__builtin_amdgcn_sinf(rev);
+                o[d * 24 + 2 * f + 1] = (half_t)__builtin_amdgcn_cosf(rev);
+                t = t + t;
+            }
+        } else if (POS == 1) {
+            o[d] = (half_t)x[d];
+        } else {
+#pragma unroll
+            for (int f = 0; f < 12; f++) o[d * 12 + f] = (half_t)tri_wave(x[d], f);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        if (DIR == 0) {
+            float b[4];
+            oneblob4(x[3 + d], b);
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[NP + 4 * d + q] = (half_t)b[q];
+        } else if (DIR == 1) {
+            o[NP + d] = (half_t)x[3 + d];
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; f++) o[NP + 4 * d + f] = (half_t)tri_wave(x[3 + d], f);
+        }
+    }
+#pragma unroll
+    for (int k = NP + ND; k < E16; k++) o[k] = (half_t)1.0f;
+}
+
+template <int POS>
+static void launch_encode_pos(uint32_t dir_id, dim3 g, hipStream_t s, const float* in, half_t* feat, uint32_t n)
+{
+    if (dir_id == 0) hipLaunchKernelGGL((k_encode<POS, 0>), g, dim3(256), 0, s, in, feat, n);
+    else if (dir_id == 1) hipLaunchKernelGGL((k_encode<POS, 1>), g, dim3(256), 0, s, in, feat, n);
+    else hipLaunchKernelGGL((k_encode<POS, 2>), g, dim3(256), 0, s, in, feat, n);
+}
+static void launch_encode(uint32_t pos_id, uint32_t dir_id, hipStream_t s, const float* in, half_t* feat, uint32_t n)
+{
+    const dim3 g(ceil_div(n, 256));
+    if (pos_id == 3) launch_encode_pos<3>(dir_id, g, s, in, feat, n);
+    else if (pos_id == 1) launch_encode_pos<1>(dir_id, g, s, in, feat, n);
+    else launch_encode_pos<2>(dir_id, g, s, in, feat, n);
+}
+
+__device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int frag, int lane)
+{
+    const uint4 v = img[frag * 64 + lane];
+    return __builtin_bit_cast(half8, v);
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
+                                                  const uint4* __restrict__ img, int depth, int ks0)
+{
+    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = (n + 31u) >> 5;
+    const uint32_t e16 = (uint32_t)ks0 * 16u;
+    const int hid_base = MTG * ks0;
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t sidx = tile * 32u + r;
+        const bool valid = sidx < n;
+        const half_t* fp = feat + (size_t)(valid ? sidx : n - 1u) * e16 + 8 * h;
+        f32x16 acc[MTG];
+#pragma unroll
+        for (int m = 0; m < MTG; m++) acc[m] = zero16();
+        for (int s = 0; s < ks0; s++) {
+            const half8 b0 = *reinterpret_cast<const half8*>(fp + 16 * s);
+#pragma unroll
+            for (int m = 0; m < MTG; m++) acc[m] = mfma(ld_frag_g(img, m * ks0 + s, lane), b0, acc[m]);
+        }
+        half8 b[KSG];
+#pragma unroll
+        for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
+#pragma unroll 1
+        for (int l = 1; l < depth; l++) {
+            const int base = hid_base + (l - 1) * MTG * KSG;
+#pragma unroll
+            for (int m = 0; m < MTG; m++) {
+                acc[m] = zero16();
+#pragma unroll
+                for (int s = 0; s < KSG; s++) acc[m] = mfma(ld_frag_g(img, base + m * KSG + s, lane), b[s], acc[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
+        }
+        f32x16 y = zero16();
+        const int obase = hid_base + (depth - 1) * MTG * KSG;
+#pragma unroll
+        for (int s = 0; s < KSG; s++) y = mfma(ld_frag_g(img, obase + s, lane), b[s], y);
+        if (valid && h == 0) {
+            float* o = out + (size_t)sidx * 3u;
+            o[0] = y[0];
+            o[1] = y[1];
+            o[2] = y[2];
+        }
+    }
+}
+
+struct TrainArgsGen {
+    const half_t* feat;   // [n][e16]
+    const float* target;
+    uint32_t n;
+    float inv_n_total;
+    uint32_t loss_id;
+    half_t* acts;         // [n/8][e16 + depth*WIDTH][8]
+    half_t* deltas;       // [n/8][depth*WIDTH + 8][8]
+    float* loss_part;
+    int depth, ks0;
+};
+
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
+                                                  const uint4* __restrict__ img_bwd)
+{
+    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int depth = a.depth, ks0 = a.ks0;
+    const uint32_t e16 = (uint32_t)ks0 * 16u;
+    const uint32_t rows_a = e16 + (uint32_t)depth * WIDTH, rows_d = (uint32_t)depth * WIDTH + 8u;
+    const uint32_t n_tiles = a.n >> 5;
+    const int hid_base = MTG * ks0;
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t sidx = tile * 32u + r;
+        const half_t* fp = a.feat + (size_t)sidx * e16 + 8 * h;
+        half_t* const pa = a.acts + ((size_t)(sidx >> 3) * rows_a) * 8 + (sidx & 7u);
+        half_t* const pd = a.deltas + ((size_t)(sidx >> 3) * rows_d) * 8 + (sidx & 7u);
+        half_t* const pa4 = pa + 32 * h;       // rows + 4h
+        half_t* const pd4 = pd + 32 * h;
+        // ---- forward; every layer's input goes to HBM in the k-group layout the weight-gradient GEMM reads
+        f32x16 acc[MTG];
+#pragma unroll
+        for (int m = 0; m < MTG; m++) acc[m] = zero16();
+        for (int s = 0; s < ks0; s++) {
+            const half8 b0 = *reinterpret_cast<const half8*>(fp + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 8; j++) pa[(size_t)(16 * s + 8 * h + j) * 8] = b0[j];
+#pragma unroll
+            for (int m = 0; m < MTG; m++) acc[m] = mfma(ld_frag_g(img_fwd, m * ks0 + s, lane), b0, acc[m]);
+        }
+        half8 b[KSG];
+#pragma unroll
+        for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
+        for (int l = 0;; l++) {
+            half_t* const pl = pa4 + (size_t)(e16 + (uint32_t)l * WIDTH) * 8;
+#pragma unroll
+            for (int s = 0; s < KSG; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) pl[kperm(s, 0, j) * 8] = b[s][j];
+            if (l + 1 >= depth) break;
+            const int base = hid_base + l * MTG * KSG;
+#pragma unroll
+            for (int m = 0; m < MTG; m++) {
+                acc[m] = zero16();
+#pragma unroll
+                for (int s = 0; s < KSG; s++) acc[m] = mfma(ld_frag_g(img_fwd, base + m * KSG + s, lane), b[s], acc[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
+        }
+        f32x16 y = zero16();
+        const int obase = hid_base + (depth - 1) * MTG * KSG;
+#pragma unroll
+        for (int s = 0; s < KSG; s++) y = mfma(ld_frag_g(img_fwd, obase + s, lane), b[s], y);
+
+        // ---- loss + dL/dy
+        float loss_v = 0.0f;
+        half8 bo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
+        if (h == 0) {
+            const float* t = a.target + (size_t)sidx * 3u;
+            float yv[3] = {y[0], y[1], y[2]};
+            float den[3];
+            if (a.loss_id == 0u) {
+                float lum = (0.299f * yv[0] + 0.587f * yv[1]) + 0.114f * yv[2];
+                den[0] = den[1] = den[2] = lum * lum + 0.01f;
+            } else if (a.loss_id == 1u) {
+                den[0] = den[1] = den[2] = 1.0f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) den[c] = yv[c] * yv[c] + 0.01f;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float d = yv[c] - t[c];
+                loss_v += d * d / den[c] * a.inv_n_total;
+                float dy = Mlp::kLossScale * (2.0f * d / den[c] * a.inv_n_total);
+                bo[c] = (half_t)dy;
+                pd[(size_t)((uint32_t)depth * WIDTH + c) * 8] = bo[c];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
+        if (lane == 0) a.loss_part[tile] = loss_v;
+
+        // ---- dgrad chain; the ReLU mask is re-read from this lane's own activation stores
+        const int bout = (depth - 1) * MTG * KSG;
+        f32x16 d[MTG];
+#pragma unroll
+        for (int m = 0; m < MTG; m++) d[m] = mfma(ld_frag_g(img_bwd, bout + m, lane), bo, zero16());
+        for (int l = depth - 1; l >= 0; l--) {
+            const half_t* const pl = pa4 + (size_t)(e16 + (uint32_t)l * WIDTH) * 8;
+            half_t* const pdl = pd4 + (size_t)((uint32_t)l * WIDTH) * 8;
+            half8 dl[KSG];
+#pragma unroll
+            for (int s = 0; s < KSG; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const half_t act = pl[kperm(s, 0, j) * 8];
+                    const half_t v = (act > (half_t)0.0f) ? (half_t)d[s >> 1][8 * (s & 1) + j] : (half_t)0.0f;
+                    dl[s][j] = v;
+                    pdl[kperm(s, 0, j) * 8] = v;
+                }
+            if (l > 0) {
+                const int base = (l - 1) * MTG * KSG;
+#pragma unroll
+                for (int m = 0; m < MTG; m++) {
+                    d[m] = zero16();
+#pragma unroll
+                    for (int s = 0; s < KSG; s++) d[m] = mfma(ld_frag_g(img_bwd, base + m * KSG + s, lane), dl[s], d[m]);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ training: weight gradients
 // dW_l = delta_l (rows: out neurons, k: samples) * a_{l-1}^T.  One workgroup per K-chunk of samples, one 32x32
 // output tile per wave iteration, partial result to this chunk's slab (fixed-order reduction afterwards).
@@ -614,19 +895,25 @@ __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ em
 }  // namespace
 
 // ================================================================================================ host
+static uint32_t pos_enc_dims(uint32_t id) { return id == 1 ? 3u : id == 2 ? 36u : id == 3 ? 72u : 0u; }
+static uint32_t dir_enc_dims(uint32_t id) { return id == 0 ? 8u : id == 1 ? 2u : id == 2 ? 8u : ~0u; }
+
 Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 {
     width_ = cfg.nn_width;
     depth_ = cfg.nn_depth;
-    if (cfg.pos_id != 3 || cfg.dir_id != 0)
-        fail("this build fuses only the Frequency(12) + OneBlob(4) input encoding (posID 3, dirID 0)");
-    if (width_ != 64 || depth_ != 6) fail("this build supports nnWidth 64 / nnDepth 6 (got " + std::to_string(width_) + "/" + std::to_string(depth_) + ")");
+    if (cfg.pos_id == 0) fail("HashGrid position encoding (posID 0) is not built yet (DESIGN.md section 6)");
+    if (pos_enc_dims(cfg.pos_id) == 0 || dir_enc_dims(cfg.dir_id) == ~0u) fail("NNEncodingConfig posID/dirID is invalid");
+    if (width_ != 64 && width_ != 128) fail("nnWidth must be 64 or 128 (got " + std::to_string(width_) + ")");
+    if (depth_ < 1 || depth_ > 16) fail("nnDepth must be in 1..16 (got " + std::to_string(depth_) + ")");
     if (std::strcmp(cfg.optimizer, "Adam") != 0) fail(std::string("unsupported optimizer ") + cfg.optimizer);
     if (std::strcmp(cfg.loss_fn, "RelativeL2Luminance") == 0) loss_id_ = 0;
     else if (std::strcmp(cfg.loss_fn, "L2") == 0) loss_id_ = 1;
     else if (std::strcmp(cfg.loss_fn, "RelativeL2") == 0) loss_id_ = 2;
     else fail(std::string("unsupported loss ") + cfg.loss_fn);
-    enc_dims_ = ENC;
+    // encoded width, padded to a multiple of 16 with 1.0 (tiny-cuda-nn); the fused kernels cover the north-star model
+    enc_dims_ = (pos_enc_dims(cfg.pos_id) + dir_enc_dims(cfg.dir_id) + 15u) / 16u * 16u;
+    fused_ = cfg.pos_id == 3 && cfg.dir_id == 0 && width_ == 64 && depth_ == 6;
 
     uint32_t off = 0;
     for (uint32_t l = 0; l <= depth_; l++) {
@@ -662,30 +949,35 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     NRC_HIP(hipMemset(d_v_, 0, pb));
     NRC_HIP(hipMemset(d_grad_, 0, pb + 4 * sizeof(float)));
 
-    // fragment-image gather tables
-    const int D = (int)depth_;
-    n_frag_fwd_ = (uint32_t)n_frag_fwd(D);
-    n_frag_bwd_ = (uint32_t)n_frag_bwd(D);
+    // fragment-image gather tables: [frag][lane][8]; layer 0 [mt][s], hidden layer l [mt][s], output [s];
+    // backward image: hidden layer l (W^T) [mt over inputs][s over outputs], output layer [mt] (one k-step, 3 live rows)
+    const int D = (int)depth_, mt_n = (int)width_ / 32, ksh = (int)width_ / 16, ks0 = (int)enc_dims_ / 16, W = (int)width_;
+    const int E = (int)enc_dims_;
+    const int hid_base = mt_n * ks0, out_base = hid_base + (D - 1) * mt_n * ksh;
+    n_frag_fwd_ = (uint32_t)(out_base + ksh);
+    n_frag_bwd_ = (uint32_t)((D - 1) * mt_n * ksh + mt_n);
     std::vector<int32_t> sf((size_t)n_frag_fwd_ * 512, -1), sb((size_t)n_frag_bwd_ * 512, -1);
     auto slot = [](int frag, int lane, int j) { return ((size_t)frag * 64 + lane) * 8 + j; };
     for (int lane = 0; lane < 64; lane++) {
         const int r = lane & 31, h = lane >> 5;
         for (int j = 0; j < 8; j++) {
-            for (int mt = 0; mt < MT; mt++) {
-                for (int s = 0; s < KS0; s++)
-                    sf[slot(FRAG_L0 + mt * KS0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + r) * ENC + fmap80(s, h, j));
+            for (int mt = 0; mt < mt_n; mt++) {
+                for (int s = 0; s < ks0; s++) {
+                    const int k = fused_ ? fmap80(s, h, j) : 16 * s + 8 * h + j;
+                    sf[slot(mt * ks0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + r) * E + k);
+                }
                 for (int l = 1; l < D; l++)
-                    for (int s = 0; s < KSH; s++) {
-                        sf[slot(FRAG_HID + (l - 1) * MT * KSH + mt * KSH + s, lane, j)] =
-                            (int32_t)(layers_[l].off + (32 * mt + r) * WIDTH + kperm(s, h, j));
-                        sb[slot((l - 1) * MT * KSH + mt * KSH + s, lane, j)] =
-                            (int32_t)(layers_[l].off + kperm(s, h, j) * WIDTH + (32 * mt + r));
+                    for (int s = 0; s < ksh; s++) {
+                        sf[slot(hid_base + (l - 1) * mt_n * ksh + mt * ksh + s, lane, j)] =
+                            (int32_t)(layers_[l].off + (32 * mt + r) * W + kperm(s, h, j));
+                        sb[slot((l - 1) * mt_n * ksh + mt * ksh + s, lane, j)] =
+                            (int32_t)(layers_[l].off + kperm(s, h, j) * W + (32 * mt + r));
                     }
                 const int k = 8 * h + j;
-                if (k < 3) sb[slot((D - 1) * MT * KSH + mt, lane, j)] = (int32_t)(layers_[D].off + k * WIDTH + (32 * mt + r));
+                if (k < 3) sb[slot((D - 1) * mt_n * ksh + mt, lane, j)] = (int32_t)(layers_[D].off + k * W + (32 * mt + r));
             }
-            for (int s = 0; s < KSH; s++)
-                if (r < 3) sf[slot(frag_out(D) + s, lane, j)] = (int32_t)(layers_[D].off + r * WIDTH + kperm(s, h, j));
+            for (int s = 0; s < ksh; s++)
+                if (r < 3) sf[slot(out_base + s, lane, j)] = (int32_t)(layers_[D].off + r * W + kperm(s, h, j));
         }
     }
     NRC_HIP(hipMalloc(&d_src_fwd_, sf.size() * 4));
@@ -702,7 +994,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 Mlp::~Mlp()
 {
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_, d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
-                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_};
+                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -747,9 +1039,35 @@ static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float
     hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img);
 }
 
+// fp16 feature buffer of the generic path ([n][E16]); grows on demand (never inside a captured region: first use sizes it)
+void Mlp::ensure_features(uint32_t n)
+{
+    if (n <= feat_n_) return;
+    if (d_feat_) (void)hipFree(d_feat_);
+    d_feat_ = nullptr;
+    NRC_HIP(hipMalloc(&d_feat_, (size_t)n * enc_dims_ * 2));
+    feat_n_ = n;
+}
+
 void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s)
 {
     if (n == 0) return;
+    const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
+    if (!fused_) {
+        ensure_features(n);
+        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, (half_t*)d_feat_, n);
+        uint32_t blocks = ceil_div(ceil_div(n, 32), 4);
+        const uint32_t cap = (uint32_t)num_cus() * 8u;
+        if (blocks > cap) blocks = cap;
+        if (width_ == 64)
+            hipLaunchKernelGGL(k_infer_gen<64>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_, d_out, n, img, (int)depth_,
+                               (int)enc_dims_ / 16);
+        else
+            hipLaunchKernelGGL(k_infer_gen<128>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_, d_out, n, img, (int)depth_,
+                               (int)enc_dims_ / 16);
+        NRC_HIP(hipGetLastError());
+        return;
+    }
     // persistent workgroups sharing one 54 KB weight image in LDS.  Tunables (env, read once): workgroup size,
     // tiles per wave iteration, workgroups per CU.
     static const int threads = [] { const char* e = getenv("NRC_INFER_THREADS"); return e ? atoi(e) : 512; }();
@@ -760,66 +1078,60 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     uint32_t blocks = ceil_div(n_tiles, (uint32_t)(threads / 64) * (uint32_t)nt);
     if (blocks > max_blocks) blocks = max_blocks;
     const size_t lds = (size_t)n_frag_fwd_ * 1024;
-    const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
-    static const bool diag = [&] {
-        if (!getenv("NRC_DIAG")) return false;
-        int nb512 = -1, nb1024 = -1, nb256 = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb512, k_infer<6, 512, 1, 0>, 512, lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1024, k_infer<6, 1024, 1, 0>, 1024, lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb256, k_infer<6, 256, 1, 0>, 256, lds);
-        hipDeviceProp_t prop;
-        (void)hipGetDeviceProperties(&prop, 0);
-        fprintf(stderr, "[nrc diag] occupancy API blocks/CU: 256thr %d, 512thr %d, 1024thr %d (lds %zu B); sharedMemPerMultiprocessor %zu, "
-                        "sharedMemPerBlock %zu, maxSharedMemoryPerMultiProcessor %zu\n", nb256, nb512, nb1024, lds,
-                (size_t)prop.sharedMemPerMultiprocessor, (size_t)prop.sharedMemPerBlock, (size_t)prop.maxSharedMemoryPerMultiProcessor);
-        return true;
-    }();
-    (void)diag;
+    static const int abl = [] { const char* e = getenv("NRC_INFER_ABL"); return e ? atoi(e) : 0; }();
+    if (abl != 0) {       // diagnostic builds only (ablations / in-kernel clock): tools/bench_mlp.py
+        infer_diagnostic(abl, blocks, lds, s, d_in, d_out, n, img);
+        return;
+    }
     if (threads == 1024 && nt == 1) launch_infer<1024, 1>(blocks, lds, s, d_in, d_out, n, img);
     else if (threads == 256 && nt == 1) launch_infer<256, 1>(blocks, lds, s, d_in, d_out, n, img);
     else if (threads == 256 && nt == 2) launch_infer<256, 2>(blocks, lds, s, d_in, d_out, n, img);
-    else if (threads == 512 && nt == 2) launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img);
+    else if (threads == 512 && nt == 1) launch_infer<512, 1>(blocks, lds, s, d_in, d_out, n, img);
     else if (threads == 1024 && nt == 2) launch_infer<1024, 2>(blocks, lds, s, d_in, d_out, n, img);
-    else {
-        static const int abl = [] { const char* e = getenv("NRC_INFER_ABL"); return e ? atoi(e) : 0; }();
-        if (abl == 4) {       // diagnostic only: in-kernel clock / residency / inter-kernel gaps printed to stderr
-            static unsigned long long* d_st = nullptr;
-            constexpr int SLOTS = 16;
-            if (!d_st) NRC_HIP(hipMalloc(&d_st, (size_t)SLOTS * 4 * 2048 * sizeof(unsigned long long)));
-            static int count = 0;
-            const int slot = count % SLOTS;
-            static const bool nostore = getenv("NRC_INFER_NOSTORE") != nullptr;
-            if (nostore) hipLaunchKernelGGL((k_infer<6, 512, 1, 12>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
-            else hipLaunchKernelGGL((k_infer<6, 512, 1, 4>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
-            if (++count % 64 == 0) {
-                std::vector<unsigned long long> h((size_t)SLOTS * 4 * 2048);
-                NRC_HIP(hipStreamSynchronize(s));
-                NRC_HIP(hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
-                std::vector<std::pair<unsigned long long, unsigned long long>> span;
-                std::vector<double> clk;
-                for (int k = 0; k < SLOTS; k++) {
-                    unsigned long long first = ~0ull, last = 0;
-                    for (uint32_t b = 0; b < blocks; b++) {
-                        const unsigned long long* e = &h[((size_t)k * 2048 + b) * 4];
-                        first = std::min(first, e[2]);
-                        last = std::max(last, e[2] + e[1]);
-                        clk.push_back((double)e[0] / (double)e[1] * 100.0);
-                    }
-                    span.push_back({first, last});
+    else launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img);
+    NRC_HIP(hipGetLastError());
+}
+
+// diagnostics of the fused inference kernel (never on the product path): ABL 1/2/3 drop the encoding / ReLU-convert work,
+// ABL 4 stamps s_memtime / s_memrealtime per workgroup and prints the in-kernel clock and inter-kernel gaps
+void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
+                           const void* image)
+{
+    const uint4* img = (const uint4*)image;
+    if (abl == 4) {
+        static unsigned long long* d_st = nullptr;
+        constexpr int SLOTS = 16;
+        if (!d_st) NRC_HIP(hipMalloc(&d_st, (size_t)SLOTS * 4 * 2048 * sizeof(unsigned long long)));
+        static int count = 0;
+        const int slot = count % SLOTS;
+        hipLaunchKernelGGL((k_infer<6, 512, 1, 4>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
+        if (++count % 64 == 0) {
+            std::vector<unsigned long long> h((size_t)SLOTS * 4 * 2048);
+            NRC_HIP(hipStreamSynchronize(s));
+            NRC_HIP(hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<std::pair<unsigned long long, unsigned long long>> span;
+            std::vector<double> clk;
+            for (int k = 0; k < SLOTS; k++) {
+                unsigned long long first = ~0ull, last = 0;
+                for (uint32_t b = 0; b < blocks; b++) {
+                    const unsigned long long* e = &h[((size_t)k * 2048 + b) * 4];
+                    first = std::min(first, e[2]);
+                    last = std::max(last, e[2] + e[1]);
+                    clk.push_back((double)e[0] / (double)e[1] * 100.0);
                 }
-                std::sort(span.begin(), span.end());
-                std::sort(clk.begin(), clk.end());
-                fprintf(stderr, "[nrc diag] clock MHz med %.0f | per launch (span us, gap to next us):", clk[clk.size() / 2]);
-                for (int k = 0; k + 1 < SLOTS; k++)
-                    fprintf(stderr, " (%.1f, %.1f)", (double)(span[k].second - span[k].first) / 100.0,
-                            (double)(span[k + 1].first - span[k].second) / 100.0);
-                fprintf(stderr, "\n");
+                span.push_back({first, last});
             }
-        } else if (abl == 1) hipLaunchKernelGGL((k_infer<6, 512, 1, 1>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
-        else if (abl == 2) hipLaunchKernelGGL((k_infer<6, 512, 1, 2>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
-        else if (abl == 3) hipLaunchKernelGGL((k_infer<6, 512, 1, 3>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
-        else launch_infer<512, 1>(blocks, lds, s, d_in, d_out, n, img);
-    }
+            std::sort(span.begin(), span.end());
+            std::sort(clk.begin(), clk.end());
+            fprintf(stderr, "[nrc diag] clock MHz med %.0f | per launch (wave-0 span us, gap to next us):", clk[clk.size() / 2]);
+            for (int k = 0; k + 1 < SLOTS; k++)
+                fprintf(stderr, " (%.1f, %.1f)", (double)(span[k].second - span[k].first) / 100.0,
+                        (double)(span[k + 1].first - span[k].second) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    } else if (abl == 1) hipLaunchKernelGGL((k_infer<6, 512, 1, 1>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
+    else if (abl == 2) hipLaunchKernelGGL((k_infer<6, 512, 1, 2>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
+    else hipLaunchKernelGGL((k_infer<6, 512, 1, 3>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
     NRC_HIP(hipGetLastError());
 }
 
@@ -832,7 +1144,7 @@ void Mlp::ensure_train_workspace(uint32_t n)
     if (d_loss_part_) (void)hipFree(d_loss_part_);
     d_acts_ = d_deltas_ = nullptr;
     d_slabs_ = d_loss_part_ = nullptr;
-    const size_t rows_a = ENC + (size_t)depth_ * WIDTH, rows_d = (size_t)depth_ * WIDTH + 8;
+    const size_t rows_a = enc_dims_ + (size_t)depth_ * width_, rows_d = (size_t)depth_ * width_ + 8;
     NRC_HIP(hipMalloc(&d_acts_, rows_a * n * 2));
     NRC_HIP(hipMalloc(&d_deltas_, rows_d * n * 2));
     NRC_HIP(hipMemset(d_deltas_, 0, rows_d * n * 2));
@@ -844,8 +1156,8 @@ void Mlp::ensure_train_workspace(uint32_t n)
         const uint32_t D = depth_;
         for (uint32_t l = 0; l <= D; l++) {
             const MlpLayer& L = layers_[l];
-            const uint32_t a_rows = l == D ? D * WIDTH : l * WIDTH;           // delta_l rows
-            const uint32_t b_rows = l == 0 ? 0 : ENC + (l - 1) * WIDTH;       // a_{l-1} rows (enc for l = 0)
+            const uint32_t a_rows = l == D ? D * width_ : l * width_;                 // delta_l rows
+            const uint32_t b_rows = l == 0 ? 0 : enc_dims_ + (l - 1) * width_;        // a_{l-1} rows (enc for l = 0)
             for (uint32_t mt = 0; mt * 32 < L.out; mt++)
                 for (uint32_t nt = 0; nt * 32 < L.in; nt++) {
                     WgradTile T;
@@ -868,32 +1180,55 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
 {
     if (n == 0 || n % 32 != 0) fail("training batch must be a non-zero multiple of 32 samples");
     ensure_train_workspace(n);
-    constexpr int THREADS = 256;
-    TrainArgs a;
-    a.in = d_in;
-    a.target = d_target;
-    a.n = n;
-    a.inv_n_total = 1.0f / (float)(3u * n_norm);
-    a.loss_id = loss_id_;
-    a.acts = (half_t*)d_acts_;
-    a.deltas = (half_t*)d_deltas_;
-    a.loss_part = d_loss_part_;
     const uint32_t n_tiles = n / 32;
+    constexpr int THREADS = 256;
     uint32_t blocks = ceil_div(n_tiles, THREADS / 64);
-    if (blocks > (uint32_t)num_cus()) blocks = (uint32_t)num_cus();
-    const size_t lds = ((size_t)n_frag_fwd_ + n_frag_bwd_) * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_fwd_bwd<6, THREADS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    if (fused_) {
+        TrainArgs a;
+        a.in = d_in;
+        a.target = d_target;
+        a.n = n;
+        a.inv_n_total = 1.0f / (float)(3u * n_norm);
+        a.loss_id = loss_id_;
+        a.acts = (half_t*)d_acts_;
+        a.deltas = (half_t*)d_deltas_;
+        a.loss_part = d_loss_part_;
+        if (blocks > (uint32_t)num_cus()) blocks = (uint32_t)num_cus();
+        const size_t lds = ((size_t)n_frag_fwd_ + n_frag_bwd_) * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_fwd_bwd<6, THREADS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
+                           (const uint4*)d_pk_bwd_);
+    } else {
+        ensure_features(n);
+        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, (half_t*)d_feat_, n);
+        TrainArgsGen a;
+        a.feat = (const half_t*)d_feat_;
+        a.target = d_target;
+        a.n = n;
+        a.inv_n_total = 1.0f / (float)(3u * n_norm);
+        a.loss_id = loss_id_;
+        a.acts = (half_t*)d_acts_;
+        a.deltas = (half_t*)d_deltas_;
+        a.loss_part = d_loss_part_;
+        a.depth = (int)depth_;
+        a.ks0 = (int)enc_dims_ / 16;
+        const uint32_t cap = (uint32_t)num_cus() * 4u;
+        if (blocks > cap) blocks = cap;
+        if (width_ == 64)
+            hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+        else
+            hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
     }
-    hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
-                       (const uint4*)d_pk_bwd_);
     NRC_HIP(hipGetLastError());
     const uint32_t n_chunks = ceil_div(n, WGRAD_CHUNK);
-    hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_,
-                       (const half_t*)d_acts_, n, depth_ * WIDTH + 8, ENC + depth_ * WIDTH, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_, n_params_);
+    hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_, (const half_t*)d_acts_, n,
+                       depth_ * width_ + 8, enc_dims_ + depth_ * width_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
+                       n_params_);
     NRC_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_params_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_params_,
                        d_grad_, d_loss_part_, n_tiles, d_loss_);

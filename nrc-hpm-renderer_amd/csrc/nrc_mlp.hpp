@@ -39,11 +39,17 @@ public:
 
 private:
     void ensure_train_workspace(uint32_t n);
+    void ensure_features(uint32_t n);
+    void infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
+                          const void* image);
 
     nrc_config cfg_;
     uint32_t width_, depth_, enc_dims_, n_params_;
     uint32_t loss_id_;
+    bool fused_ = false;         // north-star model (Frequency+OneBlob, 6x64): fully fused kernels; otherwise the generic path
     std::vector<MlpLayer> layers_;
+    void* d_feat_ = nullptr;     // generic path: fp16 features [n][enc_dims]
+    uint32_t feat_n_ = 0;
 
     float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)

@@ -220,7 +220,8 @@ def test_checkpoint_roundtrip(api, torch_gpu):
 
 
 def test_unsupported_configurations_fail_loudly(api, torch_gpu):
-    for kw in (dict(pos_id=0), dict(nn_width=128), dict(optimizer="SGD"), dict(loss_fn="Huber")):
+    for kw in (dict(pos_id=0), dict(pos_id=4), dict(dir_id=3), dict(nn_width=96), dict(nn_depth=0), dict(optimizer="SGD"),
+               dict(loss_fn="Huber")):
         with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
             api.NeuralRadianceCache(api.AppConfig(**kw))
 
@@ -237,3 +238,40 @@ def test_full_size_inference_properties(cache, orc, torch_gpu):
     idx = torch_gpu.randint(0, n, (2048,), device="cuda", generator=g)
     ref = orc.nn_create().forward(x[idx].cpu().numpy(), True, 1)
     assert rel(out[idx].cpu().numpy(), ref) < 2e-3
+
+
+GENERIC = [  # (posID, dirID, width, depth): everything except the fused 3/0/64/6 model runs the generic kernels
+    (1, 0, 64, 6), (2, 2, 64, 4), (3, 1, 64, 2), (3, 0, 64, 5), (3, 0, 128, 8), (1, 1, 128, 3), (2, 0, 128, 1),
+]
+
+
+@pytest.mark.parametrize("pos_id,dir_id,width,depth", GENERIC)
+def test_generic_models_match_oracle(api, orc, torch_gpu, pos_id, dir_id, width, depth):
+    """other encodings (src/AppConfig.cpp:11-87: Identity / TriangleWave / Frequency x OneBlob / Identity / TriangleWave),
+    widths 64/128 (BASELINE configs[4]: 8x128) and depths: inference, gradients and one optimizer step vs the oracle"""
+    c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth))
+    onn = orc.nn_create(pos_id=pos_id, dir_id=dir_id, width=width, depth=depth)
+    assert c.ParamCount() == onn.n_params
+    assert np.array_equal(c.GetParams(0), onn.buffer(0))
+    randomize(c, onn, seed=3, scale=1.0)
+    n = 1024 + 37
+    x = queries(n, seed=pos_id * 7 + dir_id, nan_frac=0.1 if dir_id == 0 else 0.0)   # only OneBlob absorbs the NaN phi of quirk Q5
+    if pos_id == 1:
+        x[:, :3] -= 31.0                                     # keep Identity positions O(1)
+    d_out = torch_gpu.empty((n, 3), device="cuda")
+    c.Infer(torch_gpu.from_numpy(x).cuda(), d_out, useEma=True)
+    got, ref = d_out.cpu().numpy(), onn.forward(x, True, 1)
+    assert np.isfinite(got).all()
+    assert rel(got, ref) < 3e-3
+    m = 1024
+    rng = np.random.default_rng(5)
+    t = rng.random((m, 3), dtype=np.float32)
+    c.Backward(torch_gpu.from_numpy(x[:m].copy()).cuda(), torch_gpu.from_numpy(t).cuda())
+    loss_ref = onn.backward(x[:m], t)
+    assert abs(c.GetLoss() - loss_ref) < 3e-3 * abs(loss_ref)
+    g, g_ref = c.GetParams(4) / 128.0, np.array(onn.buffer(4))
+    assert rel(g, g_ref) < 2e-2
+    c.OptimizerStep()
+    onn.optimizer_step()
+    assert rel(c.GetParams(0), onn.buffer(0)) < 3e-3
+    c.Destroy()
