@@ -168,8 +168,10 @@ def main():
 
     out = None
     if rank == 0:
-        # per-launch figures of the fused encode+MLP inference kernel: stage "nrc" brackets exactly that launch when the
-        # frame does not train; with training on it is measured by a dedicated event-timed loop on the same stream
+        # ---- per-launch figures.  k_infer: event-timed loop on the launch stream (same buffers the frame uses); k_gen_rays:
+        # the renderer's own HIP events around the launch, averaged over the timed region.  `traffic` = HBM-side bytes per
+        # launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, gfx950
+        # corrections of MI355X_MICROARCH.md) -- only quoted when this run is the profiled workload.
         n_inf = n_px
         d_in = ren.Buffer("infer_input")
         d_out = ren.Buffer("infer_output")
@@ -185,14 +187,21 @@ def main():
         mlp_ms = e0.elapsed_time(e1) / reps
         mlp_tflops = MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms * 1e-3) / 1e12
         gen_ms = stats["gen_rays"]
-        gen_bytes = n_fetch * 1.0 + n_px * (16 + 16 + 4 + 16 + 16 + 20)     # fetches + the stage's stores
+        gen_store_bytes = n_px * (16 + 4 + 16 + 16 + 20)                    # primary, info, origin, dir, query
+        gen_bytes = n_fetch * 1.0 + gen_store_bytes
+        traffic = {}
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tf) and (W, H, args.volume, world) == (1920, 1080, 256, 1):
+            with open(tf) as f:
+                traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
         dominant_is_gen = gen_ms >= mlp_ms
         roof_mlp = dict(bound="mfma", kernel="k_infer (fused encode + 6x64 MLP)", achieved=mlp_tflops, peak=MFMA_F16_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=None,
-                        ms_per_launch=mlp_ms, samples_per_launch=n_inf)
-        roof_gen = dict(bound="hbm", kernel="k_gen_rays (delta/ratio tracking path integrator)",
+                        unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=traffic.get("k_infer"),
+                        algorithmic_bytes=MLP_BYTES_PER_SAMPLE * n_inf, ms_per_launch=mlp_ms, samples_per_launch=n_inf)
+        roof_gen = dict(bound="hbm", kernel="k_gen_rays (delta/ratio tracking path integrator; ALU/latency-bound, quoted against HBM)",
                         achieved=gen_bytes / (gen_ms * 1e-3) / 1e9 if gen_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=(gen_bytes / (gen_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0, traffic=None,
+                        frac=(gen_bytes / (gen_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0,
+                        traffic=traffic.get("k_gen_rays"), algorithmic_bytes=gen_bytes,
                         ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
