@@ -95,8 +95,10 @@ def main():
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from nrc_hpm_renderer_amd import api, scene as sc, parallel
@@ -122,8 +124,8 @@ def main():
                         primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337)
     nrc = api.NeuralRadianceCache(cfg)
     ren = api.NrcHpmRenderer(local_w, gh, True, cam, cfg, scene, nrc, tile=tile)
-    if world > 1:
-        parallel.attach_gradient_allreduce(nrc, world)
+    if use_dist and args.train:
+        parallel.attach_gradient_allreduce(nrc, world)      # RCCL all-reduce of the MLP gradients every training step
     randoms = sc.frame_randoms((args.steps + args.warmup) * spp + 8, seed=1337)
     ri = [0]
 
@@ -135,7 +137,7 @@ def main():
             ren.Render(None, bool(args.train))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +151,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     stats = ren.StageStats(reset=True)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -226,7 +228,7 @@ def main():
         print(json.dumps(out))
     ren.Destroy()
     nrc.Destroy()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -58,13 +58,15 @@ public:
         if (train) train_all(stream_, nullptr);
     }
 
-    void infer_all(const uint32_t* filter, hipStream_t s)          // Inference, :134-145
+    // skip_zero: device-side replacement of the reference's per-batch host filter (src/NrcHpmRenderer.cu:332-337,
+    // prep_infer_rays.comp:43-45): the renderer zero-fills the query of every pixel that did not scatter
+    void infer_all(const uint32_t* filter, hipStream_t s, bool skip_zero = false)          // Inference, :134-145
     {
         if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
         for (size_t i = 0; i < infer_batches_.size(); i++) {
             if (filter != nullptr && filter[i] == 0) continue;
             const auto& b = infer_batches_[i];
-            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, s);
+            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, s, skip_zero);
         }
     }
 
@@ -317,7 +319,8 @@ public:
         NRC_HIP(hipEventRecord(ev_[2], B));
         if (B != A && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(A, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         cache_.set_stream(A);
-        cache_.infer_all(nullptr, A);                // no host read-back of the batch filter: every batch runs
+        // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
+        cache_.infer_all(nullptr, A, !getenv("NRC_DENSE_INFER"));
         NRC_HIP(hipEventRecord(ev_[3], A));
         if (train) cache_.train_all(B, B != A ? ev_[3] : nullptr);
         NRC_HIP(hipEventRecord(ev_[5], B));

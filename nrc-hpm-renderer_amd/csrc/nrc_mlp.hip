@@ -290,7 +290,8 @@ __device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, half8 (
 // sample, straight from HBM/L2 into registers) before the current tiles are computed, so their latency is hidden.
 template <int DEPTH, int THREADS, int NT, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
-                                                  const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr)
+                                                  const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
+                                                  int skip_zero = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
@@ -328,20 +329,36 @@ __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in,
 #pragma unroll
             for (int i = 0; i < 5; i++) xn[t][i] = __builtin_nontemporal_load(p + i);
         }
-        half8 enc[NT][KS0];
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if constexpr ((ABL & 1) != 0) {
-#pragma unroll
-                for (int s2 = 0; s2 < KS0; s2++)
-#pragma unroll
-                    for (int j = 0; j < 8; j++) enc[t][s2][j] = (half_t)x[t][(s2 + j) % 5];
-            } else {
-                encode80(x[t], h, enc[t]);
-            }
-        }
         f32x16 y[NT];
-        forward_tiles<DEPTH, NT, ABL>(lw, lane, enc, y);
+        // renderer mode: gen_rays writes an all-zero query for every pixel that did not scatter (the reference's zero-filled
+        // slots, whose network output render.comp never reads); tiles made only of such queries skip the network and store 0
+        bool live = true;
+        if (skip_zero) {
+            bool nz = false;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) nz |= (__builtin_bit_cast(uint32_t, x[t][i]) & 0x7fffffffu) != 0u;
+            live = __ballot(nz) != 0ull;
+        }
+        if (live) {
+            half8 enc[NT][KS0];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+                    for (int s2 = 0; s2 < KS0; s2++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) enc[t][s2][j] = (half_t)x[t][(s2 + j) % 5];
+                } else {
+                    encode80(x[t], h, enc[t]);
+                }
+            }
+            forward_tiles<DEPTH, NT, ABL>(lw, lane, enc, y);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) y[t] = zero16();
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const uint32_t sidx = (tile + t) * 32u + r;
@@ -1034,9 +1051,11 @@ static int num_cus()
 }
 
 template <int THREADS, int NT>
-static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n, const uint4* img)
+static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n, const uint4* img,
+                         int skip_zero)
 {
-    hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img);
+    hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
+                       (unsigned long long*)nullptr, skip_zero);
 }
 
 // fp16 feature buffer of the generic path ([n][E16]); grows on demand (never inside a captured region: first use sizes it)
@@ -1049,7 +1068,7 @@ void Mlp::ensure_features(uint32_t n)
     feat_n_ = n;
 }
 
-void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s)
+void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries)
 {
     if (n == 0) return;
     const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
@@ -1083,12 +1102,13 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
         infer_diagnostic(abl, blocks, lds, s, d_in, d_out, n, img);
         return;
     }
-    if (threads == 1024 && nt == 1) launch_infer<1024, 1>(blocks, lds, s, d_in, d_out, n, img);
-    else if (threads == 256 && nt == 1) launch_infer<256, 1>(blocks, lds, s, d_in, d_out, n, img);
-    else if (threads == 256 && nt == 2) launch_infer<256, 2>(blocks, lds, s, d_in, d_out, n, img);
-    else if (threads == 512 && nt == 1) launch_infer<512, 1>(blocks, lds, s, d_in, d_out, n, img);
-    else if (threads == 1024 && nt == 2) launch_infer<1024, 2>(blocks, lds, s, d_in, d_out, n, img);
-    else launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img);
+    const int sz = skip_zero_queries ? 1 : 0;
+    if (threads == 1024 && nt == 1) launch_infer<1024, 1>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 256 && nt == 1) launch_infer<256, 1>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 256 && nt == 2) launch_infer<256, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 512 && nt == 1) launch_infer<512, 1>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 1024 && nt == 2) launch_infer<1024, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
     NRC_HIP(hipGetLastError());
 }
 

@@ -22,7 +22,8 @@ public:
     Mlp& operator=(const Mlp&) = delete;
 
     // network->inference: y = MLP_ema(encode(x)); in [n][5], out [n][3] (device, fp32)
-    void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s);
+    // skip_zero_queries (renderer only): 32-sample tiles whose queries are all exactly zero store 0 without running the network
+    void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries = false);
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
     void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s);
     // EMA{Adam} step + re-pack of the fp16 MFMA fragment images
