@@ -97,6 +97,11 @@ int nrc_cache_optimizer_step(nrc_cache_t* c);
 float* nrc_cache_grad_ptr(nrc_cache_t* c);
 uint32_t nrc_cache_param_count(nrc_cache_t* c);
 float* nrc_cache_loss_ptr(nrc_cache_t* c);
+/* multi-GPU, native exchange: rank 0 obtains a 128-byte RCCL unique id (nrc_comm_unique_id), distributes it, and every
+ * rank calls nrc_cache_comm_init(id, rank, world) (collective).  From then on every train batch all-reduces (sum) the
+ * gradient vector + loss cell with ncclAllReduce on the training stream and normalises the loss by the global batch. */
+int nrc_comm_unique_id(void* out128);
+int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world);
 /* multi-GPU: the loss normaliser of InferAndTrain's train batches becomes 3 * trainBatchSize * factor (factor = world size) */
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor);
 /* move the cache's work to another hipStream_t (Init binds the first one) */

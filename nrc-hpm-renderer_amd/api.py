@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
+    "nrc_comm_unique_id", "nrc_cache_comm_init",
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
     "nrc_cache_get_step", "nrc_cache_set_step",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
@@ -291,6 +292,11 @@ class NeuralRadianceCache:
         import torch
         return _wrap_device(self.L.nrc_cache_loss_ptr(self.h), 8, torch.float32, (2,))
 
+    def CommInit(self, unique_id, rank, world):
+        """native RCCL gradient exchange: unique_id = 128 bytes from comm_unique_id() of rank 0 (collective call)"""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _check(self.L.nrc_cache_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))
+
     def SetLossNormFactor(self, factor):
         _check(self.L.nrc_cache_set_loss_norm_factor(self.h, C.c_uint32(factor)))
 
@@ -500,6 +506,12 @@ class McHpmRenderer:
             self.Destroy()
         except Exception:
             pass
+
+
+def comm_unique_id():
+    buf = (C.c_char * 128)()
+    _check(load_library().nrc_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def CompareImages(ref, own, stream=None):

@@ -15,12 +15,49 @@
 #include <random>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "nrc_integrator.hpp"
 #include "nrc_mlp.hpp"
 
 namespace nrc {
 
 static thread_local std::string g_last_error;
+
+// RCCL is bound at run time (dlopen by soname: inside a PyTorch process this resolves to the librccl.so.1 torch already
+// loaded, so both share one library instance); the product has no link-time dependency on it.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    static Rccl& get()
+    {
+        static Rccl r = [] {
+            Rccl x;
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (x.handle) break;
+            }
+            if (!x.handle) fail("cannot load librccl.so.1 (multi-GPU gradient exchange needs RCCL)");
+            x.get_unique_id = (decltype(x.get_unique_id))dlsym(x.handle, "ncclGetUniqueId");
+            x.comm_init_rank = (decltype(x.comm_init_rank))dlsym(x.handle, "ncclCommInitRank");
+            x.comm_destroy = (decltype(x.comm_destroy))dlsym(x.handle, "ncclCommDestroy");
+            x.all_reduce = (decltype(x.all_reduce))dlsym(x.handle, "ncclAllReduce");
+            x.error_string = (decltype(x.error_string))dlsym(x.handle, "ncclGetErrorString");
+            if (!x.get_unique_id || !x.comm_init_rank || !x.comm_destroy || !x.all_reduce) fail("librccl lacks the expected entry points");
+            return x;
+        }();
+        return r;
+    }
+    void check(ncclResult_t r, const char* what)
+    {
+        if (r != ncclSuccess) fail(std::string(what) + " failed: " + (error_string ? error_string(r) : "rccl error"));
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------- Cache
 class Cache {
@@ -79,6 +116,10 @@ public:
             const size_t o = (size_t)b * train_batch_size_;
             mlp_->backward(d_train_in_ + o * 5, d_train_target_ + o * 3, train_batch_size_,
                            train_batch_size_ * loss_norm_factor_, st);
+            // the one exchange step of the sharded path: sum the fp32 gradient vector + loss cell over the ranks (103 KB,
+            // latency-bound) on the training stream; every rank then applies the identical optimizer step
+            if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
+                                                               ncclSum, comm_, st), "ncclAllReduce");
             if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
             if (b == 0 && ev_infer_done) NRC_HIP(hipStreamWaitEvent(st, ev_infer_done, 0));
             mlp_->optimizer_step(st);
@@ -104,6 +145,19 @@ public:
     uint32_t infer_batch_size() const { return infer_batch_size_; }
     uint32_t train_batch_size() const { return train_batch_size_; }
     void set_hook(nrc_grad_hook h, void* u) { hook_ = h; hook_user_ = u; }
+    void comm_init(const void* unique_id, int rank, int world)
+    {
+        if (world < 1 || rank < 0 || rank >= world) fail("bad rank / world size");
+        if (comm_) fail("communicator already initialised");
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof(id));
+        Rccl::get().check(Rccl::get().comm_init_rank(&comm_, world, id, rank), "ncclCommInitRank");
+        loss_norm_factor_ = (uint32_t)world;
+    }
+    ~Cache()
+    {
+        if (comm_) (void)Rccl::get().comm_destroy(comm_);
+    }
     void set_loss_norm_factor(uint32_t f) { loss_norm_factor_ = f ? f : 1; }
     void mark_loss_dirty() { loss_dirty_ = true; }
     const nrc_config& config() const { return cfg_; }
@@ -119,6 +173,7 @@ private:
     bool initialised_ = false;
     nrc_grad_hook hook_ = nullptr;
     void* hook_user_ = nullptr;
+    ncclComm_t comm_ = nullptr;
     uint32_t loss_norm_factor_ = 1;
     float loss_ = 0.0f;
     bool loss_dirty_ = false;
@@ -687,6 +742,20 @@ int nrc_cache_set_grad_hook(nrc_cache_t* c, nrc_grad_hook hook, void* user)
     NRC_REQUIRE(c);
     c->impl.set_hook(hook, user);
     return NRC_OK;
+}
+int nrc_comm_unique_id(void* out128)
+{
+    NRC_REQUIRE(out128);
+    return guarded([&] {
+        ncclUniqueId id;
+        nrc::Rccl::get().check(nrc::Rccl::get().get_unique_id(&id), "ncclGetUniqueId");
+        std::memcpy(out128, &id, sizeof(id));
+    });
+}
+int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(unique_id128);
+    return guarded([&] { c->impl.comm_init(unique_id128, rank, world); });
 }
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor)
 {

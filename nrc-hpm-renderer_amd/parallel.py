@@ -37,14 +37,27 @@ def shard_train_batch(n_global, rank, world):
     return slice(rank * per, (rank + 1) * per)
 
 
-def attach_gradient_allreduce(nrc, world, group=None):
+def attach_gradient_allreduce(nrc, world, group=None, native=True):
     """Installs the exchange step of the training path on a NeuralRadianceCache: the loss normaliser becomes the global
     batch (3 * trainBatchSize * world) and the fp32 gradient vector + loss cell are all-reduced (sum) between backward and
-    the optimizer of every train batch, on the stream the kernels run on."""
+    the optimizer of every train batch, on the stream the training kernels run on.
+
+    native=True (default): the library calls ncclAllReduce itself (RCCL communicator created from a unique id that rank 0
+    broadcasts through torch.distributed) -- no Python in the per-frame path.
+    native=False: a Python hook calls torch.distributed.all_reduce (used by the CPU/gloo-style tests of the logic)."""
     import torch
     import torch.distributed as dist
-    n = nrc.ParamCount()
     from . import api
+    if native:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+        if dist.is_initialized() and world > 1:
+            dist.broadcast(idt, 0, group=group)
+        nrc.CommInit(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        return None
+    n = nrc.ParamCount()
     both = api._wrap_device(nrc.L.nrc_cache_grad_ptr(nrc.h), (n + 2) * 4, torch.float32, (n + 2,))
     nrc.SetLossNormFactor(world)
 
