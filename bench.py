@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the renderer overlaps two HIP streams; give the runtime enough hardware queues that they never share one (must be set
+# before the HIP runtime initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 MFMA_F16_PEAK_TFLOPS = 2500.0      # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (6.3 TB/s measured copy)

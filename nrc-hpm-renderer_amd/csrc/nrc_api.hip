@@ -319,7 +319,14 @@ public:
         alloc(&d_scratch_, (2 * T + 4) * 4);
         alloc(&d_fetch_, 8);
         // train-ray generation + backward overlap inference + compositing on a second stream (NRC_SINGLE_STREAM=1 disables)
-        if (!getenv("NRC_SINGLE_STREAM")) NRC_HIP(hipStreamCreateWithFlags(&stream_b_, hipStreamNonBlocking));
+        // HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4): a same-priority second stream
+        // can land on the queue of the first one (observed under torch.distributed, where RCCL owns several streams) and then
+        // nothing overlaps.  A high-priority stream comes from a separate queue pool.
+        if (!getenv("NRC_SINGLE_STREAM")) {
+            int lo = 0, hi = 0;
+            NRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            NRC_HIP(hipStreamCreateWithPriority(&stream_b_, hipStreamNonBlocking, hi));
+        }
         // CreateNrcTrainRingBuffer: head = tail = 0, pos = 0, dir = (0,0,1)  (:866-875)
         std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
         for (size_t r = 0; r < ring_entries_; r++) { float one = 1.0f; std::memcpy(&ring[2 + 6 * r + 5], &one, 4); }
