@@ -178,18 +178,28 @@ def main():
         # launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, gfx950
         # corrections of MI355X_MICROARCH.md) -- only quoted when this run is the profiled workload.
         n_inf = n_px
-        d_in = ren.Buffer("infer_input")
         d_out = ren.Buffer("infer_output")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            nrc.Infer(d_in, d_out, True)
-        reps = 20
-        e0.record()
-        for _ in range(reps):
-            nrc.Infer(d_in, d_out, True)
-        e1.record()
-        torch.cuda.synchronize()
-        mlp_ms = e0.elapsed_time(e1) / reps
+
+        def time_infer(d_in):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                nrc.Infer(d_in, d_out, True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                nrc.Infer(d_in, d_out, True)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        # (a) dense pass over uniformly random queries (positions in the quirk-Q3 range): the conservative figure -- zero or
+        #     repetitive operands let the chip hold a higher clock (cdna_hip_programming.md rule 25);
+        # (b) dense pass over this frame's own query buffer (78 % all-zero queries of unscattered pixels)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        rnd = torch.rand((n_inf, 5), device="cuda", generator=g)
+        rnd[:, :3] += 31.0
+        mlp_ms = time_infer(rnd)
+        mlp_ms_frame = time_infer(ren.Buffer("infer_input"))
         mlp_tflops = MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms * 1e-3) / 1e12
         gen_ms = stats["gen_rays"]
         gen_store_bytes = n_px * (16 + 4 + 16 + 16 + 20)                    # primary, info, origin, dir, query
@@ -202,7 +212,11 @@ def main():
         dominant_is_gen = gen_ms >= mlp_ms
         roof_mlp = dict(bound="mfma", kernel="k_infer (fused encode + 6x64 MLP)", achieved=mlp_tflops, peak=MFMA_F16_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=traffic.get("k_infer"),
-                        algorithmic_bytes=MLP_BYTES_PER_SAMPLE * n_inf, ms_per_launch=mlp_ms, samples_per_launch=n_inf)
+                        algorithmic_bytes=MLP_BYTES_PER_SAMPLE * n_inf, ms_per_launch=mlp_ms, samples_per_launch=n_inf,
+                        data="uniform random queries",
+                        on_frame_queries=dict(ms_per_launch=mlp_ms_frame,
+                                              achieved=MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms_frame * 1e-3) / 1e12,
+                                              frac=MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms_frame * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS))
         roof_gen = dict(bound="hbm", kernel="k_gen_rays (delta/ratio tracking path integrator; ALU/latency-bound, quoted against HBM)",
                         achieved=gen_bytes / (gen_ms * 1e-3) / 1e9 if gen_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(gen_bytes / (gen_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0,
