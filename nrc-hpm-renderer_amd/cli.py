@@ -1,0 +1,100 @@
+"""Headless counterpart of the reference's main loop (src/main.cu:152-419) for the hot path.
+
+    python -m nrc_hpm_renderer_amd.cli [17 positional AppConfig args] [--frames N] [--vdb FILE | --volume N] ...
+
+The 17 positional arguments are the reference's (src/AppConfig.cpp:154-182, defaults src/main.cu:432-439 -- with posID 3 as
+default instead of the not-yet-built HashGrid).  Every frame is `NrcHpmRenderer::Render(queue, true)` (src/main.cu:287); with
+--benchmark each frame is also evaluated like `Benchmark()` (src/main.cu:140-150): the NRC image without training from the same
+camera against a reference image, one line `frame mse relBias CV` in `output/ <config-name>/log.txt` (the literal space is the
+reference's, src/main.cu:240,446).  The reference image is `--reference FILE.exr` or, like Reference::GenRefImages
+(src/Reference.cpp:566-606), a blended MC render (PATH_LENGTH 64, --ref-frames frames).
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+
+DEFAULT_ARGV = ["RelativeL2Luminance", "Adam", "0.01", "0.99", "3", "0", "64", "6", "21", "14", "4", "4", "1.0", "1", "1", "0.0", "32"]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("config", nargs="*", help="17 positional AppConfig arguments (all or none)")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--vdb", default=None, help="OpenVDB FloatGrid file (Texture3D::FromVDB semantics)")
+    ap.add_argument("--volume", type=int, default=256, help="edge of the procedural fBm cloud when no --vdb is given")
+    ap.add_argument("--env", choices=["white", "black", "sky"], default="white")
+    ap.add_argument("--benchmark", action="store_true")
+    ap.add_argument("--reference", default=None, help="reference EXR (e.g. reference/4/0.exr of the reference repo)")
+    ap.add_argument("--ref-frames", type=int, default=256)
+    ap.add_argument("--output", default="output")
+    ap.add_argument("--export", default=None, help="write the final NRC image to this EXR")
+    args = ap.parse_args(argv)
+
+    import torch
+    from . import api, io_exr, io_vdb, scene as sc
+
+    if args.config and len(args.config) != 17:
+        raise SystemExit("SkyRenderer ERROR: Argument count does not match requirements for AppConfig")
+    cfg = api.AppConfig(["NRC-HPM-Renderer"] + (args.config or DEFAULT_ARGV))
+    if args.vdb:
+        vol, _ = io_vdb.from_vdb(args.vdb)
+        density = sc.quantize_density(vol)
+    else:
+        density = sc.quantize_density(sc.fbm_cloud_volume(args.volume, seed=1337))
+    env = {"white": None, "black": sc.black_env(), "sky": sc.procedural_sky()}[args.env]
+    scene = sc.make_scene(density, scene_id=cfg.scene_id, env=env)
+    W, H = args.width, args.height
+    camera = sc.make_camera(aspect=W / H)            # src/main.cu:180-187
+    torch.cuda.set_device(0)
+
+    nrc = api.NeuralRadianceCache(cfg)
+    nrc_renderer = api.NrcHpmRenderer(W, H, False, camera, cfg, scene, nrc)
+    out_dir = os.path.join(args.output, " " + cfg.GetName())
+    os.makedirs(out_dir, exist_ok=True)
+    log = open(os.path.join(out_dir, "log.txt"), "w")
+
+    ref = None
+    if args.benchmark:
+        if args.reference:
+            ref = torch.from_numpy(io_exr.read_exr(args.reference)).cuda()
+            if ref.shape[0] != H or ref.shape[1] != W:
+                raise SystemExit("SkyRenderer ERROR: reference image resolution mismatch")     # src/Reference.cpp:627
+        else:
+            mc = api.McHpmRenderer(W, H, 64, True, camera, scene)
+            for _ in range(args.ref_frames):
+                mc.Render()
+            ref = mc.GetImage().clone()
+            mc.Destroy()
+        eval_renderer = api.NrcHpmRenderer(W, H, False, camera, cfg, scene, nrc)        # Reference::CompareNrc renders with train=false
+
+    for frame in range(args.frames):
+        nrc_renderer.Render(None, True)
+        loss = nrc.GetLoss()
+        if math.isnan(loss) or math.isinf(loss):                    # src/main.cu:380-384
+            print("SkyRenderer ERROR: NRC Loss is %s" % loss, file=sys.stderr)
+            break
+        if ref is not None:
+            eval_renderer.Render(None, False)
+            r = api.CompareImages(ref, eval_renderer.GetImage())
+            rel_bias = (r["own_mean"] - r["ref_mean"]) / r["ref_mean"] if r["ref_mean"] else 0.0
+            cv = math.sqrt(max(r["own_var"], 0.0)) / r["own_mean"] if r["own_mean"] else 0.0
+            log.write("%d %g %g %g\n" % (frame, r["mse"], rel_bias, cv))
+        if frame % 16 == 0 or frame == args.frames - 1:
+            print("frame %d: loss %.5f, %.3f ms" % (frame, loss, nrc_renderer.GetFrameTimeMS()))
+    log.close()
+    if args.export:
+        nrc_renderer.ExportOutputImageToFile(None, args.export)
+    nrc_renderer.Destroy()
+    if ref is not None:
+        eval_renderer.Destroy()
+    nrc.Destroy()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

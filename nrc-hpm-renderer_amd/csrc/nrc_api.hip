@@ -380,7 +380,10 @@ public:
                           (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, B);
         NRC_HIP(hipEventRecord(ev_[2], B));
         if (B != A && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(A, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
-        cache_.set_stream(A);
+        // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
+        // same NRC from another camera, src/Reference.cpp:71-107)
+        cache_.init((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
+                    (float*)d_train_target_, A);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
         cache_.infer_all(nullptr, A, !getenv("NRC_DENSE_INFER"));
         NRC_HIP(hipEventRecord(ev_[3], A));

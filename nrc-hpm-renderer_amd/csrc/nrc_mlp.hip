@@ -1108,6 +1108,9 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     else if (threads == 256 && nt == 2) launch_infer<256, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
     else if (threads == 512 && nt == 1) launch_infer<512, 1>(blocks, lds, s, d_in, d_out, n, img, sz);
     else if (threads == 1024 && nt == 2) launch_infer<1024, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 512 && nt == 3) launch_infer<512, 3>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 256 && nt == 3) launch_infer<256, 3>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else if (threads == 256 && nt == 4) launch_infer<256, 4>(blocks, lds, s, d_in, d_out, n, img, sz);
     else launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
     NRC_HIP(hipGetLastError());
 }

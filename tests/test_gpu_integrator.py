@@ -288,3 +288,25 @@ def test_full_size_frame_against_reference_exr_statistics(api, sc, cloud16, exr_
     bg = img[img[..., 3] == 0]
     assert np.allclose(bg[:, :3], st["background"], atol=2e-4)
     mc.Destroy()
+
+
+def test_cli_main_loop_and_benchmark_log(torch_gpu, tmp_path):
+    """headless main loop (src/main.cu:248-391): 17 positional args, Render(queue, true) per frame, per-frame
+    `frame mse relBias CV` log in `output/ <config name>/log.txt`, EXR export"""
+    from nrc_hpm_renderer_amd import cli, io_exr
+    out = str(tmp_path / "output")
+    exr = str(tmp_path / "final.exr")
+    argv = ["RelativeL2Luminance", "Adam", "0.01", "0.99", "3", "0", "64", "6", "14", "10", "1", "4", "1.0", "1", "1", "0.0", "32",
+            "--frames", "12", "--width", "128", "--height", "80", "--volume", "32", "--benchmark", "--ref-frames", "64",
+            "--output", out, "--export", exr]
+    assert cli.main(argv) == 0
+    name = " RelativeL2Luminance_Adam_0.010000_0.990000_3_0_64_6_14_10_1_4_1.000000_1_1_0.000000_32"
+    lines = open(os.path.join(out, name, "log.txt")).read().strip().splitlines()
+    assert len(lines) == 12
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines])
+    assert rows.shape == (12, 4) and np.isfinite(rows).all()
+    assert (rows[:, 0] == np.arange(12)).all() and (rows[:, 1] > 0).all()
+    img = io_exr.read_exr(exr)
+    assert img.shape == (80, 128, 4) and np.isfinite(img).all()
+    with pytest.raises(SystemExit):
+        cli.main(argv[:5])
