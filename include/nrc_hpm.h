@@ -37,7 +37,7 @@ typedef struct nrc_config {
     char optimizer[32];            /* "Adam" */
     float learning_rate;
     float ema_decay;
-    uint32_t pos_id;               /* 3 Frequency-12 | 1 Identity | 2 TriangleWave-12 (0 HashGrid: not yet) */
+    uint32_t pos_id;               /* 0 HashGrid(16x2, 2^19) | 1 Identity | 2 TriangleWave-12 | 3 Frequency-12 */
     uint32_t dir_id;               /* 0 OneBlob-4 | 1 Identity | 2 TriangleWave-4 */
     uint32_t nn_width;             /* 64 */
     uint32_t nn_depth;             /* n_hidden_layers, 6 */
@@ -53,6 +53,7 @@ typedef struct nrc_config {
     /* additions of this build */
     uint32_t seed;                 /* weight-init seed (tiny-cuda-nn default 1337) */
     uint32_t compat_fix;           /* bit 0: fix quirk Q1 (TRAIN_Y_DIST), bit 1: fix quirk Q2 (trainRayLength); 0 = faithful */
+    uint32_t hashgrid_log2_size;   /* posID 0: log2_hashmap_size; 0 = the reference's 19 (src/AppConfig.cpp:24) */
 } nrc_config;
 
 #define NRC_FIX_Q1_TRAIN_Y_DIST 1u

@@ -30,7 +30,7 @@ class NrcConfig(C.Structure):
         ("log2_infer_batch_size", C.c_uint32), ("log2_train_batch_size", C.c_uint32), ("train_batch_count", C.c_uint32),
         ("scene_id", C.c_uint32), ("train_ring_buf_size", C.c_float), ("train_spp", C.c_uint32),
         ("primary_ray_length", C.c_uint32), ("primary_ray_prob", C.c_float), ("train_ray_length", C.c_uint32),
-        ("seed", C.c_uint32), ("compat_fix", C.c_uint32),
+        ("seed", C.c_uint32), ("compat_fix", C.c_uint32), ("hashgrid_log2_size", C.c_uint32),
     ]
 
 

@@ -609,6 +609,129 @@ static void launch_encode(uint32_t pos_id, uint32_t dir_id, hipStream_t s, const
     else launch_encode_pos<2>(dir_id, g, s, in, feat, n);
 }
 
+// ---- HashGrid position encoding (AppConfig posID 0, src/AppConfig.cpp:19-27: 16 levels x 2 features, 2^19 entries per hashed
+// level, base resolution 16, per-level scale 2).  tiny-cuda-nn v1.6 grid semantics (PARITY UNPINNED):
+// pos = fma(scale, x, 0.5), trilinear weights over the 8 corners, dense index while res^3 fits the level else the coherent
+// prime hash, index % level size.  The table is trainable: fp32 master + EMA in the parameter vector, fp16 (half2 per
+// entry) copies for the gathers.
+constexpr uint32_t HG_LEVELS = 16;
+struct HashLevels {
+    uint32_t off[HG_LEVELS + 1];      // per-level entry offsets
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void hg_corners(const HashLevels& lv, uint32_t level, const float (&x)[3], uint32_t (&idx)[8], float (&w8)[8])
+{
+    const uint32_t res = 16u << level;                      // ceil(scale) + 1
+    const float scale = (float)res - 1.0f;                  // exp2(level) * 16 - 1
+    const uint32_t base = lv.off[level], hsize = lv.off[level + 1] - base;
+    float pos[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        pos[d] = __builtin_fmaf(scale, x[d], 0.5f);
+        const float tmp = floorf(pos[d]);
+        pg[d] = (uint32_t)(int)tmp;
+        pos[d] -= tmp;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        float w = 1.0f;
+        uint32_t pl[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if ((c & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+        }
+        uint32_t stride = 1, index = 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+            if (stride <= hsize) { index += pl[d] * stride; stride *= res; }
+        if (hsize < stride) index = (pl[0] * 1u) ^ (pl[1] * 2654435761u) ^ (pl[2] * 805459861u);
+        idx[c] = base + index % hsize;
+        w8[c] = w;
+    }
+}
+
+// 16 lanes per sample, one level each (64 contiguous bytes of features per sample); lane 0 also writes the direction encoding
+template <int DIR>
+__global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ in, const uint32_t* __restrict__ table16,
+                                                    half_t* __restrict__ feat, uint32_t n, HashLevels lv)
+{
+    constexpr int ND = DIR == 1 ? 2 : 8, E16 = 48;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t sample = gid >> 4, level = gid & 15u;
+    if (sample >= n) return;
+    const float* p = in + (size_t)sample * 5u;
+    const float x[3] = {p[0], p[1], p[2]};
+    uint32_t idx[8];
+    float w8[8];
+    hg_corners(lv, level, x, idx, w8);
+    float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t v = table16[idx[c]];
+        const half2v hv = __builtin_bit_cast(half2v, v);
+        r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
+        r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
+    }
+    half_t* o = feat + (size_t)sample * E16;
+    o[2 * level] = (half_t)r0;
+    o[2 * level + 1] = (half_t)r1;
+    if (level == 0) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            if (DIR == 0) {
+                float b[4];
+                oneblob4(p[3 + d], b);
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[32 + 4 * d + q] = (half_t)b[q];
+            } else if (DIR == 1) {
+                o[32 + d] = (half_t)p[3 + d];
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; f++) o[32 + 4 * d + f] = (half_t)tri_wave(p[3 + d], f);
+            }
+        }
+#pragma unroll
+        for (int k = 32 + ND; k < E16; k++) o[k] = (half_t)1.0f;
+    }
+}
+
+// dL/d(table): every (sample, level) scatters weight * dL/d(feature) to its 8 corners with fp32 atomics (the sum order, hence
+// the last bits, vary from run to run -- unlike the MLP's slab reduction; tiny-cuda-nn uses fp16 atomics here)
+__global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
+                                                      float* __restrict__ grad_table, uint32_t n, HashLevels lv)
+{
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t sample = gid >> 4, level = gid & 15u;
+    if (sample >= n) return;
+    const float de0 = (float)d_enc[(size_t)sample * 32u + 2u * level], de1 = (float)d_enc[(size_t)sample * 32u + 2u * level + 1u];
+    if (de0 == 0.0f && de1 == 0.0f) return;
+    const float* p = in + (size_t)sample * 5u;
+    const float x[3] = {p[0], p[1], p[2]};
+    uint32_t idx[8];
+    float w8[8];
+    hg_corners(lv, level, x, idx, w8);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (de0 != 0.0f) atomicAdd(grad_table + (size_t)idx[c] * 2u, w8[c] * de0);
+        if (de1 != 0.0f) atomicAdd(grad_table + (size_t)idx[c] * 2u + 1u, w8[c] * de1);
+    }
+}
+#pragma clang fp contract(fast)
+
+// fp16 gather copies of the table: training weights and EMA weights (half2 per entry)
+__global__ void k_pack_grid(const float* __restrict__ w, const float* __restrict__ ema, uint32_t* __restrict__ t_train,
+                            uint32_t* __restrict__ t_ema, uint32_t n_entries)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    float2v a = {w[2 * (size_t)i], w[2 * (size_t)i + 1]}, b = {ema[2 * (size_t)i], ema[2 * (size_t)i + 1]};
+    t_train[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, half2v));
+    t_ema[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, half2v));
+}
+
 __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int frag, int lane)
 {
     const uint4 v = img[frag * 64 + lane];
@@ -675,6 +798,7 @@ struct TrainArgsGen {
     half_t* deltas;       // [n/8][depth*WIDTH + 8][8]
     float* loss_part;
     int depth, ks0;
+    half_t* d_enc;        // [n][32] dL/d(first 32 encoded dims) for a trainable encoding (HashGrid), or nullptr
 };
 
 template <int WIDTH>
@@ -789,6 +913,15 @@ __global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* 
 #pragma unroll
                     for (int s = 0; s < KSG; s++) d[m] = mfma(ld_frag_g(img_bwd, base + m * KSG + s, lane), dl[s], d[m]);
                 }
+            } else if (a.d_enc != nullptr) {
+                // dL/d(encoded input rows 0..31) = W0^T delta_0: fragments appended behind the output layer's in the W^T image
+                const int base = (depth - 1) * MTG * KSG + MTG;
+                f32x16 de = zero16();
+#pragma unroll
+                for (int s = 0; s < KSG; s++) de = mfma(ld_frag_g(img_bwd, base + s, lane), dl[s], de);
+                half_t* const po = a.d_enc + (size_t)sidx * 32u + 4 * h;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) po[(reg & 3) + 8 * (reg >> 2)] = (half_t)de[reg];
             }
         }
     }
@@ -876,13 +1009,18 @@ struct AdamArgs {
     float lr_t, inv_loss_scale, ema_old, ema_new, ema_div;
 };
 __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
-                           float* __restrict__ v, const float* __restrict__ grad, uint32_t n, AdamArgs a)
+                           float* __restrict__ v, const float* __restrict__ grad, uint32_t n, uint32_t n_matrix, AdamArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, l2 = 1e-8f;
     float wi = w[i];
-    float g = grad[i] * a.inv_loss_scale + l2 * wi;
+    const float graw = grad[i];
+    if (i >= n_matrix && graw == 0.0f) {      // tiny-cuda-nn: grid entries with a zero gradient keep weight and moments
+        ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+        return;
+    }
+    float g = graw * a.inv_loss_scale + (i < n_matrix ? l2 * wi : 0.0f);
     float mi = b1 * m[i] + (1.0f - b1) * g;
     float vi = b2 * v[i] + (1.0f - b2) * (g * g);
     m[i] = mi;
@@ -912,14 +1050,13 @@ __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ em
 }  // namespace
 
 // ================================================================================================ host
-static uint32_t pos_enc_dims(uint32_t id) { return id == 1 ? 3u : id == 2 ? 36u : id == 3 ? 72u : 0u; }
+static uint32_t pos_enc_dims(uint32_t id) { return id == 0 ? 32u : id == 1 ? 3u : id == 2 ? 36u : id == 3 ? 72u : 0u; }
 static uint32_t dir_enc_dims(uint32_t id) { return id == 0 ? 8u : id == 1 ? 2u : id == 2 ? 8u : ~0u; }
 
 Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 {
     width_ = cfg.nn_width;
     depth_ = cfg.nn_depth;
-    if (cfg.pos_id == 0) fail("HashGrid position encoding (posID 0) is not built yet (DESIGN.md section 6)");
     if (pos_enc_dims(cfg.pos_id) == 0 || dir_enc_dims(cfg.dir_id) == ~0u) fail("NNEncodingConfig posID/dirID is invalid");
     if (width_ != 64 && width_ != 128) fail("nnWidth must be 64 or 128 (got " + std::to_string(width_) + ")");
     if (depth_ < 1 || depth_ > 16) fail("nnDepth must be in 1..16 (got " + std::to_string(depth_) + ")");
@@ -941,9 +1078,28 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         off += L.in * L.out;
         layers_.push_back(L);
     }
-    n_params_ = off;
+    n_mlp_ = off;
+    hash_ = cfg.pos_id == 0;
+    uint32_t n_grid = 0;
+    if (hash_) {      // per-level tables: dense while res^3 (rounded up to 8) fits, else 2^log2_hashmap_size entries
+        const uint32_t log2_size = cfg.hashgrid_log2_size ? cfg.hashgrid_log2_size : 19u;
+        if (log2_size < 4 || log2_size > 24) fail("hashgrid_log2_size must be in 4..24");
+        uint32_t o = 0;
+        for (uint32_t l = 0; l < HG_LEVELS; l++) {
+            const double dense = std::pow((double)(16u << l), 3.0);
+            uint32_t cnt = dense > 2147483647.0 ? 2147483647u : (uint32_t)dense;
+            cnt = (cnt + 7u) / 8u * 8u;
+            if (cnt > (1u << log2_size)) cnt = 1u << log2_size;
+            hg_off_[l] = o;
+            o += cnt;
+        }
+        hg_off_[HG_LEVELS] = o;
+        n_grid_entries_ = o;
+        n_grid = o * 2u;
+    }
+    n_params_ = n_mlp_ + n_grid;
 
-    // Xavier-uniform init from pcg32(seed) -- same stream as the oracle's statement of the spec
+    // Xavier-uniform init from pcg32(seed), then the grid uniform in [-1e-4, 1e-4) -- same stream as the oracle's statement
     std::vector<float> w(n_params_);
     Pcg32 rng;
     rng.seed(cfg.seed, 0);
@@ -951,6 +1107,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         const float scale = sqrtf(6.0f / (float)(L.in + L.out));
         for (uint32_t i = 0; i < L.in * L.out; i++) w[L.off + i] = (rng.nextf() * 2.0f - 1.0f) * scale;
     }
+    for (uint32_t i = 0; i < n_grid; i++) w[n_mlp_ + i] = rng.nextf() * 2e-4f - 1e-4f;
 
     const size_t pb = (size_t)n_params_ * sizeof(float);
     NRC_HIP(hipMalloc(&d_w_, pb));
@@ -972,7 +1129,8 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     const int E = (int)enc_dims_;
     const int hid_base = mt_n * ks0, out_base = hid_base + (D - 1) * mt_n * ksh;
     n_frag_fwd_ = (uint32_t)(out_base + ksh);
-    n_frag_bwd_ = (uint32_t)((D - 1) * mt_n * ksh + mt_n);
+    const int din_base = (D - 1) * mt_n * ksh + mt_n;      // W0^T fragments (rows = encoded dims 0..31) for dL/d(input)
+    n_frag_bwd_ = (uint32_t)(din_base + (hash_ ? ksh : 0));
     std::vector<int32_t> sf((size_t)n_frag_fwd_ * 512, -1), sb((size_t)n_frag_bwd_ * 512, -1);
     auto slot = [](int frag, int lane, int j) { return ((size_t)frag * 64 + lane) * 8 + j; };
     for (int lane = 0; lane < 64; lane++) {
@@ -993,8 +1151,10 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
                 const int k = 8 * h + j;
                 if (k < 3) sb[slot((D - 1) * mt_n * ksh + mt, lane, j)] = (int32_t)(layers_[D].off + k * W + (32 * mt + r));
             }
-            for (int s = 0; s < ksh; s++)
+            for (int s = 0; s < ksh; s++) {
                 if (r < 3) sf[slot(out_base + s, lane, j)] = (int32_t)(layers_[D].off + r * W + kperm(s, h, j));
+                if (hash_) sb[slot(din_base + s, lane, j)] = (int32_t)(layers_[0].off + kperm(s, h, j) * E + r);
+            }
         }
     }
     NRC_HIP(hipMalloc(&d_src_fwd_, sf.size() * 4));
@@ -1004,6 +1164,10 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     NRC_HIP(hipMalloc(&d_pk_infer_, sf.size() * 2));
     NRC_HIP(hipMalloc(&d_pk_fwd_, sf.size() * 2));
     NRC_HIP(hipMalloc(&d_pk_bwd_, sb.size() * 2));
+    if (hash_) {
+        NRC_HIP(hipMalloc(&d_t16_train_, (size_t)n_grid_entries_ * 4));
+        NRC_HIP(hipMalloc(&d_t16_ema_, (size_t)n_grid_entries_ * 4));
+    }
     repack(nullptr);
     NRC_HIP(hipStreamSynchronize(nullptr));
 }
@@ -1011,7 +1175,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 Mlp::~Mlp()
 {
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_, d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
-                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_};
+                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_, d_t16_train_, d_t16_ema_, d_denc_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -1034,7 +1198,27 @@ void Mlp::repack(hipStream_t s)
     const uint32_t nmax = nf > nb ? nf : nb;
     hipLaunchKernelGGL(k_pack, dim3(ceil_div(nmax, 256)), dim3(256), 0, s, d_w_, d_ema_, d_src_fwd_, nf, d_src_bwd_, nb,
                        (half_t*)d_pk_infer_, (half_t*)d_pk_fwd_, (half_t*)d_pk_bwd_);
+    if (hash_)
+        hipLaunchKernelGGL(k_pack_grid, dim3(ceil_div(n_grid_entries_, 256)), dim3(256), 0, s, d_w_ + n_mlp_, d_ema_ + n_mlp_,
+                           (uint32_t*)d_t16_train_, (uint32_t*)d_t16_ema_, n_grid_entries_);
     NRC_HIP(hipGetLastError());
+}
+
+// generic-path encoding launch: HashGrid gathers from the fp16 table copy that belongs to the weight set in use
+void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, hipStream_t s)
+{
+    ensure_features(n);
+    if (!hash_) {
+        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, (half_t*)d_feat_, n);
+        return;
+    }
+    HashLevels lv;
+    for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
+    const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_ : d_t16_train_);
+    const dim3 g(ceil_div(n * 16u, 256));
+    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, (half_t*)d_feat_, n, lv);
+    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, (half_t*)d_feat_, n, lv);
+    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, (half_t*)d_feat_, n, lv);
 }
 
 static int g_num_cus = 0;
@@ -1073,8 +1257,7 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     if (n == 0) return;
     const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
     if (!fused_) {
-        ensure_features(n);
-        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, (half_t*)d_feat_, n);
+        launch_features(d_in, n, use_ema, s);
         uint32_t blocks = ceil_div(ceil_div(n, 32), 4);
         const uint32_t cap = (uint32_t)num_cus() * 8u;
         if (blocks > cap) blocks = cap;
@@ -1171,7 +1354,12 @@ void Mlp::ensure_train_workspace(uint32_t n)
     NRC_HIP(hipMalloc(&d_acts_, rows_a * n * 2));
     NRC_HIP(hipMalloc(&d_deltas_, rows_d * n * 2));
     NRC_HIP(hipMemset(d_deltas_, 0, rows_d * n * 2));
-    NRC_HIP(hipMalloc(&d_slabs_, (size_t)ceil_div(n, WGRAD_CHUNK) * n_params_ * 4));
+    NRC_HIP(hipMalloc(&d_slabs_, (size_t)ceil_div(n, WGRAD_CHUNK) * n_mlp_ * 4));
+    if (hash_) {
+        if (d_denc_) (void)hipFree(d_denc_);
+        d_denc_ = nullptr;
+        NRC_HIP(hipMalloc(&d_denc_, (size_t)n * 32 * 2));
+    }
     NRC_HIP(hipMalloc(&d_loss_part_, (size_t)(n / 32) * 4));
     ws_n_ = n;
     if (!d_tiles_) {
@@ -1227,8 +1415,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
                            (const uint4*)d_pk_bwd_);
     } else {
-        ensure_features(n);
-        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, (half_t*)d_feat_, n);
+        launch_features(d_in, n, false, s);
+        if (hash_) NRC_HIP(hipMemsetAsync(d_grad_ + n_mlp_, 0, (size_t)n_grid_entries_ * 2 * sizeof(float), s));
         TrainArgsGen a;
         a.feat = (const half_t*)d_feat_;
         a.target = d_target;
@@ -1240,20 +1428,27 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.loss_part = d_loss_part_;
         a.depth = (int)depth_;
         a.ks0 = (int)enc_dims_ / 16;
+        a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
         const uint32_t cap = (uint32_t)num_cus() * 4u;
         if (blocks > cap) blocks = cap;
         if (width_ == 64)
             hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
         else
             hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+        if (hash_) {
+            HashLevels lv;
+            for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
+            hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
+                               d_grad_ + n_mlp_, n, lv);
+        }
     }
     NRC_HIP(hipGetLastError());
     const uint32_t n_chunks = ceil_div(n, WGRAD_CHUNK);
     hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_, (const half_t*)d_acts_, n,
                        depth_ * width_ + 8, enc_dims_ + depth_ * width_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
-                       n_params_);
+                       n_mlp_);
     NRC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_params_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_params_,
+    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_mlp_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_mlp_,
                        d_grad_, d_loss_part_, n_tiles, d_loss_);
     NRC_HIP(hipGetLastError());
 }
@@ -1271,7 +1466,7 @@ void Mlp::optimizer_step(hipStream_t s)
     a.ema_new = (float)(1.0 - d);
     a.ema_div = (float)(1.0 - std::pow(d, t));
     hipLaunchKernelGGL(k_adam_ema, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_,
-                       n_params_, a);
+                       n_params_, n_mlp_, a);
     NRC_HIP(hipGetLastError());
     repack(s);
 }

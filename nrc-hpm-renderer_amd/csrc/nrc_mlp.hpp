@@ -41,6 +41,7 @@ public:
 private:
     void ensure_train_workspace(uint32_t n);
     void ensure_features(uint32_t n);
+    void launch_features(const float* d_in, uint32_t n, bool use_ema, hipStream_t s);
     void infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
                           const void* image);
 
@@ -51,6 +52,12 @@ private:
     std::vector<MlpLayer> layers_;
     void* d_feat_ = nullptr;     // generic path: fp16 features [n][enc_dims]
     uint32_t feat_n_ = 0;
+    uint32_t n_mlp_ = 0;         // matrix parameters; (posID 0) the hash-grid table [entry][2] follows them in every vector
+    bool hash_ = false;
+    uint32_t hg_off_[17] = {0};  // per-level entry offsets
+    uint32_t n_grid_entries_ = 0;
+    void *d_t16_train_ = nullptr, *d_t16_ema_ = nullptr;   // half2-per-entry gather copies of the table
+    void* d_denc_ = nullptr;     // fp16 [n][32] dL/d(grid features)
 
     float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)

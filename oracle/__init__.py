@@ -31,6 +31,7 @@ class OrcNNConfig(C.Structure):
     _fields_ = [
         ("pos_id", C.c_uint32), ("dir_id", C.c_uint32), ("width", C.c_uint32), ("depth", C.c_uint32),
         ("loss_id", C.c_uint32), ("learning_rate", C.c_float), ("ema_decay", C.c_float), ("seed", C.c_uint32),
+        ("hashgrid_log2_size", C.c_uint32),
     ]
 
 
@@ -73,6 +74,8 @@ class Oracle:
         L.orc_nn_param_count.argtypes = [C.c_void_p]
         L.orc_nn_encoded_dims.restype = C.c_uint32
         L.orc_nn_encoded_dims.argtypes = [C.c_void_p]
+        L.orc_nn_mlp_param_count.restype = C.c_uint32
+        L.orc_nn_mlp_param_count.argtypes = [C.c_void_p]
         L.orc_nn_buffer.restype = C.POINTER(C.c_float)
         L.orc_nn_buffer.argtypes = [C.c_void_p, C.c_int]
         L.orc_nn_set_step.argtypes = [C.c_void_p, C.c_uint32]
@@ -184,8 +187,9 @@ class Oracle:
         return dict(mse=float(r[0]), ref_mean=float(r[1]), own_mean=float(r[2]), own_var=float(r[3]), valid=float(r[4]))
 
     # ---- NN ----
-    def nn_create(self, pos_id=3, dir_id=0, width=64, depth=6, loss_id=0, lr=0.01, ema_decay=0.99, seed=1337):
-        cfg = OrcNNConfig(pos_id, dir_id, width, depth, loss_id, lr, ema_decay, seed)
+    def nn_create(self, pos_id=3, dir_id=0, width=64, depth=6, loss_id=0, lr=0.01, ema_decay=0.99, seed=1337,
+                  hashgrid_log2_size=0):
+        cfg = OrcNNConfig(pos_id, dir_id, width, depth, loss_id, lr, ema_decay, seed, hashgrid_log2_size)
         h = self.lib.orc_nn_create(C.byref(cfg))
         if not h:
             raise ValueError("unsupported encoding for the oracle")
@@ -199,6 +203,7 @@ class OracleNN:
         self.orc, self.h = orc, C.c_void_p(handle)
         self.n_params = int(orc.lib.orc_nn_param_count(self.h))
         self.enc_dims = int(orc.lib.orc_nn_encoded_dims(self.h))
+        self.n_mlp = int(orc.lib.orc_nn_mlp_param_count(self.h))
 
     def buffer(self, which):
         p = self.orc.lib.orc_nn_buffer(self.h, C.c_int(which))

@@ -610,15 +610,20 @@ struct Pcg32 {     /* O'Neill's pcg32 (XSH-RR), the generator tiny-cuda-nn seeds
 
 struct Layer { uint32_t out, in; size_t off; };
 
+/* HashGrid (AppConfig posID 0, src/AppConfig.cpp:19-27): 16 levels x 2 features, 2^19 entries per hashed level,
+ * base resolution 16, per-level scale 2.0.  tiny-cuda-nn v1.6 grid encoding semantics (recalled; PARITY UNPINNED). */
+constexpr uint32_t HG_LEVELS = 16, HG_FEATS = 2, HG_BASE_RES = 16;
 struct NN {
     orc_nn_config cfg;
     uint32_t enc_raw, enc_dims;            /* enc_dims = padded to a multiple of 16 with 1.0 */
     std::vector<Layer> layers;             /* depth hidden matrices + output */
-    std::vector<float> w, ema, m, v, grad;
+    std::vector<float> w, ema, m, v, grad; /* MLP parameters, then (posID 0) the hash-grid table */
+    size_t n_mlp = 0;                      /* number of matrix (MLP) parameters */
+    uint32_t hg_off[HG_LEVELS + 1] = {0};  /* per-level entry offsets */
     uint32_t step;
 };
 
-static uint32_t pos_dims(uint32_t id) { return id == 1 ? 3 : id == 2 ? 36 : id == 3 ? 72 : 0; }
+static uint32_t pos_dims(uint32_t id) { return id == 0 ? HG_LEVELS * HG_FEATS : id == 1 ? 3 : id == 2 ? 36 : id == 3 ? 72 : 0; }
 static uint32_t dir_dims(uint32_t id) { return id == 0 ? 8 : id == 1 ? 2 : id == 2 ? 8 : 0; }
 
 /* tiny-cuda-nn one_blob: quartic kernel CDF */
@@ -634,10 +639,57 @@ static inline float quartic_cdf(float x, float inv_radius)
     return p;
 }
 
-static void encode_one(const NN& nn, const float* in, float* out)     /* out: enc_dims floats, fp16-rounded */
+static inline float hg_scale(uint32_t level) { return exp2f((float)level * 1.0f) * (float)HG_BASE_RES - 1.0f; }   /* per_level_scale 2 */
+static inline uint32_t hg_resolution(float scale) { return (uint32_t)ceilf(scale) + 1u; }
+static inline uint32_t hg_index(uint32_t hashmap_size, uint32_t resolution, const uint32_t* pg)
+{
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < 3 && stride <= hashmap_size; d++) { index += pg[d] * stride; stride *= resolution; }
+    if (hashmap_size < stride) index = (pg[0] * 1u) ^ (pg[1] * 2654435761u) ^ (pg[2] * 805459861u);   /* coherent prime hash */
+    return index % hashmap_size;
+}
+/* per level: the 8 corner entry indices (into the whole table) and trilinear weights of a position */
+static inline void hg_corners(const NN& nn, uint32_t level, const float* x, uint32_t* idx8, float* w8)
+{
+    const float scale = hg_scale(level);
+    const uint32_t res = hg_resolution(scale);
+    const uint32_t hsize = nn.hg_off[level + 1] - nn.hg_off[level];
+    float pos[3]; uint32_t pg[3];
+    for (int d = 0; d < 3; d++) {
+        pos[d] = fmaf(scale, x[d], 0.5f);
+        float tmp = floorf(pos[d]);
+        pg[d] = (uint32_t)(int)tmp;
+        pos[d] -= tmp;
+    }
+    for (uint32_t c = 0; c < 8; c++) {
+        float w = 1.0f; uint32_t pl[3];
+        for (int d = 0; d < 3; d++) {
+            if ((c & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1u; }
+        }
+        idx8[c] = nn.hg_off[level] + hg_index(hsize, res, pl);
+        w8[c] = w;
+    }
+}
+
+static void encode_one(const NN& nn, const float* in, float* out, const float* table = nullptr, bool table_fp16 = true)     /* out: enc_dims floats, fp16-rounded */
 {
     uint32_t o = 0;
     const uint32_t pid = nn.cfg.pos_id, did = nn.cfg.dir_id;
+    if (pid == 0) {            /* HashGrid: trilinear interpolation of 2 features per level */
+        for (uint32_t l = 0; l < HG_LEVELS; l++) {
+            uint32_t idx[8]; float w8[8];
+            hg_corners(nn, l, in, idx, w8);
+            float r[2] = {0.0f, 0.0f};
+            for (int c = 0; c < 8; c++)
+                for (int f = 0; f < 2; f++) {
+                    float v = table[(size_t)idx[c] * 2 + f];
+                    if (table_fp16) v = orc_round_f16(v);
+                    r[f] = fmaf(w8[c], v, r[f]);
+                }
+            out[o++] = r[0]; out[o++] = r[1];
+        }
+    }
     /* position: input dims 0..2 (Composite: nested encodings consume dims in order, AppConfig.cpp:82-86) */
     if (pid == 3) {            /* Frequency n=12: sin(2^f*pi*x + s*pi/2), argument reduced exactly (Q3) */
         for (int d = 0; d < 3; d++)
@@ -735,12 +787,29 @@ void* orc_nn_create(const orc_nn_config* cfg)
         L.off = off; off += (size_t)L.in * L.out;
         nn->layers.push_back(L);
     }
-    nn->w.assign(off, 0.0f); nn->ema = nn->w; nn->m = nn->w; nn->v = nn->w; nn->grad = nn->w;
+    nn->n_mlp = off;
+    size_t n_grid = 0;
+    if (cfg->pos_id == 0) {                       /* per-level tables: dense while res^3 fits, else 2^log2_hashmap_size entries */
+        const uint32_t log2_size = cfg->hashgrid_log2_size ? cfg->hashgrid_log2_size : 19u;
+        uint32_t o = 0;
+        for (uint32_t l = 0; l < HG_LEVELS; l++) {
+            const uint32_t res = hg_resolution(hg_scale(l));
+            const double dense = (double)res * res * res;
+            uint32_t cnt = dense > 2147483647.0 ? 2147483647u : (uint32_t)dense;
+            cnt = (cnt + 7u) / 8u * 8u;
+            cnt = std::min(cnt, 1u << log2_size);
+            nn->hg_off[l] = o; o += cnt;
+        }
+        nn->hg_off[HG_LEVELS] = o;
+        n_grid = (size_t)o * HG_FEATS;
+    }
+    nn->w.assign(off + n_grid, 0.0f); nn->ema = nn->w; nn->m = nn->w; nn->v = nn->w; nn->grad = nn->w;
     Pcg32 rng; rng.seed(cfg->seed, 0);
     for (const Layer& L : nn->layers) {           /* Xavier uniform */
         float scale = sqrtf(6.0f / (float)(L.in + L.out));
         for (size_t i = 0; i < (size_t)L.in * L.out; i++) nn->w[L.off + i] = (rng.nextf() * 2.0f - 1.0f) * scale;
     }
+    for (size_t i = 0; i < n_grid; i++) nn->w[off + i] = rng.nextf() * 2e-4f - 1e-4f;     /* grid: uniform [-1e-4, 1e-4) */
     nn->ema = nn->w;
     nn->step = 0;
     return nn;
@@ -749,6 +818,7 @@ void* orc_nn_create(const orc_nn_config* cfg)
 void orc_nn_destroy(void* p) { delete (NN*)p; }
 uint32_t orc_nn_param_count(void* p) { return (uint32_t)((NN*)p)->w.size(); }
 uint32_t orc_nn_encoded_dims(void* p) { return ((NN*)p)->enc_dims; }
+uint32_t orc_nn_mlp_param_count(void* p) { return (uint32_t)((NN*)p)->n_mlp; }
 void orc_nn_set_step(void* p, uint32_t step) { ((NN*)p)->step = step; }
 
 float* orc_nn_buffer(void* p, int which)
@@ -761,17 +831,19 @@ float* orc_nn_buffer(void* p, int which)
 void orc_nn_encode(void* p, const float* in, uint32_t n, float* out)
 {
     NN* nn = (NN*)p;
-    for (uint32_t i = 0; i < n; i++) encode_one(*nn, in + 5 * (size_t)i, out + (size_t)nn->enc_dims * i);
+    for (uint32_t i = 0; i < n; i++)
+        encode_one(*nn, in + 5 * (size_t)i, out + (size_t)nn->enc_dims * i, nn->ema.data() + nn->n_mlp);
 }
 
 /* NeuralRadianceCache::Inference -> network->inference (src/NeuralRadianceCache.cu:134-145): EMA weights */
 void orc_nn_forward(void* p, const float* in, uint32_t n, int use_ema, int mode, float* out)
 {
     NN* nn = (NN*)p;
-    std::vector<float> wq = quantized_weights(use_ema ? nn->ema : nn->w, mode);
+    const std::vector<float>& src = use_ema ? nn->ema : nn->w;
+    std::vector<float> wq = quantized_weights(std::vector<float>(src.begin(), src.begin() + nn->n_mlp), mode);
     std::vector<float> enc(nn->enc_dims);
     for (uint32_t i = 0; i < n; i++) {
-        encode_one(*nn, in + 5 * (size_t)i, enc.data());
+        encode_one(*nn, in + 5 * (size_t)i, enc.data(), src.data() + nn->n_mlp, mode == 1);
         forward_one(*nn, wq, enc.data(), mode, nullptr, out + 3 * (size_t)i);
     }
 }
@@ -782,8 +854,9 @@ float orc_nn_backward(void* p, const float* in, const float* target, uint32_t n,
     NN* nn = (NN*)p;
     const uint32_t depth = nn->cfg.depth, width = nn->cfg.width;
     const float loss_scale = 128.0f;
-    std::vector<float> wq = quantized_weights(nn->w, 1);
+    std::vector<float> wq = quantized_weights(std::vector<float>(nn->w.begin(), nn->w.begin() + nn->n_mlp), 1);
     std::vector<double> g(nn->w.size(), 0.0);
+    const float* table = nn->w.data() + nn->n_mlp;
     std::vector<float> enc(nn->enc_dims);
     std::vector<std::vector<float>> acts(depth);
     std::vector<float> delta, prev;
@@ -791,7 +864,7 @@ float orc_nn_backward(void* p, const float* in, const float* target, uint32_t n,
     const float n_total = (float)(3u * n_norm);
     for (uint32_t i = 0; i < n; i++) {
         float y[3];
-        encode_one(*nn, in + 5 * (size_t)i, enc.data());
+        encode_one(*nn, in + 5 * (size_t)i, enc.data(), table, true);
         forward_one(*nn, wq, enc.data(), 1, &acts, y);
         const float* t = target + 3 * (size_t)i;
         float dy[3];
@@ -837,6 +910,20 @@ float orc_nn_backward(void* p, const float* in, const float* target, uint32_t n,
                     prev[k] = orc_round_f16(d);
                 }
                 delta.swap(prev);
+            } else if (nn->cfg.pos_id == 0) {
+                /* dL/d(encoding) for the trainable grid: W0^T delta_0 (fp16, like every delta), scattered to the 8 corners */
+                for (uint32_t lv = 0; lv < HG_LEVELS; lv++) {
+                    uint32_t idx[8]; float w8[8];
+                    hg_corners(*nn, lv, in + 5 * (size_t)i, idx, w8);
+                    for (int f = 0; f < 2; f++) {
+                        const uint32_t k = lv * 2 + f;
+                        double acc = 0.0;
+                        for (uint32_t j = 0; j < L.out; j++) acc += (double)wq[L.off + (size_t)j * L.in + k] * (double)delta[j];
+                        const float de = orc_round_f16((float)acc);
+                        if (de == 0.0f) continue;
+                        for (int c = 0; c < 8; c++) g[nn->n_mlp + (size_t)idx[c] * 2 + f] += (double)w8[c] * (double)de;
+                    }
+                }
             }
         }
     }
@@ -861,7 +948,13 @@ void orc_nn_optimizer_step(void* p)
     const float ema_div = (float)(1.0 - pow(d, t));
     for (size_t i = 0; i < nn->w.size(); i++) {
         float w = nn->w[i];
-        float g = nn->grad[i] + l2 * w;
+        /* tiny-cuda-nn Adam: L2 only on matrix (MLP) weights; grid entries with a zero gradient are left untouched */
+        const bool matrix = i < nn->n_mlp;
+        if (!matrix && nn->grad[i] == 0.0f) {
+            nn->ema[i] = (nn->ema[i] * ema_old + w * ema_new) / ema_div;
+            continue;
+        }
+        float g = nn->grad[i] + (matrix ? l2 * w : 0.0f);
         float m = nn->m[i] = b1 * nn->m[i] + (1.0f - b1) * g;
         float v = nn->v[i] = b2 * nn->v[i] + (1.0f - b2) * (g * g);
         w = w - lr * m / (sqrtf(v) + eps);

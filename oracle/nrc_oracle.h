@@ -96,13 +96,16 @@ typedef struct orc_nn_config {
     uint32_t loss_id;            /* 0 RelativeL2Luminance, 1 L2, 2 RelativeL2 */
     float learning_rate, ema_decay;
     uint32_t seed;
+    uint32_t hashgrid_log2_size; /* posID 0 only: log2_hashmap_size (0 = 19, src/AppConfig.cpp:24) */
 } orc_nn_config;
 
 void* orc_nn_create(const orc_nn_config* cfg);
 void orc_nn_destroy(void* nn);
 uint32_t orc_nn_param_count(void* nn);
 uint32_t orc_nn_encoded_dims(void* nn);
-/* which: 0 master weights, 1 EMA weights, 2 adam m, 3 adam v, 4 last gradient (already / loss_scale) */
+/* which: 0 master weights, 1 EMA weights, 2 adam m, 3 adam v, 4 last gradient (already / loss_scale);
+ * layout: MLP matrices, then (posID 0) the hash-grid table [entry][2] */
+uint32_t orc_nn_mlp_param_count(void* nn);
 float* orc_nn_buffer(void* nn, int which);
 void orc_nn_set_step(void* nn, uint32_t step);
 /* features after fp16 rounding, [n][encoded_dims] */

@@ -135,17 +135,19 @@ def test_prep_train_and_ring_buffer_match_oracle(api, orc, sc, cloud16, torch_gp
     nrc.Destroy()
 
 
-@pytest.mark.parametrize("model", [(3, 0, 64, 6), (3, 0, 128, 8), (2, 0, 64, 3)])
+@pytest.mark.parametrize("model", [(3, 0, 64, 6), (3, 0, 128, 8), (2, 0, 64, 3), (0, 0, 64, 6)])
 def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu, model):
     """NrcHpmRenderer::Render(queue, true): gen_rays -> prep_train -> InferAndTrain -> render.comp, two frames with
     blending; inference always sees the previous frame's EMA weights (quirk Q13).  Models: the north-star 6x64 (fused
-    kernels), BASELINE configs[4]'s 8x128 and a TriangleWave/3x64 net (generic kernels)."""
+    kernels), BASELINE configs[4]'s 8x128, a TriangleWave/3x64 net and the reference-default HashGrid model (generic kernels)."""
     W, H = 128, 80
     scene = sc.make_scene(cloud16, scene_id=4)
     pos_id, dir_id, width, depth = model
-    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth)
+    hg = 12 if pos_id == 0 else 0          # HashGrid (the reference's default encoding) with a small table for the oracle
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth,
+                                    hashgrid_log2_size=hg)
     ren.SetBlend(True)
-    onn = orc.nn_create(pos_id=pos_id, dir_id=dir_id, width=width, depth=depth)
+    onn = orc.nn_create(pos_id=pos_id, dir_id=dir_id, width=width, depth=depth, hashgrid_log2_size=hg)
     tg = ren.TrainGrid()
     T = tg["tw"] * tg["th"]
     head_tail = np.zeros(2, np.uint32)

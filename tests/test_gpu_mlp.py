@@ -220,7 +220,7 @@ def test_checkpoint_roundtrip(api, torch_gpu):
 
 
 def test_unsupported_configurations_fail_loudly(api, torch_gpu):
-    for kw in (dict(pos_id=0), dict(pos_id=4), dict(dir_id=3), dict(nn_width=96), dict(nn_depth=0), dict(optimizer="SGD"),
+    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_depth=0), dict(optimizer="SGD"),
                dict(loss_fn="Huber")):
         with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
             api.NeuralRadianceCache(api.AppConfig(**kw))
@@ -274,4 +274,70 @@ def test_generic_models_match_oracle(api, orc, torch_gpu, pos_id, dir_id, width,
     c.OptimizerStep()
     onn.optimizer_step()
     assert rel(c.GetParams(0), onn.buffer(0)) < 3e-3
+    c.Destroy()
+
+
+@pytest.mark.parametrize("dir_id,width,depth,log2", [(0, 64, 6, 12), (1, 64, 2, 10), (0, 128, 4, 14)])
+def test_hashgrid_model_matches_oracle(api, orc, torch_gpu, dir_id, width, depth, log2):
+    """reference default encoding, AppConfig posID 0 (src/AppConfig.cpp:19-27, src/main.cu:435): HashGrid forward,
+    dL/d(table) scatter, Adam that skips untouched entries, EMA table for inference"""
+    c = api.NeuralRadianceCache(api.AppConfig(pos_id=0, dir_id=dir_id, nn_width=width, nn_depth=depth, hashgrid_log2_size=log2))
+    onn = orc.nn_create(pos_id=0, dir_id=dir_id, width=width, depth=depth, hashgrid_log2_size=log2)
+    assert c.ParamCount() == onn.n_params
+    assert np.array_equal(c.GetParams(0), onn.buffer(0))
+    rng = np.random.default_rng(17)
+    # O(0.3) table entries so that the grid features matter
+    w = np.array(onn.buffer(0))
+    w[onn.n_mlp:] = (rng.standard_normal(onn.n_params - onn.n_mlp) * 0.3).astype(np.float32)
+    e = w.copy()
+    e[onn.n_mlp:] += (rng.standard_normal(onn.n_params - onn.n_mlp) * 0.05).astype(np.float32)
+    onn.buffer(0)[:] = w
+    onn.buffer(1)[:] = e
+    c.SetParams(0, w)
+    c.SetParams(1, e)
+    n = 2048
+    x = rng.random((n, 5), dtype=np.float32)              # positions in [0,1): what the encoding is designed for
+    x[:256, :3] += 31.0                                   # and a block in the quirk-Q3 range (indices wrap)
+    for use_ema in (True, False):
+        out = torch_gpu.empty((n, 3), device="cuda")
+        c.Infer(torch_gpu.from_numpy(x).cuda(), out, useEma=use_ema)
+        ref = onn.forward(x, use_ema, 1)
+        assert rel(out.cpu().numpy()[256:], ref[256:]) < 3e-3
+        assert rel(out.cpu().numpy()[:256], ref[:256]) < 3e-2     # coordinates ~31: fp32 fractional parts at high levels are coarse
+    t = rng.random((n, 3), dtype=np.float32)
+    xs = x[256:1280].copy()
+    c.Backward(torch_gpu.from_numpy(xs).cuda(), torch_gpu.from_numpy(t[:1024]).cuda())
+    loss_ref = onn.backward(xs, t[:1024])
+    assert abs(c.GetLoss() - loss_ref) < 3e-3 * abs(loss_ref)
+    g, g_ref = c.GetParams(4) / 128.0, np.array(onn.buffer(4))
+    assert rel(g[:onn.n_mlp], g_ref[:onn.n_mlp]) < 2e-2
+    assert rel(g[onn.n_mlp:], g_ref[onn.n_mlp:]) < 3e-2            # fp32 atomics, fp16 dL/d(feature)
+    assert np.array_equal(g[onn.n_mlp:] != 0, g_ref[onn.n_mlp:] != 0) or \
+        (np.logical_xor(g[onn.n_mlp:] != 0, g_ref[onn.n_mlp:] != 0).mean() < 1e-3)
+    c.OptimizerStep()
+    onn.optimizer_step()
+    w1, w1_ref = c.GetParams(0), np.array(onn.buffer(0))
+    untouched = g_ref[onn.n_mlp:] == 0
+    assert np.array_equal(w1[onn.n_mlp:][untouched & (g[onn.n_mlp:] == 0)], w[onn.n_mlp:][untouched & (g[onn.n_mlp:] == 0)])
+    assert rel(w1, w1_ref) < 2e-2
+    out = torch_gpu.empty((n, 3), device="cuda")
+    c.Infer(torch_gpu.from_numpy(x).cuda(), out, useEma=True)          # EMA table after the step
+    assert rel(out.cpu().numpy()[256:], onn.forward(x, True, 1)[256:]) < 1e-2
+    c.Destroy()
+
+
+def test_hashgrid_default_size_trains(api, torch_gpu):
+    """the reference's actual default: 2^19 entries per hashed level = 14.2 M table parameters (57 MB fp32)"""
+    c = api.NeuralRadianceCache(api.AppConfig(pos_id=0))
+    assert c.ParamCount() == 64 * 48 + 5 * 64 * 64 + 3 * 64 + 2 * 7114752
+    rng = np.random.default_rng(3)
+    x = rng.random((4096, 5), dtype=np.float32)
+    t = np.stack([np.sin(x[:, 0] * 9) * 0.5 + 0.5, x[:, 1], np.full(4096, 0.3, np.float32)], axis=1).astype(np.float32)
+    d_x, d_t = torch_gpu.from_numpy(x).cuda(), torch_gpu.from_numpy(t).cuda()
+    losses = []
+    for _ in range(60):
+        c.Backward(d_x, d_t)
+        c.OptimizerStep()
+        losses.append(c.GetLoss())
+    assert np.isfinite(losses).all() and losses[-1] < 0.3 * losses[0]
     c.Destroy()

@@ -152,3 +152,82 @@ def test_training_reduces_loss(orc):
         first = last if first is None else first
         nn.optimizer_step()
     assert last < 0.5 * first
+
+
+def numpy_hashgrid(x3, table, offsets):
+    """independent statement of tiny-cuda-nn's multiresolution hash encoding (16 levels x 2 features, base 16, scale 2)"""
+    n = x3.shape[0]
+    out = np.zeros((n, 32), np.float64)
+    for l in range(16):
+        res = 16 << l
+        scale = np.float32(res - 1)
+        hsize = offsets[l + 1] - offsets[l]
+        pos = np.float32(scale) * x3.astype(np.float32) + np.float32(0.5)      # fma differs from mul+add by <= 1 ulp: fine here
+        pg = np.floor(pos)
+        fr = (pos - pg).astype(np.float64)
+        pg = pg.astype(np.int64)
+        for c in range(8):
+            w = np.ones(n)
+            pl = []
+            for d in range(3):
+                if c & (1 << d):
+                    w *= fr[:, d]
+                    pl.append(pg[:, d] + 1)
+                else:
+                    w *= 1 - fr[:, d]
+                    pl.append(pg[:, d])
+            pl = [p.astype(np.uint64) & 0xFFFFFFFF for p in pl]
+            if res ** 3 <= hsize:
+                idx = (pl[0] + pl[1] * res + pl[2] * res * res) & 0xFFFFFFFF
+            else:
+                idx = ((pl[0] * 1) ^ ((pl[1] * 2654435761) & 0xFFFFFFFF) ^ ((pl[2] * 805459861) & 0xFFFFFFFF)) & 0xFFFFFFFF
+            idx = (idx % hsize).astype(np.int64) + offsets[l]
+            for f in range(2):
+                out[:, 2 * l + f] += w * table[idx * 2 + f]
+    return out
+
+
+def test_hashgrid_encoding_and_layout(orc):
+    """AppConfig posID 0 (src/AppConfig.cpp:19-27): table sizes of SURVEY section 5 and the encoding itself"""
+    full = orc.nn_create(pos_id=0)
+    assert (full.n_params - full.n_mlp) == 2 * 7114752                     # 16^3 + 32^3 + 64^3 + 13 * 2^19 entries
+    assert full.enc_dims == 48 and full.n_mlp == 64 * 48 + 5 * 64 * 64 + 3 * 64
+    nn = orc.nn_create(pos_id=0, hashgrid_log2_size=12)
+    offsets = [0]
+    for l in range(16):
+        offsets.append(offsets[-1] + min(((16 << l) ** 3 + 7) // 8 * 8, 1 << 12))
+    assert (nn.n_params - nn.n_mlp) == 2 * offsets[-1]
+    table = np.array(nn.buffer(1)[nn.n_mlp:])
+    assert np.abs(table).max() <= 1e-4 and np.abs(table).max() > 0.9e-4      # uniform [-1e-4, 1e-4)
+    rng = np.random.default_rng(0)
+    nn.buffer(1)[nn.n_mlp:] = rng.standard_normal(table.size).astype(np.float32)    # O(1) features for a meaningful check
+    table = np.array(nn.buffer(1)[nn.n_mlp:]).astype(np.float16).astype(np.float64)  # the oracle gathers fp16 copies
+    x = rng.random((64, 5), dtype=np.float32)
+    x[32:, :3] += 31.0                                                       # quirk Q3 range: indices wrap by modulo / hash
+    e = nn.encode(x)
+    ref = numpy_hashgrid(x[:, :3], table, offsets)
+    # low levels only for the large coordinates: at level l >= 8 an fma-vs-mul+add ulp moves the fractional part visibly
+    assert np.allclose(e[:32, :32], ref[:32], atol=2e-3, rtol=2e-3)
+    assert np.allclose(e[32:, :8], ref[32:, :8], atol=5e-2, rtol=5e-2)
+    assert np.allclose(e[:, 40:], 1.0)                                       # 32 + 8 -> padded to 48 with ones
+
+
+def test_hashgrid_backward_and_sparse_adam(orc):
+    nn = orc.nn_create(pos_id=0, hashgrid_log2_size=10)
+    rng = np.random.default_rng(1)
+    x = rng.random((64, 5), dtype=np.float32)
+    t = rng.random((64, 3), dtype=np.float32)
+    w0 = np.array(nn.buffer(0))
+    nn.backward(x, t)
+    g = np.array(nn.buffer(4))
+    gg = g[nn.n_mlp:]
+    assert 0 < np.count_nonzero(gg) < gg.size            # sparse: only touched corners
+    # finite-difference check of one touched grid entry (loss is smooth in the table)
+    k = int(np.argmax(np.abs(gg)))
+    nn.optimizer_step()
+    w1 = np.array(nn.buffer(0))
+    touched = gg != 0
+    assert np.array_equal(w1[nn.n_mlp:][~touched], w0[nn.n_mlp:][~touched])      # zero-gradient entries untouched
+    assert (w1[nn.n_mlp:][touched] != w0[nn.n_mlp:][touched]).mean() > 0.99
+    assert abs(abs(w1[nn.n_mlp + k] - w0[nn.n_mlp + k]) - 0.01) < 1e-3              # first Adam step = lr * sign(g)
+    assert np.array_equal(np.array(nn.buffer(2))[nn.n_mlp:][~touched], np.zeros((~touched).sum(), np.float32))
