@@ -85,6 +85,12 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # model overrides (default = the north-star model of BASELINE.json: Frequency+OneBlob, 6x64)
+    ap.add_argument("--pos-id", type=int, default=3)
+    ap.add_argument("--dir-id", type=int, default=0)
+    ap.add_argument("--nn-width", type=int, default=64)
+    ap.add_argument("--nn-depth", type=int, default=6)
+    ap.add_argument("--smoke-volume", action="store_true", help="configs[4]: seeded smoke plume instead of the fBm cloud")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,11 +114,12 @@ def main():
 
     W, H, spp = args.width, args.height, args.spp
     # ---- synthetic inputs: seeded 256^3 fBm cloud, procedural HDR sky, scene preset 4 values
-    cache_file = "/tmp/nrc_cloud_%d_1337.npy" % args.volume
+    cache_file = "/tmp/nrc_%s_%d_1337.npy" % ("smoke" if args.smoke_volume else "cloud", args.volume)
     if os.path.exists(cache_file):
         vol = np.load(cache_file)
     else:
-        vol = sc.quantize_density(sc.fbm_cloud_volume(args.volume, seed=1337))
+        gen = sc.smoke_volume if args.smoke_volume else sc.fbm_cloud_volume
+        vol = sc.quantize_density(gen(args.volume, seed=1337))
         try:
             np.save(cache_file + ".%d.tmp.npy" % os.getpid(), vol)
             os.replace(cache_file + ".%d.tmp.npy" % os.getpid(), cache_file)
@@ -124,7 +131,9 @@ def main():
     local_w = parallel.local_width(rank, world, gw)
     cam = sc.make_camera(aspect=gw / gh)
     cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=14, log2_infer_batch_size=21, scene_id=4,
-                        primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337)
+                        primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337,
+                        pos_id=args.pos_id, dir_id=args.dir_id, nn_width=args.nn_width, nn_depth=args.nn_depth)
+    north_star = (args.pos_id, args.dir_id, args.nn_width, args.nn_depth) == (3, 0, 64, 6)
     nrc = api.NeuralRadianceCache(cfg)
     ren = api.NrcHpmRenderer(local_w, gh, True, cam, cfg, scene, nrc, tile=tile)
     if use_dist and args.train:

@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnrc_hpm.so")
+# NRC_HPM_LIB: tooling override (tools/loop_profile.py loads an instrumented build)
+LIB_PATH = os.environ.get("NRC_HPM_LIB") or os.path.join(_HERE, "lib", "libnrc_hpm.so")
 
 NRC_FIX_Q1_TRAIN_Y_DIST = 1
 NRC_FIX_Q2_TRAIN_RAY_LEN = 2

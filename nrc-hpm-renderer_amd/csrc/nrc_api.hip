@@ -306,13 +306,17 @@ public:
         tg_.ray_length = (cfg.compat_fix & NRC_FIX_Q2_TRAIN_RAY_LEN) ? cfg.train_ray_length : 1u;
         tg_.ring_size = (uint32_t)(cfg.train_ring_buf_size * (float)(tg_.tw * tg_.th));   // :253
         const size_t px = (size_t)w * h, T = (size_t)tg_.tw * tg_.th;
-        alloc(&d_primary_, px * 16);
-        // didScatter / NRC vertex images are double-buffered: frame N's train-ray generation (second stream) reads them while
-        // frame N+1's gen_rays already writes the other set
-        for (int k = 0; k < 2; k++) { alloc(&d_info2_[k], px * 4); alloc(&d_origin2_[k], px * 16); alloc(&d_dir2_[k], px * 16); }
-        d_info_ = d_info2_[0]; d_origin_ = d_origin2_[0]; d_dir_ = d_dir2_[0];
+        // everything gen_rays writes is double-buffered: frame N's train-ray generation (stream B), inference and compositing
+        // (stream C) read set N&1 while frame N+1's gen_rays (stream A) already writes the other set
+        for (int k = 0; k < 2; k++) {
+            alloc(&d_primary2_[k], px * 16); alloc(&d_info2_[k], px * 4); alloc(&d_origin2_[k], px * 16);
+            alloc(&d_dir2_[k], px * 16); alloc(&d_infer_in2_[k], px * 20);
+        }
+        d_primary_ = d_primary2_[0]; d_info_ = d_info2_[0]; d_origin_ = d_origin2_[0]; d_dir_ = d_dir2_[0];
+        d_infer_in_ = d_infer_in2_[0];
         for (auto& e : ev_train_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        alloc(&d_out_, px * 16); alloc(&d_infer_in_, px * 20); alloc(&d_infer_out_, px * 12);
+        for (auto& e : ev_comp_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        alloc(&d_out_, px * 16); alloc(&d_infer_out_, px * 12);
         alloc(&d_train_in_, T * 20); alloc(&d_train_target_, T * 12);
         ring_entries_ = std::max<size_t>(T, tg_.ring_size);
         alloc(&d_ring_, 8 + ring_entries_ * 24);
@@ -326,6 +330,8 @@ public:
             int lo = 0, hi = 0;
             NRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
             NRC_HIP(hipStreamCreateWithPriority(&stream_b_, hipStreamNonBlocking, hi));
+            // third stream: inference + compositing of frame N run beside gen_rays of frame N+1 (MFMA beside VALU work)
+            if (!getenv("NRC_TWO_STREAMS")) NRC_HIP(hipStreamCreateWithPriority(&stream_c_, hipStreamNonBlocking, hi));
         }
         // CreateNrcTrainRingBuffer: head = tail = 0, pos = 0, dir = (0,0,1)  (:866-875)
         std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
@@ -341,7 +347,9 @@ public:
         for (auto& set : ev_pool_)
             for (auto& e : set) if (e) (void)hipEventDestroy(e);
         if (stream_b_) (void)hipStreamDestroy(stream_b_);
+        if (stream_c_) (void)hipStreamDestroy(stream_c_);
         for (auto& e : ev_train_done_) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_comp_done_) if (e) (void)hipEventDestroy(e);
     }
 
     void render(bool train)      // NrcHpmRenderer::Render, :299-353
@@ -360,45 +368,58 @@ public:
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
         if (blend_) blend_index_++;
-        // Frame graph on two streams, pipelined across frames (no host sync anywhere):
-        //   A: gen_rays(N) -> [wait train(N-1)] inference(N) -> composite(N)
-        //   B: [wait gen_rays(N)] train-ray generation(N) -> backward(N) -> (all-reduce hook) -> [wait inference(N)] optimizer(N)
-        // so frame N's training overlaps frame N's inference AND frame N+1's gen_rays; inference(N+1) still sees the weights
-        // after frame N's training (quirk Q13 ordering).
+        // Frame graph on three streams, pipelined across frames (no host sync anywhere):
+        //   A: [wait composite(N-2), train(N-2)] gen_rays(N)
+        //   C: [wait gen_rays(N), train(N-1)] inference(N) -> composite(N)
+        //   B: [wait gen_rays(N)] train-ray generation(N) -> backward(N) -> (all-reduce) -> [wait inference(N)] optimizer(N)
+        // so frame N's training and inference overlap frame N+1's gen_rays (the MFMA kernel runs beside the VALU-bound
+        // integrator); inference(N+1) still sees the weights after frame N's training (quirk Q13 ordering).
         // events: 0 frame start, 1 gen_rays done, 2 prep_train done (B), 3 inference done, 4 composite done, 5 training done (B)
-        hipStream_t A = stream_, B = stream_b_ ? stream_b_ : stream_;
+        hipStream_t A = stream_, B = stream_b_ ? stream_b_ : stream_, Cs = stream_c_ ? stream_c_ : stream_;
         const int pp = (int)(frame_index_ & 1u);
-        d_info_ = d_info2_[pp]; d_origin_ = d_origin2_[pp]; d_dir_ = d_dir2_[pp];
+        d_primary_ = d_primary2_[pp]; d_info_ = d_info2_[pp]; d_origin_ = d_origin2_[pp]; d_dir_ = d_dir2_[pp];
+        d_infer_in_ = d_infer_in2_[pp];
+        if (frame_index_ >= 2) {      // buffer set pp was last read by frame N-2
+            if (Cs != A) NRC_HIP(hipStreamWaitEvent(A, ev_comp_done_[pp], 0));
+            if (B != A) NRC_HIP(hipStreamWaitEvent(A, ev_train_done_[pp], 0));
+        }
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
                         count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, A);
         NRC_HIP(hipEventRecord(ev_[1], A));
         if (B != A) NRC_HIP(hipStreamWaitEvent(B, ev_[1], 0));
+        if (Cs != A) NRC_HIP(hipStreamWaitEvent(Cs, ev_[1], 0));
         // the reference records prep_train_rays into every frame's pre-CUDA command buffer (:2039-2040), trained or not
         launch_prep_train(scene_.d, frame_, tg_, (const float*)d_info_, (const float*)d_origin_, (const float*)d_dir_,
                           (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, B);
         NRC_HIP(hipEventRecord(ev_[2], B));
-        if (B != A && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(A, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
+        if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
         // same NRC from another camera, src/Reference.cpp:71-107)
         cache_.init((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
-                    (float*)d_train_target_, A);
+                    (float*)d_train_target_, Cs);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
-        cache_.infer_all(nullptr, A, !getenv("NRC_DENSE_INFER"));
-        NRC_HIP(hipEventRecord(ev_[3], A));
-        if (train) cache_.train_all(B, B != A ? ev_[3] : nullptr);
+        cache_.infer_all(nullptr, Cs, !getenv("NRC_DENSE_INFER"));
+        NRC_HIP(hipEventRecord(ev_[3], Cs));
+        if (train) cache_.train_all(B, B != Cs ? ev_[3] : nullptr);
         NRC_HIP(hipEventRecord(ev_[5], B));
         NRC_HIP(hipEventRecord(ev_train_done_[pp], B));
         launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
-                         (const float*)d_infer_out_, (float*)d_out_, A);
-        NRC_HIP(hipEventRecord(ev_[4], A));
+                         (const float*)d_infer_out_, (float*)d_out_, Cs);
+        NRC_HIP(hipEventRecord(ev_[4], Cs));
+        NRC_HIP(hipEventRecord(ev_comp_done_[pp], Cs));
         frame_index_++;
         timed_ = true;
     }
 
     // everything this renderer has enqueued (both streams) is complete
-    void sync() { NRC_HIP(hipStreamSynchronize(stream_)); if (stream_b_) NRC_HIP(hipStreamSynchronize(stream_b_)); }
+    void sync()
+    {
+        NRC_HIP(hipStreamSynchronize(stream_));
+        if (stream_b_) NRC_HIP(hipStreamSynchronize(stream_b_));
+        if (stream_c_) NRC_HIP(hipStreamSynchronize(stream_c_));
+    }
 
     void set_camera(const nrc_camera& c)       // SetCamera, :561-604: reset blending, clear the accumulation images
     {
@@ -407,8 +428,10 @@ public:
         blend_index_ = 1;
         const size_t px = (size_t)w_ * h_;
         NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
-        NRC_HIP(hipMemsetAsync(d_primary_, 0, px * 16, stream_));
-        for (int k = 0; k < 2; k++) NRC_HIP(hipMemsetAsync(d_info2_[k], 0, px * 4, stream_));
+        for (int k = 0; k < 2; k++) {
+            NRC_HIP(hipMemsetAsync(d_primary2_[k], 0, px * 16, stream_));
+            NRC_HIP(hipMemsetAsync(d_info2_[k], 0, px * 4, stream_));
+        }
     }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }      // :606-610
     void set_show_nrc(bool s) { show_nrc_ = s ? 1u : 0u; }
@@ -474,6 +497,7 @@ public:
     void export_exr(const char* path)
     {
         std::vector<float> host((size_t)w_ * h_ * 4);
+        sync();
         NRC_HIP(hipMemcpyAsync(host.data(), d_out_, host.size() * 4, hipMemcpyDeviceToHost, stream_));
         NRC_HIP(hipStreamSynchronize(stream_));
         write_exr(path, host, w_, h_);
@@ -545,13 +569,14 @@ private:
     size_t ring_entries_ = 0;
     void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
     void *d_info2_[2] = {nullptr, nullptr}, *d_origin2_[2] = {nullptr, nullptr}, *d_dir2_[2] = {nullptr, nullptr};
-    hipEvent_t ev_train_done_[2] = {nullptr, nullptr};
+    void *d_primary2_[2] = {nullptr, nullptr}, *d_infer_in2_[2] = {nullptr, nullptr};
+    hipEvent_t ev_train_done_[2] = {nullptr, nullptr}, ev_comp_done_[2] = {nullptr, nullptr};
     uint64_t frame_index_ = 0;
     void *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
     void *d_ring_ = nullptr, *d_scratch_ = nullptr, *d_fetch_ = nullptr;
     std::vector<void*> allocs_;
     std::vector<std::array<hipEvent_t, 10>> ev_pool_;
-    hipStream_t stream_b_ = nullptr;
+    hipStream_t stream_b_ = nullptr, stream_c_ = nullptr;
     size_t ev_used_ = 0;
     bool timed_ = false;
     float pinned_random_[4] = {0, 0, 0, 0};

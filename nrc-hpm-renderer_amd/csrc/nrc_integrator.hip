@@ -58,10 +58,78 @@ __device__ __forceinline__ float random4(const float* v)
     return float_construct(hash1(nrc_f2u(v[0]) ^ hash1(nrc_f2u(v[1])) ^ hash1(nrc_f2u(v[2])) ^ hash1(nrc_f2u(v[3]))));
 }
 
+// two fp32 lanes per VGPR pair: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 perform the same IEEE operation on each half,
+// so the packed forms below are bit-identical to their scalar statements (nrc_math.h) at half the VALU issue cost
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// nrc_logf (nrc_math.h) on two arguments
+__device__ __forceinline__ f2 logf2(f2 x)
+{
+    const uint32_t i0 = nrc_f2u(x.x), i1 = nrc_f2u(x.y);
+    int e0 = (int)(i0 >> 23) - 126, e1 = (int)(i1 >> 23) - 126;
+    f2 m = f2{nrc_u2f((i0 & 0x007fffffu) | 0x3f000000u), nrc_u2f((i1 & 0x007fffffu) | 0x3f000000u)};
+    const bool lo0 = m.x < 0.707106769084930420f, lo1 = m.y < 0.707106769084930420f;
+    e0 -= lo0 ? 1 : 0;
+    e1 -= lo1 ? 1 : 0;
+    m = (m + f2{lo0 ? m.x : 0.0f, lo1 ? m.y : 0.0f}) - splat(1.0f);      // (m + m) - 1 or (m + 0) - 1 == m - 1
+    f2 z = m * m;
+    f2 y = splat(7.0376836292E-2f);
+    y = fma2(y, m, splat(-1.1514610310E-1f));
+    y = fma2(y, m, splat(1.1676998740E-1f));
+    y = fma2(y, m, splat(-1.2420140846E-1f));
+    y = fma2(y, m, splat(1.4249322787E-1f));
+    y = fma2(y, m, splat(-1.6668057665E-1f));
+    y = fma2(y, m, splat(2.0000714765E-1f));
+    y = fma2(y, m, splat(-2.4999993993E-1f));
+    y = fma2(y, m, splat(3.3333331174E-1f));
+    y = y * m;
+    y = y * z;
+    const f2 fe = f2{(float)e0, (float)e1};
+    y = fma2(splat(-2.12194440e-4f), fe, y);
+    y = fma2(splat(-0.5f), z, y);
+    z = m + y;
+    z = fma2(splat(0.693359375f), fe, z);
+    return z;
+}
+
+// correctly rounded sqrt for x == 0 or normal x: v_sqrt_f32 (1 ulp) + the one-ulp fix-up hipcc's own sqrtf lowering uses,
+// without its denormal pre-scaling and class test.  Only sky_sdf calls it: its argument is a sum of squares of
+// |p| - half_size terms, each 0 or >= half an ulp of a scene-sized coordinate, never denormal.
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = nrc_u2f(nrc_f2u(y) - 1u), yp = nrc_u2f(nrc_f2u(y) + 1u);
+    const float rm = nrc_fmaf_(-ym, y, x), rp = nrc_fmaf_(-yp, y, x);
+    y = (rm <= 0.0f) ? ym : y;
+    y = (rp > 0.0f) ? yp : y;
+    return y;
+}
+
+// tools/loop_profile.py builds a second library with -DNRC_LOOP_PROFILE: per loop kind, iterations summed over lanes
+// ("useful") and 64 x iterations issued by the wave ("issued"); never defined in the product build
+#ifdef NRC_LOOP_PROFILE
+__device__ unsigned long long g_loop_prof[16];
+#define NRC_PROF(c, k)                                                                    \
+    do {                                                                                  \
+        (c).useful[k]++;                                                                  \
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) (c).issued[k] += 64u; \
+    } while (0)
+#else
+#define NRC_PROF(c, k) do { } while (0)
+#endif
+
 struct Ctx {
     const DevScene& sc;
     float rng;              // randomState
     uint32_t fetches;
+    // raw buffer view of the volume: offsets >= the voxel count read 0, which is the sampler's black border
+    __amdgpu_buffer_rsrc_t vol = __builtin_amdgcn_make_buffer_rsrc((void*)sc.density, 0, (int)(sc.nx * sc.ny * sc.nz), 0x00020000);
+#ifdef NRC_LOOP_PROFILE
+    uint32_t useful[8] = {0, 0, 0, 0, 0, 0, 0, 0}, issued[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t fee_kind = 1;
+#endif
     __device__ __forceinline__ float rand(float max_val)
     {
         rng = random1(rng);
@@ -79,13 +147,15 @@ __device__ __forceinline__ float sky_sdf(const DevScene& s, V3 p)
 {
     V3 d = v3(fabsf(p.x) - s.half_size[0], fabsf(p.y) - s.half_size[1], fabsf(p.z) - s.half_size[2]);
     V3 dm = v3(fmaxf(d.x, 0.0f), fmaxf(d.y, 0.0f), fmaxf(d.z, 0.0f));
-    return length(dm) + fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f);
+    return sqrt_rn_normal(dot(dm, dm)) + fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f);
 }
 
-__device__ __forceinline__ void find_entry_exit(const DevScene& s, V3 ro, V3 rd, V3* entry, V3* exit_)
+__device__ __forceinline__ void find_entry_exit(Ctx& c, V3 ro, V3 rd, V3* entry, V3* exit_)
 {
+    const DevScene& s = c.sc;
     float dist;
     do {
+        NRC_PROF(c, c.fee_kind);
         dist = sky_sdf(s, ro);
         ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
@@ -93,6 +163,7 @@ __device__ __forceinline__ void find_entry_exit(const DevScene& s, V3 ro, V3 rd,
     ro = madd(rd, s.len2size, ro);
     rd = neg(rd);
     do {
+        NRC_PROF(c, c.fee_kind);
         dist = sky_sdf(s, ro);
         ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
@@ -118,6 +189,32 @@ __device__ __forceinline__ float get_density(Ctx& c, V3 p)
     const uint8_t t = s.density[idx];
     const float d = s.density_factor * ((float)t * (1.0f / 255.0f));
     return inb ? d : 0.0f;
+}
+
+// get_density at start + dir*t1 and start + dir*t2 (second fetch masked unless `second`); returns densities
+__device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, float t2, bool second)
+{
+    const DevScene& s = c.sc;
+    const f2 t = f2{t1, t2};
+    const f2 px = fma2(splat(dir.x), t, splat(start.x));
+    const f2 py = fma2(splat(dir.y), t, splat(start.y));
+    const f2 pz = fma2(splat(dir.z), t, splat(start.z));
+    const f2 u = fma2(px, splat(s.inv_size[0]), splat(0.5f));
+    const f2 v = fma2(py, splat(s.inv_size[1]), splat(0.5f));
+    const f2 w = fma2(pz, splat(s.inv_size[2]), splat(0.5f));
+    const f2 fx = u * splat(s.fnx), fy = v * splat(s.fny), fz = w * splat(s.fnz);
+    // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
+    const bool in0 = max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u;
+    const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
+    uint32_t idx0 = __umul24((uint32_t)fz.x, s.ny) + (uint32_t)fy.x;
+    uint32_t idx1 = __umul24((uint32_t)fz.y, s.ny) + (uint32_t)fy.y;
+    idx0 = idx0 * s.nx + (uint32_t)fx.x;
+    idx1 = idx1 * s.nx + (uint32_t)fx.y;
+    idx0 = in0 ? idx0 : 0x80000000u;
+    idx1 = in1 ? idx1 : 0x80000000u;
+    const uint8_t b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx0, 0, 0);
+    const uint8_t b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx1, 0, 0);
+    return splat(s.density_factor) * (f2{(float)b0, (float)b1} * splat(1.0f / 255.0f));
 }
 
 // ---- include/dir_gen.glsl
@@ -146,6 +243,7 @@ __device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
 
 __device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_sampling)
 {
+    NRC_PROF(c, 4);
     old_dir = normalize(old_dir);
     V3 ortho = old_dir.z < old_dir.x ? v3(old_dir.y, -old_dir.x, 0.0f) : v3(0.0f, -old_dir.z, old_dir.y);
     if (ortho.x == 0.0f && ortho.y == 0.0f && ortho.z == 0.0f) ortho = v3(0.0f, 1.0f, 0.0f);   // robustness
@@ -171,18 +269,35 @@ __device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_samplin
 }
 
 // ---- include/path_trace.glsl
+// RatioTrack, path_trace.glsl:24-43, two collisions per trip: nothing in a step depends on the previous fetch, so both
+// free-flight logs share packed math and both fetches are in flight together; a lane that ends on the first collision
+// keeps the RNG state of that draw, exactly as the one-step loop would
 __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
 {
     V3 d = sub(end, start);
     V3 dir = normalize(d);
-    float t_max = length(d);
+    const float t_max = length(d);
+    const float inv = c.sc.inv_max_density;
     float tr = 1.0f, t = 0.0f;
-    for (uint32_t i = 0; i < 128; i++) {
-        t = nrc_fmaf_(-nrc_logf(1.0f - c.rand(1.0f)), c.sc.inv_max_density, t);
-        if (t >= t_max) break;
-        V3 p = madd(dir, t, start);
-        tr *= nrc_fmaf_(-get_density(c, p), c.sc.inv_max_density, 1.0f);
+    float rng = c.rng;
+    for (uint32_t i = 0; i < 128; i += 2) {
+        NRC_PROF(c, 3);
+        const float s1 = random1(rng), s2 = random1(s1);
+        const f2 l = logf2(f2{1.0f - s1, 1.0f - s2});
+        const float t1 = nrc_fmaf_(-l.x, inv, t);
+        rng = s1;
+        if (t1 >= t_max) break;
+        const float t2 = nrc_fmaf_(-l.y, inv, t1);
+        const bool second = !(t2 >= t_max);
+        const f2 dens = get_density2(c, dir, start, t1, t2, second);
+        c.fetches += second ? 2u : 1u;
+        tr *= nrc_fmaf_(-dens.x, inv, 1.0f);
+        rng = s2;
+        if (!second) break;
+        tr *= nrc_fmaf_(-dens.y, inv, 1.0f);
+        t = t2;
     }
+    c.rng = rng;
     return tr;
 }
 
@@ -192,7 +307,7 @@ __device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir)
     if (s.dir_light_strength == 0.0f) return v3(0, 0, 0);
     V3 ld = v3(s.dir_light_dir[0], s.dir_light_dir[1], s.dir_light_dir[2]);
     V3 en, ex;
-    find_entry_exit(s, pos, neg(normalize(ld)), &en, &ex);
+    find_entry_exit(c, pos, neg(normalize(ld)), &en, &ex);
     float tr = ratio_track(c, pos, ex);
     float phase = hg_phase(s, dot(ld, neg(dir)));
     float l = (1.0f * tr) * s.dir_light_strength * phase;
@@ -250,7 +365,7 @@ __device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir)
     V3 rdir = new_ray_dir(c, dir, false);
     float phase = hg_phase(c.sc, dot(rdir, neg(dir)));
     V3 en, ex;
-    find_entry_exit(c.sc, pos, rdir, &en, &ex);
+    find_entry_exit(c, pos, rdir, &en, &ex);
     float tr = ratio_track(c, pos, ex);
     V3 e = sample_env_dir(c.sc, rdir);
     return v3((e.x * phase) * tr, (e.y * phase) * tr, (e.z * phase) * tr);
@@ -258,28 +373,49 @@ __device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir)
 
 __device__ __forceinline__ V3 trace_scene(Ctx& c, V3 pos, V3 dir)
 {
+    NRC_PROF(c, 5);
     V3 a = trace_dir_light(c, pos, dir);
     V3 b = trace_point_light(c, pos, dir);
     V3 e = sample_env(c, pos, dir);
     return add(add(a, b), e);
 }
 
+// DeltaTrack, path_trace.glsl:150-174, two collisions per trip: the second collision's free flight and fetch are issued
+// speculatively beside the first's (the RNG chain does not depend on the density); whichever event comes first in
+// sequence order -- exit, accept 1, exit, accept 2 -- ends the walk with the RNG state the one-step loop would have
 __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)
 {
     *volume_exit = false;
     V3 en, ex;
-    find_entry_exit(c.sc, ro, rd, &en, &ex);
-    float t_max = length(sub(ex, ro));
+    find_entry_exit(c, ro, rd, &en, &ex);
+    const float t_max = length(sub(ex, ro));
+    const float inv = c.sc.inv_max_density;
     float t = 0.0f;
-    for (uint32_t i = 0; i < 128; i++) {
-        t = nrc_fmaf_(-nrc_logf(1.0f - c.rand(1.0f)), c.sc.inv_max_density, t);
-        if (t >= t_max) {
-            *volume_exit = true;
-            break;
-        }
-        V3 p = madd(rd, t, ro);
-        if (get_density(c, p) * c.sc.inv_max_density > c.rand(1.0f)) return p;
+    float rng = c.rng;
+    bool hit = false;
+    float t_hit = 0.0f;
+    for (uint32_t i = 0; i < 128; i += 2) {
+        NRC_PROF(c, 2);
+        const float s1 = random1(rng), a1 = random1(s1), s2 = random1(a1), a2 = random1(s2);
+        const f2 l = logf2(f2{1.0f - s1, 1.0f - s2});
+        const float t1 = nrc_fmaf_(-l.x, inv, t);
+        rng = s1;
+        if (t1 >= t_max) { *volume_exit = true; break; }
+        const float t2 = nrc_fmaf_(-l.y, inv, t1);
+        const bool second = !(t2 >= t_max);
+        const f2 dens = get_density2(c, rd, ro, t1, t2, second) * splat(inv);
+        c.fetches++;
+        rng = a1;
+        if (dens.x > a1) { hit = true; t_hit = t1; break; }
+        rng = s2;
+        if (!second) { *volume_exit = true; break; }
+        c.fetches++;
+        rng = a2;
+        if (dens.y > a2) { hit = true; t_hit = t2; break; }
+        t = t2;
     }
+    c.rng = rng;
+    if (hit) return madd(rd, t_hit, ro);
     return madd(rd, c.rand(t_max), ro);
 }
 
@@ -345,7 +481,14 @@ __global__ __launch_bounds__(256) void k_gen_rays(DevScene sc, DevCamera cam, De
         camera_ray(cam, u, v, &ro, &rd);
         init_random(c, u, v, fr.random);
         V3 entry, ex;
-        find_entry_exit(sc, ro, rd, &entry, &ex);
+#ifdef NRC_LOOP_PROFILE
+        c.fee_kind = 0;
+        NRC_PROF(c, 6);
+#endif
+        find_entry_exit(c, ro, rd, &entry, &ex);
+#ifdef NRC_LOOP_PROFILE
+        c.fee_kind = 1;
+#endif
         const size_t pix = (size_t)y * fr.w + lx;
         V3 col;
         float thr = 1.0f;
@@ -389,6 +532,9 @@ __global__ __launch_bounds__(256) void k_gen_rays(DevScene sc, DevCamera cam, De
         for (int k = 0; k < 5; k++) qo[k] = q[k];
     }
     count_fetches(fetch_counter, c.fetches);
+#ifdef NRC_LOOP_PROFILE
+    for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ mc/render.comp
@@ -406,7 +552,7 @@ __global__ __launch_bounds__(256) void k_mc_render(DevScene sc, DevCamera cam, D
         camera_ray(cam, u, v, &ro, &rd);
         init_random(c, u, v, fr.random);
         V3 entry, ex;
-        find_entry_exit(sc, ro, rd, &entry, &ex);
+        find_entry_exit(c, ro, rd, &entry, &ex);
         V3 col;
         bool did_scatter = false;
         if (sky_sdf(sc, entry) > 100000.0f) {
@@ -534,7 +680,7 @@ __global__ __launch_bounds__(256) void k_paths(DevScene sc, DevCamera cam, DevFr
                         camera_ray(cam, u, v, &ro, &rd_cam);
                         init_random(c, u, v, fr.random);
                         V3 entry, ex;
-                        find_entry_exit(sc, ro, rd_cam, &entry, &ex);
+                        find_entry_exit(c, ro, rd_cam, &entry, &ex);
                         light = v3(0, 0, 0);
                         factor = 1.0f;
                         vi = 0;
@@ -618,7 +764,7 @@ __global__ __launch_bounds__(256) void k_paths(DevScene sc, DevCamera cam, DevFr
             else if (next == NX_RENV) { need_fee = true; fee_o = cur; fee_d = env_rdir; }
             if (need_fee) {
                 V3 en, ex;
-                find_entry_exit(sc, fee_o, fee_d, &en, &ex);
+                find_entry_exit(c, fee_o, fee_d, &en, &ex);
                 // ---- (d) set up the next track
                 if (next == NX_DELTA) {            // DeltaTrack: unnormalised path direction, tMax = |exit - origin|
                     S = cur; D = dir;
@@ -788,7 +934,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     for (uint32_t s = 0; s < tg.spp; s++) {
         V3 light = v3(0, 0, 0);
         V3 en, ex;
-        find_entry_exit(sc, ro, rdir, &en, &ex);
+        find_entry_exit(c, ro, rdir, &en, &ex);
         V3 cur = en, dir = rdir;
         float factor = 1.0f;
         bool vexit = false;
@@ -953,6 +1099,8 @@ __global__ void k_test_math(int fn, const float* __restrict__ a, const float* __
     case 6: s = a[i] / b[i]; break;
     case 7: s = sqrtf(a[i]); break;
     case 8: s = (float)(_Float16)a[i]; break;
+    case 9: { const f2 r = logf2(f2{a[i], b[i]}); s = r.x; c = r.y; break; }
+    case 10: s = sqrt_rn_normal(a[i]); break;
     default: break;
     }
     out[i] = s;
@@ -1071,3 +1219,17 @@ void launch_test_rng(float u, float v, const float* fr, uint32_t n, float* out, 
 }
 
 }  // namespace nrc
+
+#ifdef NRC_LOOP_PROFILE
+// profiling build only (tools/loop_profile.py): read / reset the loop counters
+extern "C" int nrc_debug_loop_profile(unsigned long long* out16, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(nrc::g_loop_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nrc::g_loop_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -50,6 +50,23 @@ def test_binary_math_bit_exact(orc, api, torch_gpu, fn):
     assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
 
 
+def test_packed_log_matches_scalar_spec(orc, api, torch_gpu):
+    """the tracking loops evaluate two free-flight logs per trip with packed fp32 math: same bits as the scalar spec"""
+    a, b = _inputs("log", seed=3), _inputs("log", seed=4)[::-1].copy()
+    out, out2 = api.test_math(9, torch_gpu.from_numpy(a).cuda(), torch_gpu.from_numpy(b).cuda())
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(orc.math_eval(0, a)[0]))
+    assert np.array_equal(_bits(out2.cpu().numpy()), _bits(orc.math_eval(0, b)[0]))
+
+
+def test_box_sdf_sqrt_is_correctly_rounded(orc, api, torch_gpu):
+    """sky_sdf's lean sqrt (v_sqrt_f32 + one-ulp fix-up, no denormal path) == the oracle's sqrtf on zero and normal inputs"""
+    rng = np.random.default_rng(5)
+    a = np.concatenate([np.exp(rng.uniform(-60, 60, 400000)).astype(np.float32), rng.random(200000, dtype=np.float32) * 1e4,
+                        np.array([0.0, 1.0, 4.0, 2.0, 1e-30, 3e38, 0.015625, 1.0000001, 0.99999994], np.float32)])
+    out, _ = api.test_math(10, torch_gpu.from_numpy(a).cuda())
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(orc.math_eval(7, a)[0]))
+
+
 def test_math_spec_accuracy(orc):
     """the spec itself is a faithful log/sin/cos/acos/atan2 (GLSL precision requirements are far looser)"""
     a = _inputs("log")
