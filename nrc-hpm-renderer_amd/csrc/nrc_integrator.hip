@@ -111,6 +111,10 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
 // ("useful") and 64 x iterations issued by the wave ("issued"); never defined in the product build
 #ifdef NRC_LOOP_PROFILE
 __device__ unsigned long long g_loop_prof[16];
+__device__ unsigned long long g_wave_times[4 * 65536];
+#endif
+// -DNRC_NO_LOOP_COUNTERS keeps only the per-wave time stamps (the counters slow the kernel several-fold)
+#if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
 #define NRC_PROF(c, k)                                                                    \
     do {                                                                                  \
         (c).useful[k]++;                                                                  \
@@ -150,13 +154,27 @@ __device__ __forceinline__ float sky_sdf(const DevScene& s, V3 p)
     return sqrt_rn_normal(dot(dm, dm)) + fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f);
 }
 
+// sky_sdf inside the sphere-trace loops.  When at most one of the three per-axis distances is positive (the point is inside
+// the box or in front of one face: med3 <= 0) the box distance is max3 itself -- length((0,0,x)) = sqrt(fl(x*x)) = x under
+// correct rounding, and 0 + min(max3,0) = max3 -- so the square root is skipped whenever every active lane of the wave is
+// in that case (4 of 5 iterations on the bench view); "+ 0.0f" keeps the -0 -> +0 of the general formula.
+__device__ __forceinline__ float sky_sdf_step(const DevScene& s, V3 p)
+{
+    const float dx = fabsf(p.x) - s.half_size[0], dy = fabsf(p.y) - s.half_size[1], dz = fabsf(p.z) - s.half_size[2];
+    const float m3 = fmaxf(dx, fmaxf(dy, dz));
+    const bool general = !(__builtin_amdgcn_fmed3f(dx, dy, dz) <= 0.0f);
+    if (__ballot(general) == 0ull) return m3 + 0.0f;
+    const V3 dm = v3(fmaxf(dx, 0.0f), fmaxf(dy, 0.0f), fmaxf(dz, 0.0f));
+    return sqrt_rn_normal(dot(dm, dm)) + fminf(m3, 0.0f);
+}
+
 __device__ __forceinline__ void find_entry_exit(Ctx& c, V3 ro, V3 rd, V3* entry, V3* exit_)
 {
     const DevScene& s = c.sc;
     float dist;
     do {
         NRC_PROF(c, c.fee_kind);
-        dist = sky_sdf(s, ro);
+        dist = sky_sdf_step(s, ro);
         ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
     *entry = ro;
@@ -164,7 +182,7 @@ __device__ __forceinline__ void find_entry_exit(Ctx& c, V3 ro, V3 rd, V3* entry,
     rd = neg(rd);
     do {
         NRC_PROF(c, c.fee_kind);
-        dist = sky_sdf(s, ro);
+        dist = sky_sdf_step(s, ro);
         ro = madd(rd, dist, ro);
     } while (dist > 0.125f && dist < 100000.0f);
     *exit_ = ro;
@@ -455,6 +473,24 @@ __device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx
     return *lx < fr.w && *y < fr.h;
 }
 
+// Camera kernels: each wave renders one 8x8 pixel tile (coherent paths inside a wave), four tiles of a row per workgroup.
+// Tile rows are issued centre-out, so the expensive middle of the image starts first and the cheap rim fills the tail of the
+// launch.  (Measured and rejected, tools/loop_profile.py: one-wave workgroups and a costliest-first order from per-tile clock
+// counts of earlier frames -- the launch already sits at its residency plateau; both only starve the concurrent streams.)
+constexpr uint32_t CAMERA_WAVES_PER_BLOCK = 4;
+__device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
+    const uint32_t slot = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (slot >= tiles_x * tiles_y) return false;
+    const uint32_t k = slot / tiles_x, mid = tiles_y >> 1;
+    const uint32_t ty = (k & 1u) ? mid - ((k + 1u) >> 1) : mid + (k >> 1);      // mid, mid-1, mid+1, ...: a bijection
+    *lx = (slot - k * tiles_x) * 8u + (lane & 7u);
+    *y = ty * 8u + (lane >> 3);
+    return *lx < fr.w && *y < fr.h;
+}
+
 __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint32_t n)
 {
     if (counter == nullptr) return;
@@ -465,14 +501,25 @@ __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint3
 }
 
 // ------------------------------------------------------------------------------------------------ nrc/gen_rays.comp + prep_infer_rays.comp
-__global__ __launch_bounds__(256) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
+__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
                                                  float primary_ray_prob, float4* __restrict__ primary,
                                                  float* __restrict__ info, float4* __restrict__ origin,
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
                                                  unsigned long long* fetch_counter)
 {
     uint32_t lx, y;
-    const bool inside = pixel_of_thread(fr, &lx, &y);
+    const bool inside = pixel_of_wave_tile(fr, &lx, &y);
+#ifdef NRC_LOOP_PROFILE
+    const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_wave_times[4 * wave_id] = wall_clock64();
+        g_wave_times[4 * wave_id + 2] = xcc;
+        g_wave_times[4 * wave_id + 3] = hw;
+    }
+#endif
     Ctx c{sc, 0.0f, 0u};
     if (inside) {
         const uint32_t gx = fr.x_offset + lx * fr.x_stride;
@@ -532,18 +579,21 @@ __global__ __launch_bounds__(256) void k_gen_rays(DevScene sc, DevCamera cam, De
         for (int k = 0; k < 5; k++) qo[k] = q[k];
     }
     count_fetches(fetch_counter, c.fetches);
-#ifdef NRC_LOOP_PROFILE
+#if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
     for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
+#endif
+#ifdef NRC_LOOP_PROFILE
+    if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) g_wave_times[4 * wave_id + 1] = wall_clock64();
 #endif
 }
 
 // ------------------------------------------------------------------------------------------------ mc/render.comp
-__global__ __launch_bounds__(256) void k_mc_render(DevScene sc, DevCamera cam, DevFrame fr, uint32_t path_length,
+__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_mc_render(DevScene sc, DevCamera cam, DevFrame fr, uint32_t path_length,
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
 {
     uint32_t lx, y;
-    const bool inside = pixel_of_thread(fr, &lx, &y);
+    const bool inside = pixel_of_wave_tile(fr, &lx, &y);
     Ctx c{sc, 0.0f, 0u};
     if (inside) {
         const uint32_t gx = fr.x_offset + lx * fr.x_stride;
@@ -580,267 +630,6 @@ __global__ __launch_bounds__(256) void k_mc_render(DevScene sc, DevCamera cam, D
         out_rgba[pix] = make_float4(blend_factor * col.x + ib * prev.x, blend_factor * col.y + ib * prev.y,
                                     blend_factor * col.z + ib * prev.z, blend_factor * a + ib * prev.w);
         if (info) info[pix] = a;
-    }
-    count_fetches(fetch_counter, c.fetches);
-}
-
-// ------------------------------------------------------------------------------------------------ path engine
-// Per-lane state machine over the same per-pixel operation sequence as k_gen_rays / k_mc_render (identical arithmetic and
-// RNG draw order, hence identical results), restructured for wave64 utilisation:
-//   * every tracking loop of the shaders (DeltaTrack, the RatioTrack of each light) becomes the SAME one-step body, so lanes
-//     that are in different tracks -- or at different vertices -- still execute together;
-//   * the work between two tracks (finish a track, accumulate a light, NewRayDir, find_entry_exit, set up the next track)
-//     is served for many lanes at once: a service round runs when >= SERVICE_MIN lanes wait (or nobody can step);
-//   * a lane whose path is complete stores its pixel and takes the next pixel of the wave's range (persistent lanes), so
-//     cheap pixels (empty sky) do not leave lanes idle while expensive neighbours finish.
-enum : int { ST_DELTA = 0, ST_RDIR = 1, ST_RPOINT = 2, ST_RENV = 3, ST_IDLE = 4 };
-enum : int { NX_NONE = 0, NX_RDIR, NX_RPOINT, NX_RENV, NX_AFTER, NX_DELTA, NX_DONE };
-constexpr int PATH_MODE_NRC = 0, PATH_MODE_MC = 1;
-constexpr uint32_t ENGINE_SLOTS_PER_WAVE = 128;      // 2 tiles of 8x8 pixels per wave
-constexpr int SERVICE_MIN = 64;
-
-struct EngineOut {
-    float4* primary;       // NRC: colour + throughput | MC: framebuffer (blend)
-    float* info;
-    float4* origin;
-    float4* dirs;
-    float* infer_in;
-    float blend_factor;    // MC
-    uint32_t limit;        // NRC: PRIMARY_RAY_LENGTH | MC: PATH_LENGTH
-    float prob;            // NRC: PRIMARY_RAY_PROB
-};
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_paths(DevScene sc, DevCamera cam, DevFrame fr, EngineOut o,
-                                              unsigned long long* fetch_counter, int service_num)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
-    const uint32_t total_slots = tiles_x * tiles_y * 64u;
-    uint32_t next_slot = wave_global * ENGINE_SLOTS_PER_WAVE;                 // wave-uniform
-    const uint32_t end_slot = min(next_slot + ENGINE_SLOTS_PER_WAVE, total_slots);
-
-    Ctx c{sc, 0.0f, 0u};
-    // ---- per-lane path state
-    int stage = ST_IDLE;
-    uint32_t lx = 0, y = 0;
-    V3 rd_cam = v3(0, 0, 0);
-    V3 cur = v3(0, 0, 0), dir = v3(0, 0, 0), light = v3(0, 0, 0);
-    float factor = 1.0f;
-    int vi = 0;
-    bool did_scatter = false;
-    float la = 0.0f;                       // dir-light term (equal components)
-    V3 lb = v3(0, 0, 0);                   // point-light term
-    V3 env_rdir = v3(0, 0, 0);
-    float env_phase = 0.0f;
-    // ---- current track
-    V3 S = v3(0, 0, 0), D = v3(0, 0, 0), P = v3(0, 0, 0);
-    float t = 0.0f, tmax = 0.0f, tr = 1.0f;
-    uint32_t iter = 0;
-    bool trk_done = false, hit = false, exitf = false;
-
-    const bool has_dir = sc.dir_light_strength != 0.0f, has_point = sc.point_light_strength != 0.0f,
-               has_env = sc.env_strength != 0.0f;
-    const V3 ld = v3(sc.dir_light_dir[0], sc.dir_light_dir[1], sc.dir_light_dir[2]);
-    const V3 lp = v3(sc.point_light_pos[0], sc.point_light_pos[1], sc.point_light_pos[2]);
-
-    for (;;) {
-        const bool idle = stage == ST_IDLE;
-        const unsigned long long idle_m = __ballot(idle);
-        const unsigned long long wait_m = __ballot(!idle && trk_done);
-        const unsigned long long act_m = __ballot(!idle && !trk_done);
-        const bool work_left = next_slot < end_slot;
-        const int n_need = __popcll(wait_m) + (work_left ? __popcll(idle_m) : 0);
-        if (n_need == 0 && act_m == 0ull) break;
-
-        // serve when a quarter of the lanes that still have something to do are waiting (at most SERVICE_MIN)
-        const int n_busy = __popcll(act_m) + n_need;
-        static_assert(SERVICE_MIN >= 1, "");
-        const int thresh = max(1, min(SERVICE_MIN, (n_busy * service_num) >> 3));
-        if (n_need > 0 && (n_need >= thresh || act_m == 0ull)) {
-            // ================================================================ service round
-            int next = NX_NONE;
-            bool need_fee = false;
-            V3 fee_o = v3(0, 0, 0), fee_d = v3(1, 0, 0);
-            bool path_done = false, miss = false;
-
-            // ---- (0) persistent lanes: take the next pixels of this wave's range
-            if (work_left) {
-                const uint32_t rank = __popcll(idle_m & ((1ull << lane) - 1ull));
-                const uint32_t slot = next_slot + rank;
-                if (idle && slot < end_slot) {
-                    const uint32_t tile = slot >> 6, within = slot & 63u;
-                    lx = (tile % tiles_x) * 8u + (within & 7u);
-                    y = (tile / tiles_x) * 8u + (within >> 3);
-                    if (lx < fr.w && y < fr.h) {
-                        const uint32_t gx = fr.x_offset + lx * fr.x_stride;
-                        const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
-                        V3 ro;
-                        camera_ray(cam, u, v, &ro, &rd_cam);
-                        init_random(c, u, v, fr.random);
-                        V3 entry, ex;
-                        find_entry_exit(c, ro, rd_cam, &entry, &ex);
-                        light = v3(0, 0, 0);
-                        factor = 1.0f;
-                        vi = 0;
-                        did_scatter = false;
-                        if (sky_sdf(sc, entry) > 100000.0f) {
-                            miss = true;
-                            path_done = true;
-                        } else {
-                            cur = entry;
-                            dir = rd_cam;
-                            next = NX_DELTA;
-                        }
-                        stage = ST_DELTA;      // owns a pixel now (track set up below, or finished right away)
-                        trk_done = true;
-                    }
-                }
-                next_slot = min(next_slot + (uint32_t)__popcll(idle_m), end_slot);
-            }
-
-            // ---- (a) finish the track that just ended
-            if (!idle && trk_done && next == NX_NONE && !path_done) {
-                V3 le = v3(0, 0, 0);
-                if (stage == ST_DELTA) {
-                    if (!hit) P = madd(D, c.rand(tmax), S);        // path_trace.glsl:173 (also after 128 null collisions)
-                    cur = P;
-                    if (exitf) {
-                        path_done = true;
-                        next = NX_DONE;
-                    } else {
-                        did_scatter = true;
-                        factor *= 0.5f;
-                        la = 0.0f;
-                        lb = v3(0, 0, 0);
-                        next = has_dir ? NX_RDIR : (has_point ? NX_RPOINT : (has_env ? NX_RENV : NX_AFTER));
-                    }
-                } else if (stage == ST_RDIR) {
-                    const float phase = hg_phase(sc, dot(ld, neg(dir)));
-                    la = (1.0f * tr) * sc.dir_light_strength * phase;
-                    next = has_point ? NX_RPOINT : (has_env ? NX_RENV : NX_AFTER);
-                } else if (stage == ST_RPOINT) {
-                    const float phase = hg_phase(sc, dot(normalize(sub(lp, cur)), neg(dir)));
-                    lb = v3(((sc.point_light_color[0] * sc.point_light_strength) * tr) * phase,
-                            ((sc.point_light_color[1] * sc.point_light_strength) * tr) * phase,
-                            ((sc.point_light_color[2] * sc.point_light_strength) * tr) * phase);
-                    next = has_env ? NX_RENV : NX_AFTER;
-                } else {   // ST_RENV
-                    const V3 e = sample_env_dir(sc, env_rdir);
-                    le = v3((e.x * env_phase) * tr, (e.y * env_phase) * tr, (e.z * env_phase) * tr);
-                    next = NX_AFTER;
-                }
-                if (next == NX_AFTER) {            // TraceScene = dir + point + env, then * factor (gen_rays.comp:32-33)
-                    const V3 tot = add(add(v3(la, la, la), lb), le);
-                    light = add(light, mul(tot, factor));
-                }
-            }
-
-            // ---- (b) NewRayDir, shared: phase-function sampling after a vertex, uniform angle for the env estimator
-            if (next == NX_AFTER || next == NX_RENV) {
-                const V3 nd = new_ray_dir(c, dir, next == NX_AFTER);
-                if (next == NX_AFTER) {
-                    dir = nd;
-                    if (MODE == PATH_MODE_NRC) {          // gen_rays.comp:39-42
-                        if ((uint32_t)vi >= o.limit) {
-                            if (c.rand(1.0f) >= o.prob || vi == 128) path_done = true;
-                        }
-                        vi++;
-                    } else {                              // mc/render.comp:23
-                        vi++;
-                        if ((uint32_t)vi >= o.limit) path_done = true;
-                    }
-                    next = path_done ? NX_DONE : NX_DELTA;
-                } else {
-                    env_rdir = nd;
-                    env_phase = hg_phase(sc, dot(nd, neg(dir)));
-                }
-            }
-
-            // ---- (c) find_entry_exit, shared by every track that needs the volume exit
-            if (next == NX_DELTA) { need_fee = true; fee_o = cur; fee_d = dir; }
-            else if (next == NX_RDIR) { need_fee = true; fee_o = cur; fee_d = neg(normalize(ld)); }
-            else if (next == NX_RENV) { need_fee = true; fee_o = cur; fee_d = env_rdir; }
-            if (need_fee) {
-                V3 en, ex;
-                find_entry_exit(c, fee_o, fee_d, &en, &ex);
-                // ---- (d) set up the next track
-                if (next == NX_DELTA) {            // DeltaTrack: unnormalised path direction, tMax = |exit - origin|
-                    S = cur; D = dir;
-                    tmax = length(sub(ex, cur));
-                    stage = ST_DELTA;
-                } else {                           // RatioTrack(pos, exit)
-                    const V3 d = sub(ex, cur);
-                    S = cur; D = normalize(d);
-                    tmax = length(d);
-                    stage = next == NX_RDIR ? ST_RDIR : ST_RENV;
-                }
-                t = 0.0f; tr = 1.0f; iter = 0; trk_done = false; hit = false; exitf = false;
-            } else if (next == NX_RPOINT) {        // RatioTrack(pointLight.pos, pos)
-                const V3 d = sub(cur, lp);
-                S = lp; D = normalize(d);
-                tmax = length(d);
-                stage = ST_RPOINT;
-                t = 0.0f; tr = 1.0f; iter = 0; trk_done = false; hit = false; exitf = false;
-            }
-
-            // ---- (e) completed paths: store the pixel, lane becomes idle
-            if (path_done) {
-                const size_t pix = (size_t)y * fr.w + lx;
-                V3 col = light;
-                float thr = factor;
-                if (!did_scatter) {
-                    col = sample_env_dir(sc, rd_cam);
-                    thr = 1.0f;
-                }
-                if (MODE == PATH_MODE_NRC) {
-                    float q[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                    if (!miss) {
-                        o.origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
-                        o.dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-                        if (did_scatter) nrc_query(sc, cur, dir, q);
-                    }
-                    o.primary[pix] = make_float4(col.x, col.y, col.z, thr);
-                    o.info[pix] = did_scatter ? 1.0f : 0.0f;
-                    float* qo = o.infer_in + ((size_t)lx * fr.h + y) * 5u;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) qo[k] = q[k];
-                } else {
-                    const float a = did_scatter ? 1.0f : 0.0f;
-                    const float4 prev = o.primary[pix];
-                    const float bf = o.blend_factor, ib = 1.0f - bf;
-                    o.primary[pix] = make_float4(bf * col.x + ib * prev.x, bf * col.y + ib * prev.y,
-                                                 bf * col.z + ib * prev.z, bf * a + ib * prev.w);
-                    if (o.info) o.info[pix] = a;
-                }
-                stage = ST_IDLE;
-                trk_done = false;
-            }
-            continue;
-        }
-
-        // ================================================================ one tracking step for every lane that has a live track
-        if (!idle && !trk_done) {
-            t = nrc_fmaf_(-nrc_logf(1.0f - c.rand(1.0f)), sc.inv_max_density, t);
-            if (t >= tmax) {
-                exitf = true;
-                trk_done = true;
-            } else {
-                const V3 p = madd(D, t, S);
-                const float dens = get_density(c, p);
-                if (stage == ST_DELTA) {
-                    if (dens * sc.inv_max_density > c.rand(1.0f)) {
-                        hit = true;
-                        P = p;
-                        trk_done = true;
-                    }
-                } else {
-                    tr *= nrc_fmaf_(-dens, sc.inv_max_density, 1.0f);
-                }
-                if (++iter == 128u) trk_done = true;
-            }
-        }
     }
     count_fetches(fetch_counter, c.fetches);
 }
@@ -1123,51 +912,24 @@ __global__ void k_test_rng(float u, float v, float r0, float r1, float r2, float
 
 // ================================================================================================ launchers
 static dim3 pixel_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(w, 16), ceil_div(h, 16)); }
-
-// The per-lane state-machine engine (k_paths) is bit-identical to the straightforward kernels but measured 2.3x SLOWER on
-// MI355X (a mixed service round executes every transition branch, ~4x the transition instructions of
-// the lock-step kernels, which outweighs the utilisation gained in the tracking loops).  It stays selectable for
-// experiments (NRC_INTEGRATOR=engine); the lock-step kernels are the product path.
-static bool use_simple_integrator()
-{
-    static const bool simple = [] { const char* e = getenv("NRC_INTEGRATOR"); return !(e && std::string(e) == "engine"); }();
-    return simple;
-}
-static int service_eighths()
-{
-    static const int v = [] { const char* e = getenv("NRC_ENGINE_SERVICE"); return e ? atoi(e) : 6; }();
-    return v;
-}
-static uint32_t engine_blocks(const DevFrame& fr)
-{
-    const uint32_t slots = ceil_div(fr.w, 8) * ceil_div(fr.h, 8) * 64u;
-    return ceil_div(ceil_div(slots, ENGINE_SLOTS_PER_WAVE), 4);
-}
+// k_gen_rays / k_mc_render: one 8x8 pixel tile per wave, see pixel_of_wave_tile
+static dim3 wave_tile_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(ceil_div(w, 8) * ceil_div(h, 8), CAMERA_WAVES_PER_BLOCK)); }
 
 void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
                      unsigned long long* fetch_counter, hipStream_t s)
 {
-    if (use_simple_integrator()) {
-        hipLaunchKernelGGL(k_gen_rays, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, primary_ray_length,
-                           primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in, fetch_counter);
-    } else {
-        EngineOut o{(float4*)primary, info, (float4*)origin, (float4*)dir, infer_in, 1.0f, primary_ray_length, primary_ray_prob};
-        hipLaunchKernelGGL(k_paths<PATH_MODE_NRC>, dim3(engine_blocks(fr)), dim3(256), 0, s, sc, cam, fr, o, fetch_counter, service_eighths());
-    }
+    hipLaunchKernelGGL(k_gen_rays, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
+                       primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
+                       fetch_counter);
     NRC_HIP(hipGetLastError());
 }
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s)
 {
-    if (use_simple_integrator() || path_length == 0) {
-        hipLaunchKernelGGL(k_mc_render, pixel_grid(fr.w, fr.h), dim3(256), 0, s, sc, cam, fr, path_length, blend_factor,
-                           (float4*)out_rgba, info, fetch_counter);
-    } else {
-        EngineOut o{(float4*)out_rgba, info, nullptr, nullptr, nullptr, blend_factor, path_length, 0.0f};
-        hipLaunchKernelGGL(k_paths<PATH_MODE_MC>, dim3(engine_blocks(fr)), dim3(256), 0, s, sc, cam, fr, o, fetch_counter, service_eighths());
-    }
+    hipLaunchKernelGGL(k_mc_render, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
+                       path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
     NRC_HIP(hipGetLastError());
 }
 
@@ -1222,6 +984,12 @@ void launch_test_rng(float u, float v, const float* fr, uint32_t n, float* out, 
 
 #ifdef NRC_LOOP_PROFILE
 // profiling build only (tools/loop_profile.py): read / reset the loop counters
+extern "C" int nrc_debug_wave_times(unsigned long long* out, unsigned n_waves)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nrc::g_wave_times), (size_t)n_waves * 32) == hipSuccess ? 0 : 1;
+}
+
 extern "C" int nrc_debug_loop_profile(unsigned long long* out16, int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

@@ -11,11 +11,11 @@ for d in sys.argv[1:]:
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0][-60:]
+        name = row["Kernel_Name"].replace("void ", "").replace("nrc::(anonymous namespace)::", "").split("(")[0][:60]
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
     n = max(len(v) for v in cs.values())
-    if not any(x in k for x in ("nrc", "k_")):
+    if not k.startswith("k_"):
         continue
     print("%s  (dispatches %d)" % (k, n))
     for c, v in sorted(cs.items()):
