@@ -108,7 +108,8 @@ public:
     }
 
     // Train, :147-156, on stream `st` (backward, gradient hook, optimizer).  When `st` is not the stream inference runs on,
-    // the optimizer additionally waits for ev_infer_done: it rewrites the fp16 weight image inference reads.
+    // the optimizer additionally waits for ev_infer_done -- the inference pass BEFORE the latest one: the fp16 inference image
+    // is double-buffered (Mlp::repack) and the optimizer overwrites the set that pass read.
     void train_all(hipStream_t st, hipEvent_t ev_infer_done)
     {
         if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
@@ -306,9 +307,9 @@ public:
         tg_.ray_length = (cfg.compat_fix & NRC_FIX_Q2_TRAIN_RAY_LEN) ? cfg.train_ray_length : 1u;
         tg_.ring_size = (uint32_t)(cfg.train_ring_buf_size * (float)(tg_.tw * tg_.th));   // :253
         const size_t px = (size_t)w * h, T = (size_t)tg_.tw * tg_.th;
-        // everything gen_rays writes is double-buffered: frame N's train-ray generation (stream B), inference and compositing
-        // (stream C) read set N&1 while frame N+1's gen_rays (stream A) already writes the other set
-        for (int k = 0; k < 2; k++) {
+        // everything gen_rays writes exists kGenSets times: frame N's train-ray generation (stream D), inference and
+        // compositing (stream C) read set N % kGenSets while gen_rays (stream A) is already one or two frames ahead
+        for (int k = 0; k < kGenSets; k++) {
             alloc(&d_primary2_[k], px * 16); alloc(&d_info2_[k], px * 4); alloc(&d_origin2_[k], px * 16);
             alloc(&d_dir2_[k], px * 16); alloc(&d_infer_in2_[k], px * 20);
         }
@@ -317,7 +318,11 @@ public:
         for (auto& e : ev_train_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : ev_comp_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         alloc(&d_out_, px * 16); alloc(&d_infer_out_, px * 12);
-        alloc(&d_train_in_, T * 20); alloc(&d_train_target_, T * 12);
+        // train rays are double-buffered as well: frame N+1's train-ray generation (stream D) overlaps frame N's backward pass
+        for (int k = 0; k < 2; k++) { alloc(&d_train_in2_[k], T * 20); alloc(&d_train_target2_[k], T * 12); }
+        d_train_in_ = d_train_in2_[0]; d_train_target_ = d_train_target2_[0];
+        for (auto& e : ev_prep_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : ev_infer_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ring_entries_ = std::max<size_t>(T, tg_.ring_size);
         alloc(&d_ring_, 8 + ring_entries_ * 24);
         alloc(&d_scratch_, (2 * T + 4) * 4);
@@ -331,7 +336,11 @@ public:
             NRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
             NRC_HIP(hipStreamCreateWithPriority(&stream_b_, hipStreamNonBlocking, hi));
             // third stream: inference + compositing of frame N run beside gen_rays of frame N+1 (MFMA beside VALU work)
-            if (!getenv("NRC_TWO_STREAMS")) NRC_HIP(hipStreamCreateWithPriority(&stream_c_, hipStreamNonBlocking, hi));
+            // fourth stream: train-ray generation, so that the training stream carries only backward + optimizer
+            if (!getenv("NRC_TWO_STREAMS")) {
+                NRC_HIP(hipStreamCreateWithPriority(&stream_c_, hipStreamNonBlocking, hi));
+                NRC_HIP(hipStreamCreateWithPriority(&stream_d_, hipStreamNonBlocking, hi));
+            }
         }
         // CreateNrcTrainRingBuffer: head = tail = 0, pos = 0, dir = (0,0,1)  (:866-875)
         std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
@@ -348,6 +357,9 @@ public:
             for (auto& e : set) if (e) (void)hipEventDestroy(e);
         if (stream_b_) (void)hipStreamDestroy(stream_b_);
         if (stream_c_) (void)hipStreamDestroy(stream_c_);
+        if (stream_d_) (void)hipStreamDestroy(stream_d_);
+        for (auto& e : ev_prep_done_) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_infer_done_) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_train_done_) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_comp_done_) if (e) (void)hipEventDestroy(e);
     }
@@ -368,32 +380,40 @@ public:
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
         if (blend_) blend_index_++;
-        // Frame graph on three streams, pipelined across frames (no host sync anywhere):
-        //   A: [wait composite(N-2), train(N-2)] gen_rays(N)
+        // Frame graph on four streams, pipelined across frames (no host sync anywhere):
+        //   A: [wait composite(N-3), train rays(N-3)] gen_rays(N)
+        //   D: [wait gen_rays(N), train(N-2)] train-ray generation(N)
+        //   B: [wait train rays(N)] backward(N) -> (all-reduce) -> [wait inference(N)] optimizer(N)
         //   C: [wait gen_rays(N), train(N-1)] inference(N) -> composite(N)
-        //   B: [wait gen_rays(N)] train-ray generation(N) -> backward(N) -> (all-reduce) -> [wait inference(N)] optimizer(N)
-        // so frame N's training and inference overlap frame N+1's gen_rays (the MFMA kernel runs beside the VALU-bound
-        // integrator); inference(N+1) still sees the weights after frame N's training (quirk Q13 ordering).
-        // events: 0 frame start, 1 gen_rays done, 2 prep_train done (B), 3 inference done, 4 composite done, 5 training done (B)
+        // so frame N's train rays, training and inference all overlap frame N+1's gen_rays (the MFMA kernels and the short
+        // latency-bound kernels run beside the VALU-bound integrator); inference(N+1) still sees the weights after frame N's
+        // training (quirk Q13 ordering).  gen_rays' outputs are triple-buffered (the chain gen_rays -> train rays -> training
+        // -> next frame's inference -> compositing spans almost three frames), the train rays double-buffered.
+        // events: 0 frame start, 1 gen_rays done, 2 train rays done (D), 3 inference done, 4 composite done, 5 training done (B)
         hipStream_t A = stream_, B = stream_b_ ? stream_b_ : stream_, Cs = stream_c_ ? stream_c_ : stream_;
-        const int pp = (int)(frame_index_ & 1u);
-        d_primary_ = d_primary2_[pp]; d_info_ = d_info2_[pp]; d_origin_ = d_origin2_[pp]; d_dir_ = d_dir2_[pp];
-        d_infer_in_ = d_infer_in2_[pp];
-        if (frame_index_ >= 2) {      // buffer set pp was last read by frame N-2
-            if (Cs != A) NRC_HIP(hipStreamWaitEvent(A, ev_comp_done_[pp], 0));
-            if (B != A) NRC_HIP(hipStreamWaitEvent(A, ev_train_done_[pp], 0));
+        hipStream_t D = stream_d_ ? stream_d_ : B;
+        const int pp = (int)(frame_index_ & 1u);                  // train-ray set, training / inference events
+        const int gp = (int)(frame_index_ % (uint64_t)kGenSets);  // gen_rays output set
+        d_primary_ = d_primary2_[gp]; d_info_ = d_info2_[gp]; d_origin_ = d_origin2_[gp]; d_dir_ = d_dir2_[gp];
+        d_infer_in_ = d_infer_in2_[gp]; d_train_in_ = d_train_in2_[pp]; d_train_target_ = d_train_target2_[pp];
+        if (frame_index_ >= (uint64_t)kGenSets) {      // set gp was last read by frame N - kGenSets
+            if (Cs != A) NRC_HIP(hipStreamWaitEvent(A, ev_comp_done_[gp], 0));
+            if (D != A) NRC_HIP(hipStreamWaitEvent(A, ev_prep_done_[gp], 0));
         }
+        if (frame_index_ >= 2 && D != B) NRC_HIP(hipStreamWaitEvent(D, ev_train_done_[pp], 0));   // train-ray set pp: frame N-2
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
                         count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, A);
         NRC_HIP(hipEventRecord(ev_[1], A));
-        if (B != A) NRC_HIP(hipStreamWaitEvent(B, ev_[1], 0));
+        if (D != A) NRC_HIP(hipStreamWaitEvent(D, ev_[1], 0));
         if (Cs != A) NRC_HIP(hipStreamWaitEvent(Cs, ev_[1], 0));
         // the reference records prep_train_rays into every frame's pre-CUDA command buffer (:2039-2040), trained or not
         launch_prep_train(scene_.d, frame_, tg_, (const float*)d_info_, (const float*)d_origin_, (const float*)d_dir_,
-                          (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, B);
-        NRC_HIP(hipEventRecord(ev_[2], B));
+                          (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, D);
+        NRC_HIP(hipEventRecord(ev_[2], D));
+        NRC_HIP(hipEventRecord(ev_prep_done_[gp], D));
+        if (B != D) NRC_HIP(hipStreamWaitEvent(B, ev_prep_done_[gp], 0));
         if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
         // same NRC from another camera, src/Reference.cpp:71-107)
@@ -402,13 +422,14 @@ public:
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
         cache_.infer_all(nullptr, Cs, !getenv("NRC_DENSE_INFER"));
         NRC_HIP(hipEventRecord(ev_[3], Cs));
-        if (train) cache_.train_all(B, B != Cs ? ev_[3] : nullptr);
+        NRC_HIP(hipEventRecord(ev_infer_done_[pp], Cs));
+        if (train) cache_.train_all(B, (B != Cs && frame_index_ > 0) ? ev_infer_done_[pp ^ 1] : nullptr);
         NRC_HIP(hipEventRecord(ev_[5], B));
         NRC_HIP(hipEventRecord(ev_train_done_[pp], B));
         launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
                          (const float*)d_infer_out_, (float*)d_out_, Cs);
         NRC_HIP(hipEventRecord(ev_[4], Cs));
-        NRC_HIP(hipEventRecord(ev_comp_done_[pp], Cs));
+        NRC_HIP(hipEventRecord(ev_comp_done_[gp], Cs));
         frame_index_++;
         timed_ = true;
     }
@@ -419,6 +440,7 @@ public:
         NRC_HIP(hipStreamSynchronize(stream_));
         if (stream_b_) NRC_HIP(hipStreamSynchronize(stream_b_));
         if (stream_c_) NRC_HIP(hipStreamSynchronize(stream_c_));
+        if (stream_d_) NRC_HIP(hipStreamSynchronize(stream_d_));
     }
 
     void set_camera(const nrc_camera& c)       // SetCamera, :561-604: reset blending, clear the accumulation images
@@ -428,7 +450,7 @@ public:
         blend_index_ = 1;
         const size_t px = (size_t)w_ * h_;
         NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < kGenSets; k++) {
             NRC_HIP(hipMemsetAsync(d_primary2_[k], 0, px * 16, stream_));
             NRC_HIP(hipMemsetAsync(d_info2_[k], 0, px * 4, stream_));
         }
@@ -568,15 +590,18 @@ private:
     TrainGrid tg_{};
     size_t ring_entries_ = 0;
     void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
-    void *d_info2_[2] = {nullptr, nullptr}, *d_origin2_[2] = {nullptr, nullptr}, *d_dir2_[2] = {nullptr, nullptr};
-    void *d_primary2_[2] = {nullptr, nullptr}, *d_infer_in2_[2] = {nullptr, nullptr};
-    hipEvent_t ev_train_done_[2] = {nullptr, nullptr}, ev_comp_done_[2] = {nullptr, nullptr};
+    static constexpr int kGenSets = 3;
+    void *d_info2_[kGenSets] = {}, *d_origin2_[kGenSets] = {}, *d_dir2_[kGenSets] = {};
+    void *d_primary2_[kGenSets] = {}, *d_infer_in2_[kGenSets] = {};
+    hipEvent_t ev_train_done_[2] = {nullptr, nullptr}, ev_comp_done_[kGenSets] = {};
     uint64_t frame_index_ = 0;
     void *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
     void *d_ring_ = nullptr, *d_scratch_ = nullptr, *d_fetch_ = nullptr;
     std::vector<void*> allocs_;
     std::vector<std::array<hipEvent_t, 10>> ev_pool_;
-    hipStream_t stream_b_ = nullptr, stream_c_ = nullptr;
+    hipStream_t stream_b_ = nullptr, stream_c_ = nullptr, stream_d_ = nullptr;
+    void *d_train_in2_[2] = {nullptr, nullptr}, *d_train_target2_[2] = {nullptr, nullptr};
+    hipEvent_t ev_prep_done_[kGenSets] = {}, ev_infer_done_[2] = {nullptr, nullptr};
     size_t ev_used_ = 0;
     bool timed_ = false;
     float pinned_random_[4] = {0, 0, 0, 0};

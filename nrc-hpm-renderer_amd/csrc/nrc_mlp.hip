@@ -293,6 +293,7 @@ __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in,
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
                                                   int skip_zero = 0)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     unsigned long long t0 = 0, r0 = 0;
@@ -402,6 +403,7 @@ template <int DEPTH, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const uint4* __restrict__ img_fwd,
                                                           const uint4* __restrict__ img_bwd)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     uint4* lb = lw + n_frag_fwd(DEPTH) * 64;
@@ -549,6 +551,7 @@ __device__ __forceinline__ void oneblob4(float xd, float (&out)[4])
 template <int POS, int DIR>
 __global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, half_t* __restrict__ feat, uint32_t n)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     constexpr int NP = POS == 3 ? 72 : (POS == 1 ? 3 : 36);
     constexpr int ND = DIR == 1 ? 2 : 8;
     constexpr int E16 = (NP + ND + 15) / 16 * 16;
@@ -658,6 +661,7 @@ template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ in, const uint32_t* __restrict__ table16,
                                                     half_t* __restrict__ feat, uint32_t n, HashLevels lv)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     constexpr int ND = DIR == 1 ? 2 : 8, E16 = 48;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
@@ -703,6 +707,7 @@ __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ i
 __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
                                                       float* __restrict__ grad_table, uint32_t n, HashLevels lv)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
     if (sample >= n) return;
@@ -725,6 +730,7 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
 __global__ void k_pack_grid(const float* __restrict__ w, const float* __restrict__ ema, uint32_t* __restrict__ t_train,
                             uint32_t* __restrict__ t_ema, uint32_t n_entries)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     float2v a = {w[2 * (size_t)i], w[2 * (size_t)i + 1]}, b = {ema[2 * (size_t)i], ema[2 * (size_t)i + 1]};
@@ -742,6 +748,7 @@ template <int WIDTH>
 __global__ __launch_bounds__(256) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                   const uint4* __restrict__ img, int depth, int ks0)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -805,6 +812,7 @@ template <int WIDTH>
 __global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
                                                   const uint4* __restrict__ img_bwd)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -942,6 +950,7 @@ __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __rest
                                                            const WgradTile* __restrict__ tiles, int n_tiles,
                                                            float* __restrict__ slabs, uint32_t n_params)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t k0 = blockIdx.x * WGRAD_CHUNK;
@@ -979,6 +988,7 @@ __global__ __launch_bounds__(256) void k_reduce_grads(const float* __restrict__ 
                                                      float* __restrict__ grad, const float* __restrict__ loss_part,
                                                      uint32_t n_loss, float* __restrict__ loss)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     __shared__ float part[4][64];
     __shared__ float red[256];
     const uint32_t p = threadIdx.x & 63u, g = threadIdx.x >> 6;
@@ -1011,6 +1021,7 @@ struct AdamArgs {
 __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
                            float* __restrict__ v, const float* __restrict__ grad, uint32_t n, uint32_t n_matrix, AdamArgs a)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, l2 = 1e-8f;
@@ -1035,6 +1046,7 @@ __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ em
                        uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd, half_t* __restrict__ pk_infer,
                        half_t* __restrict__ pk_fwd, half_t* __restrict__ pk_bwd)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_fwd) {
         const int32_t s = src_fwd[i];
@@ -1161,12 +1173,12 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     NRC_HIP(hipMalloc(&d_src_bwd_, sb.size() * 4));
     NRC_HIP(hipMemcpy(d_src_fwd_, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
     NRC_HIP(hipMemcpy(d_src_bwd_, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
-    NRC_HIP(hipMalloc(&d_pk_infer_, sf.size() * 2));
+    for (auto& p : d_pk_infer_) NRC_HIP(hipMalloc(&p, sf.size() * 2));
     NRC_HIP(hipMalloc(&d_pk_fwd_, sf.size() * 2));
     NRC_HIP(hipMalloc(&d_pk_bwd_, sb.size() * 2));
     if (hash_) {
         NRC_HIP(hipMalloc(&d_t16_train_, (size_t)n_grid_entries_ * 4));
-        NRC_HIP(hipMalloc(&d_t16_ema_, (size_t)n_grid_entries_ * 4));
+        for (auto& p : d_t16_ema_) NRC_HIP(hipMalloc(&p, (size_t)n_grid_entries_ * 4));
     }
     repack(nullptr);
     NRC_HIP(hipStreamSynchronize(nullptr));
@@ -1174,8 +1186,9 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 
 Mlp::~Mlp()
 {
-    void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_, d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
-                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_, d_t16_train_, d_t16_ema_, d_denc_};
+    void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
+                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_[0], d_feat_[1], d_t16_train_,
+                    d_t16_ema_[0], d_t16_ema_[1], d_denc_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -1192,33 +1205,40 @@ float* Mlp::buffer(int which)
     }
 }
 
+// The inference (EMA) image and table are double-buffered: this writes the set inference is NOT reading and then makes it
+// current for every inference enqueued from now on.  An inference pass enqueued earlier keeps reading the other set, so the
+// optimizer of frame N never has to wait for frame N's inference (only for frame N-1's, which read the set written here).
 void Mlp::repack(hipStream_t s)
 {
     const uint32_t nf = n_frag_fwd_ * 512, nb = n_frag_bwd_ * 512;
     const uint32_t nmax = nf > nb ? nf : nb;
+    const int next = infer_set_ ^ 1;
     hipLaunchKernelGGL(k_pack, dim3(ceil_div(nmax, 256)), dim3(256), 0, s, d_w_, d_ema_, d_src_fwd_, nf, d_src_bwd_, nb,
-                       (half_t*)d_pk_infer_, (half_t*)d_pk_fwd_, (half_t*)d_pk_bwd_);
+                       (half_t*)d_pk_infer_[next], (half_t*)d_pk_fwd_, (half_t*)d_pk_bwd_);
     if (hash_)
         hipLaunchKernelGGL(k_pack_grid, dim3(ceil_div(n_grid_entries_, 256)), dim3(256), 0, s, d_w_ + n_mlp_, d_ema_ + n_mlp_,
-                           (uint32_t*)d_t16_train_, (uint32_t*)d_t16_ema_, n_grid_entries_);
+                           (uint32_t*)d_t16_train_, (uint32_t*)d_t16_ema_[next], n_grid_entries_);
     NRC_HIP(hipGetLastError());
+    infer_set_ = next;
 }
 
 // generic-path encoding launch: HashGrid gathers from the fp16 table copy that belongs to the weight set in use
-void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, hipStream_t s)
+// `slot` 0 = inference, 1 = training: the two may run concurrently on different streams and own separate feature buffers
+void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s)
 {
-    ensure_features(n);
+    ensure_features(n, slot);
+    half_t* feat = (half_t*)d_feat_[slot];
     if (!hash_) {
-        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, (half_t*)d_feat_, n);
+        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, feat, n);
         return;
     }
     HashLevels lv;
     for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
-    const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_ : d_t16_train_);
+    const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_[infer_set_] : d_t16_train_);
     const dim3 g(ceil_div(n * 16u, 256));
-    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, (half_t*)d_feat_, n, lv);
-    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, (half_t*)d_feat_, n, lv);
-    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, (half_t*)d_feat_, n, lv);
+    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv);
+    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, feat, n, lv);
+    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv);
 }
 
 static int g_num_cus = 0;
@@ -1243,29 +1263,32 @@ static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float
 }
 
 // fp16 feature buffer of the generic path ([n][E16]); grows on demand (never inside a captured region: first use sizes it)
-void Mlp::ensure_features(uint32_t n)
+void Mlp::ensure_features(uint32_t n, int slot)
 {
-    if (n <= feat_n_) return;
-    if (d_feat_) (void)hipFree(d_feat_);
-    d_feat_ = nullptr;
-    NRC_HIP(hipMalloc(&d_feat_, (size_t)n * enc_dims_ * 2));
-    feat_n_ = n;
+    if (n <= feat_n_[slot]) return;
+    if (d_feat_[slot]) {
+        NRC_HIP(hipDeviceSynchronize());      // a kernel on another stream may still read the old buffer
+        (void)hipFree(d_feat_[slot]);
+    }
+    d_feat_[slot] = nullptr;
+    NRC_HIP(hipMalloc(&d_feat_[slot], (size_t)n * enc_dims_ * 2));
+    feat_n_[slot] = n;
 }
 
 void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries)
 {
     if (n == 0) return;
-    const uint4* img = (const uint4*)(use_ema ? d_pk_infer_ : d_pk_fwd_);
+    const uint4* img = (const uint4*)(use_ema ? d_pk_infer_[infer_set_] : d_pk_fwd_);
     if (!fused_) {
-        launch_features(d_in, n, use_ema, s);
+        launch_features(d_in, n, use_ema, 0, s);
         uint32_t blocks = ceil_div(ceil_div(n, 32), 4);
         const uint32_t cap = (uint32_t)num_cus() * 8u;
         if (blocks > cap) blocks = cap;
         if (width_ == 64)
-            hipLaunchKernelGGL(k_infer_gen<64>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_, d_out, n, img, (int)depth_,
+            hipLaunchKernelGGL(k_infer_gen<64>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_[0], d_out, n, img, (int)depth_,
                                (int)enc_dims_ / 16);
         else
-            hipLaunchKernelGGL(k_infer_gen<128>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_, d_out, n, img, (int)depth_,
+            hipLaunchKernelGGL(k_infer_gen<128>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_[0], d_out, n, img, (int)depth_,
                                (int)enc_dims_ / 16);
         NRC_HIP(hipGetLastError());
         return;
@@ -1415,10 +1438,10 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
                            (const uint4*)d_pk_bwd_);
     } else {
-        launch_features(d_in, n, false, s);
+        launch_features(d_in, n, false, 1, s);
         if (hash_) NRC_HIP(hipMemsetAsync(d_grad_ + n_mlp_, 0, (size_t)n_grid_entries_ * 2 * sizeof(float), s));
         TrainArgsGen a;
-        a.feat = (const half_t*)d_feat_;
+        a.feat = (const half_t*)d_feat_[1];
         a.target = d_target;
         a.n = n;
         a.inv_n_total = 1.0f / (float)(3u * n_norm);

@@ -40,8 +40,8 @@ public:
 
 private:
     void ensure_train_workspace(uint32_t n);
-    void ensure_features(uint32_t n);
-    void launch_features(const float* d_in, uint32_t n, bool use_ema, hipStream_t s);
+    void ensure_features(uint32_t n, int slot);
+    void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s);
     void infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
                           const void* image);
 
@@ -50,18 +50,19 @@ private:
     uint32_t loss_id_;
     bool fused_ = false;         // north-star model (Frequency+OneBlob, 6x64): fully fused kernels; otherwise the generic path
     std::vector<MlpLayer> layers_;
-    void* d_feat_ = nullptr;     // generic path: fp16 features [n][enc_dims]
-    uint32_t feat_n_ = 0;
+    void* d_feat_[2] = {nullptr, nullptr};     // generic path: fp16 features [n][enc_dims]; [0] inference, [1] training
+    uint32_t feat_n_[2] = {0, 0};
+    int infer_set_ = 0;          // which of the double-buffered inference (EMA) image / table sets is current
     uint32_t n_mlp_ = 0;         // matrix parameters; (posID 0) the hash-grid table [entry][2] follows them in every vector
     bool hash_ = false;
     uint32_t hg_off_[17] = {0};  // per-level entry offsets
     uint32_t n_grid_entries_ = 0;
-    void *d_t16_train_ = nullptr, *d_t16_ema_ = nullptr;   // half2-per-entry gather copies of the table
+    void *d_t16_train_ = nullptr, *d_t16_ema_[2] = {nullptr, nullptr};   // half2-per-entry gather copies of the table
     void* d_denc_ = nullptr;     // fp16 [n][32] dL/d(grid features)
 
     float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)
-    void *d_pk_infer_ = nullptr, *d_pk_fwd_ = nullptr, *d_pk_bwd_ = nullptr;
+    void *d_pk_infer_[2] = {nullptr, nullptr}, *d_pk_fwd_ = nullptr, *d_pk_bwd_ = nullptr;
     int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)
     uint32_t n_frag_fwd_ = 0, n_frag_bwd_ = 0;
 

@@ -89,6 +89,16 @@ def main():
     cu = (hw >> 8) & 0xf
     sh = (hw >> 12) & 0x1
     se = (hw >> 13) & 0x7
+    simd = (hw >> 4) & 0x3
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    skey = key * 4 + simd
+    # peak concurrent waves per SIMD / per CU at the middle of the launch
+    tmid = 0.35 * span
+    live = (start <= tmid) & (end > tmid)
+    per_simd = np.bincount(skey[live], minlength=int(skey.max()) + 1)
+    per_cu = np.bincount(key[live], minlength=int(key.max()) + 1)
+    print("waves live at t=%.0f us: %d; per-SIMD histogram %s; per-CU histogram %s" %
+          (tmid, live.sum(), np.bincount(per_simd[per_simd > 0]).tolist(), np.bincount(per_cu[per_cu > 0]).tolist()))
     print("distinct (xcc,se,sh,cu) seen:", len(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))))
 
 
