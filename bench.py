@@ -210,6 +210,8 @@ def main():
         mlp_ms = time_infer(rnd)
         mlp_ms_frame = time_infer(ren.Buffer("infer_input"))
         mlp_tflops = MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms * 1e-3) / 1e12
+        if not (0.0 < mlp_tflops < MFMA_F16_PEAK_TFLOPS):
+            raise RuntimeError("MLP timing is not physical (%.1f TFLOP/s): the events did not bracket the kernel's stream" % mlp_tflops)
         gen_ms = stats["gen_rays"]
         gen_store_bytes = n_px * (16 + 4 + 16 + 16 + 20)                    # primary, info, origin, dir, query
         gen_bytes = n_fetch * 1.0 + gen_store_bytes

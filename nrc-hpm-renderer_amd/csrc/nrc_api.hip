@@ -76,10 +76,17 @@ public:
 
     void init(uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_ttarget, hipStream_t s)
     {
+        bind(infer_count, d_in, d_out, d_tin, d_ttarget);
+        stream_ = s;
+    }
+
+    // (re)bind the caller-owned I/O buffers without touching the stream of the stand-alone entry points: the renderer does
+    // this every frame (its buffer sets rotate, and several renderers may share one cache) and names its streams explicitly
+    void bind(uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_ttarget)
+    {
         if (infer_count % 16 != 0) fail("NRC requires inferCount to be a multiple of 16");   // :52
         infer_count_ = infer_count;
         d_infer_in_ = d_in; d_infer_out_ = d_out; d_train_in_ = d_tin; d_train_target_ = d_ttarget;
-        stream_ = s;
         // batch slicing, :67-92
         infer_batches_.clear();
         const uint32_t full = infer_count / infer_batch_size_;
@@ -417,8 +424,8 @@ public:
         if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
         // same NRC from another camera, src/Reference.cpp:71-107)
-        cache_.init((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
-                    (float*)d_train_target_, Cs);
+        cache_.bind((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
+                    (float*)d_train_target_);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
         cache_.infer_all(nullptr, Cs, !getenv("NRC_DENSE_INFER"));
         NRC_HIP(hipEventRecord(ev_[3], Cs));

@@ -645,16 +645,25 @@ __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, 
     __shared__ uint32_t wsum[16];
     const uint32_t T = tg.tw * tg.th;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // each thread owns a contiguous run of train indices: local count -> block-wide exclusive scan -> ranks
+    // each thread owns a contiguous run of train indices: flags -> local count -> block-wide exclusive scan -> ranks.
+    // Runs of <= 64 indices (T <= 65536, the reference's default 4 x 2^14 included) keep their flags in a register mask, so
+    // the strided gathers from the info image are independent and all in flight together; longer runs re-read the flags.
     const uint32_t per = (T + 1023u) / 1024u;
-    const uint32_t i0 = tid * per, i1 = min(i0 + per, T);
-    uint32_t cnt = 0;
-    for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t i0 = min(tid * per, T), i1 = min(i0 + per, T);
+    const bool in_regs = per <= 64u;
+    auto flag_of = [&](uint32_t i) -> uint32_t {
         const uint32_t tx = i % tg.tw, ty = i / tg.tw;
         const uint32_t rx = tx * tg.x_dist, ry = ty * tg.y_dist;
-        const uint32_t f = (rx < fr.w && ry < fr.h) ? (info[(size_t)ry * fr.w + rx] == 1.0f ? 1u : 0u) : 0u;   // OOB imageLoad -> 0 (Q1)
-        scratch[i] = f;
-        cnt += f;
+        return (rx < fr.w && ry < fr.h) ? (info[(size_t)ry * fr.w + rx] == 1.0f ? 1u : 0u) : 0u;   // OOB imageLoad -> 0 (Q1)
+    };
+    unsigned long long flags = 0ull;
+    uint32_t cnt = 0;
+    if (in_regs) {
+#pragma unroll 8
+        for (uint32_t j = 0; j < i1 - i0; j++) flags |= (unsigned long long)flag_of(i0 + j) << j;
+        cnt = (uint32_t)__popcll(flags);
+    } else {
+        for (uint32_t i = i0; i < i1; i++) cnt += flag_of(i);
     }
     uint32_t incl = cnt;
 #pragma unroll
@@ -671,7 +680,8 @@ __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, 
     }
     uint32_t push_rank = woff + incl - cnt;        // scattered entries before i0
     for (uint32_t i = i0; i < i1; i++) {
-        const uint32_t f = scratch[i];
+        const uint32_t f = in_regs ? (uint32_t)(flags >> (i - i0)) & 1u : flag_of(i);
+        scratch[i] = f;
         scratch[T + i] = f ? push_rank : (i - push_rank);
         push_rank += f;
     }
