@@ -169,7 +169,9 @@ int nrc_renderer_set_show_nrc(nrc_renderer_t* r, int show);
 /* UniformData.random: by default drawn per frame from std::mt19937(seed) (the reference uses glm::linearRand,
  * src/NrcHpmRenderer.cu:308); this pins the next frame's value (parity tests) */
 int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float random4[4]);
-/* GetImage()/GetImageView() -> device pointer, RGBA32F, row-major height x width (local columns) */
+/* GetImage()/GetImageView() -> device pointer, RGBA32F, row-major height x width (local columns).  The renderer composites
+ * on an internal stream; this call makes the stream passed to nrc_renderer_create wait (on the device) for the latest frame's
+ * compositing, so work enqueued on that stream afterwards sees the finished image.  Call it again after every Render. */
 const float* nrc_renderer_framebuffer(nrc_renderer_t* r);
 /* ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493): scan-line EXR, FLOAT RGBA */
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);

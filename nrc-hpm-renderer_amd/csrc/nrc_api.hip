@@ -552,7 +552,15 @@ public:
         if (bytes) *bytes = b;
         return p;
     }
-    const float* framebuffer() const { return (const float*)d_out_; }
+    // The compositing kernel runs on the renderer's own stream C.  Handing out the framebuffer orders the caller's stream
+    // behind the latest compositing pass (device-side wait, no host block), so whatever the caller enqueues next on the stream
+    // it passed in -- a copy, a display blit, CompareImages -- sees the finished frame, as with the reference's single queue.
+    const float* framebuffer()
+    {
+        if (stream_c_ && frame_index_ > 0)
+            NRC_HIP(hipStreamWaitEvent(stream_, ev_comp_done_[(frame_index_ - 1) % (uint64_t)kGenSets], 0));
+        return (const float*)d_out_;
+    }
     const TrainGrid& train_grid() const { return tg_; }
     hipStream_t stream() const { return stream_; }
 

@@ -48,13 +48,3 @@ struct Pcg32 {
 };
 
 }  // namespace nrc
-
-// The frame graph runs the camera kernel (hundreds of microseconds of VALU work, every wave slot taken) beside short
-// latency-bound kernels on the training / inference streams.  Those raise their waves' issue priority (s_setprio) so that a
-// SIMD serves them first and their dependent chains do not stretch 2-3x under the camera kernel's load.
-#ifdef NRC_NO_SETPRIO
-#define NRC_RAISE_WAVE_PRIORITY() do { } while (0)
-#else
-#define NRC_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
-#endif
-

@@ -641,7 +641,6 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_mc_render(DevSc
 __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, const float* __restrict__ info,
                                                     uint32_t* __restrict__ ring, uint32_t* __restrict__ scratch)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     __shared__ uint32_t wsum[16];
     const uint32_t T = tg.tw * tg.th;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -706,7 +705,6 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
                                                    const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
                                                    float* __restrict__ train_target)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
@@ -764,7 +762,6 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
 __global__ void k_ring_push(DevFrame fr, TrainGrid tg, const float4* __restrict__ origin, const float4* __restrict__ dirs,
                             uint32_t* __restrict__ ring, const uint32_t* __restrict__ scratch)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t T = tg.tw * tg.th;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (tg.ring_size == 0) return;
@@ -788,7 +785,6 @@ __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nr
                                                   const float4* __restrict__ primary, const float* __restrict__ info,
                                                   const float* __restrict__ infer_out, float4* __restrict__ out_rgba)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     uint32_t lx, y;
     if (!pixel_of_thread(fr, &lx, &y)) return;
     const size_t pix = (size_t)y * fr.w + lx, lin = (size_t)lx * fr.h + y;

@@ -293,7 +293,6 @@ __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in,
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
                                                   int skip_zero = 0)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     unsigned long long t0 = 0, r0 = 0;
@@ -403,7 +402,6 @@ template <int DEPTH, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const uint4* __restrict__ img_fwd,
                                                           const uint4* __restrict__ img_bwd)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     uint4* lb = lw + n_frag_fwd(DEPTH) * 64;
@@ -551,7 +549,6 @@ __device__ __forceinline__ void oneblob4(float xd, float (&out)[4])
 template <int POS, int DIR>
 __global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, half_t* __restrict__ feat, uint32_t n)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     constexpr int NP = POS == 3 ? 72 : (POS == 1 ? 3 : 36);
     constexpr int ND = DIR == 1 ? 2 : 8;
     constexpr int E16 = (NP + ND + 15) / 16 * 16;
@@ -661,7 +658,6 @@ template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ in, const uint32_t* __restrict__ table16,
                                                     half_t* __restrict__ feat, uint32_t n, HashLevels lv)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     constexpr int ND = DIR == 1 ? 2 : 8, E16 = 48;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
@@ -707,7 +703,6 @@ __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ i
 __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
                                                       float* __restrict__ grad_table, uint32_t n, HashLevels lv)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
     if (sample >= n) return;
@@ -730,7 +725,6 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
 __global__ void k_pack_grid(const float* __restrict__ w, const float* __restrict__ ema, uint32_t* __restrict__ t_train,
                             uint32_t* __restrict__ t_ema, uint32_t n_entries)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     float2v a = {w[2 * (size_t)i], w[2 * (size_t)i + 1]}, b = {ema[2 * (size_t)i], ema[2 * (size_t)i + 1]};
@@ -748,7 +742,6 @@ template <int WIDTH>
 __global__ __launch_bounds__(256) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                   const uint4* __restrict__ img, int depth, int ks0)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -812,7 +805,6 @@ template <int WIDTH>
 __global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
                                                   const uint4* __restrict__ img_bwd)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -950,7 +942,6 @@ __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __rest
                                                            const WgradTile* __restrict__ tiles, int n_tiles,
                                                            float* __restrict__ slabs, uint32_t n_params)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t k0 = blockIdx.x * WGRAD_CHUNK;
@@ -988,7 +979,6 @@ __global__ __launch_bounds__(256) void k_reduce_grads(const float* __restrict__ 
                                                      float* __restrict__ grad, const float* __restrict__ loss_part,
                                                      uint32_t n_loss, float* __restrict__ loss)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     __shared__ float part[4][64];
     __shared__ float red[256];
     const uint32_t p = threadIdx.x & 63u, g = threadIdx.x >> 6;
@@ -1021,7 +1011,6 @@ struct AdamArgs {
 __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
                            float* __restrict__ v, const float* __restrict__ grad, uint32_t n, uint32_t n_matrix, AdamArgs a)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, l2 = 1e-8f;
@@ -1046,7 +1035,6 @@ __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ em
                        uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd, half_t* __restrict__ pk_infer,
                        half_t* __restrict__ pk_fwd, half_t* __restrict__ pk_bwd)
 {
-    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_fwd) {
         const int32_t s = src_fwd[i];

@@ -185,6 +185,38 @@ def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu
     nrc.Destroy()
 
 
+@pytest.mark.parametrize("model", [(3, 0, 64, 6), (2, 2, 64, 3)], ids=["fused", "generic"])
+def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_gpu, model, monkeypatch):
+    """the four-stream frame graph (train rays, training and inference of frame N beside gen_rays of frame N+1; triple-buffered
+    gen_rays outputs, double-buffered train rays and inference weights) is pure scheduling: after 8 trained, blended frames the
+    framebuffer, the loss and every parameter equal the single-stream order (NRC_SINGLE_STREAM=1) bit for bit"""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    frs = sc.frame_randoms(8, seed=21)
+    results = []
+    for mode in ("NRC_SINGLE_STREAM", "NRC_TWO_STREAMS", None, None, None, None):     # the full graph several times: races are rare
+        for k in ("NRC_SINGLE_STREAM", "NRC_TWO_STREAMS"):
+            monkeypatch.delenv(k, raising=False)
+        if mode:
+            monkeypatch.setenv(mode, "1")
+        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3])
+        ren.SetBlend(True)
+        for f in range(8):
+            ren.SetFrameRandom(frs[f])
+            ren.Render(None, True)        # no host synchronisation between frames
+        results.append((ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy(), nrc.GetParams(1).copy(),
+                        ren.Buffer("train_input").cpu().numpy().copy()))
+        ren.Destroy()
+        nrc.Destroy()
+    base = results[0]
+    for other in results[1:]:
+        assert np.array_equal(base[0].view(np.uint32), other[0].view(np.uint32))
+        assert base[1] == other[1]
+        assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
+        assert np.array_equal(base[3].view(np.uint32), other[3].view(np.uint32))
+        assert np.array_equal(base[4].view(np.uint32), other[4].view(np.uint32))
+
+
 def test_column_tiles_reproduce_the_whole_frame(api, sc, cloud16, torch_gpu):
     """pixel-tile sharding: N interleaved column tiles == the single-GPU frame, bit for bit (integrator)"""
     from nrc_hpm_renderer_amd import parallel
