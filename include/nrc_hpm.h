@@ -164,6 +164,11 @@ int nrc_renderer_render(nrc_renderer_t* r, int train);
 /* NrcHpmRenderer::SetCamera / SetBlend (src/NrcHpmRenderer.cu:561-610) */
 int nrc_renderer_set_camera(nrc_renderer_t* r, const nrc_camera* camera);
 int nrc_renderer_set_blend(nrc_renderer_t* r, int blend);
+/* The uniform-buffer half of the scene -- DirLight / PointLight / VolumeData / HdrEnvMap strength (src/DirLight.cpp:31-49,
+ * src/HpmScene.cpp:56-76 `HpmScene::Update`, the ImGui light editors): takes effect with the next Render and does not reset
+ * blending (only a camera change does, src/NrcHpmRenderer.cu:561-604).  The density volume and the environment map of `scene`
+ * are ignored (textures are fixed at creation). */
+int nrc_renderer_set_scene_params(nrc_renderer_t* r, const nrc_scene* scene);
 /* UniformData.showNrc (include/engine/graphics/renderer/NrcHpmRenderer.hpp:70-75) */
 int nrc_renderer_set_show_nrc(nrc_renderer_t* r, int show);
 /* UniformData.random: by default drawn per frame from std::mt19937(seed) (the reference uses glm::linearRand,
@@ -206,6 +211,7 @@ int nrc_mc_renderer_create(uint32_t width, uint32_t height, uint32_t path_length
 int nrc_mc_renderer_render(nrc_mc_renderer_t* r);
 int nrc_mc_renderer_set_camera(nrc_mc_renderer_t* r, const nrc_camera* camera);
 int nrc_mc_renderer_set_blend(nrc_mc_renderer_t* r, int blend);
+int nrc_mc_renderer_set_scene_params(nrc_mc_renderer_t* r, const nrc_scene* scene);   /* see nrc_renderer_set_scene_params */
 int nrc_mc_renderer_set_frame_random(nrc_mc_renderer_t* r, const float random4[4]);
 const float* nrc_mc_renderer_framebuffer(nrc_mc_renderer_t* r);   /* RGBA32F, alpha = blended didScatter */
 int nrc_mc_renderer_export_exr(nrc_mc_renderer_t* r, const char* path);

@@ -119,6 +119,7 @@ public:
     const float* GetStageTimesMS() const { return stage_ms_; }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_renderer_set_camera(h_, camera)); }
     void SetBlend(bool blend) { nrc_check(nrc_renderer_set_blend(h_, blend ? 1 : 0)); }
+    void SetSceneParams(const nrc_scene& scene) { nrc_check(nrc_renderer_set_scene_params(h_, &scene)); }   // HpmScene::Update
 
 private:
     nrc_renderer_t* h_ = nullptr;
@@ -145,6 +146,7 @@ public:
     const float* GetImage() const { return nrc_mc_renderer_framebuffer(h_); }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_mc_renderer_set_camera(h_, camera)); }
     void SetBlend(bool blend) { nrc_check(nrc_mc_renderer_set_blend(h_, blend ? 1 : 0)); }
+    void SetSceneParams(const nrc_scene& scene) { nrc_check(nrc_mc_renderer_set_scene_params(h_, &scene)); }
 
 private:
     nrc_mc_renderer_t* h_ = nullptr;

@@ -67,6 +67,7 @@ ABI_SYMBOLS = [
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
     "nrc_cache_get_step", "nrc_cache_set_step",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
+    "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_export_exr",
     "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
     "nrc_renderer_train_grid",
@@ -383,6 +384,11 @@ class NrcHpmRenderer:
     def SetBlend(self, blend):
         _check(self.L.nrc_renderer_set_blend(self.h, C.c_int(int(blend))))
 
+    def SetSceneParams(self, scene):
+        """lights / medium constants of `scene` (dict of scene.make_scene or scene.HpmScene); textures are not re-uploaded"""
+        sc_ = make_c_scene(scene.scene if hasattr(scene, "scene") else scene)
+        _check(self.L.nrc_renderer_set_scene_params(self.h, C.byref(sc_)))
+
     def SetShowNrc(self, show):
         _check(self.L.nrc_renderer_set_show_nrc(self.h, C.c_int(int(show))))
 
@@ -476,6 +482,10 @@ class McHpmRenderer:
 
     def SetBlend(self, blend):
         _check(self.L.nrc_mc_renderer_set_blend(self.h, C.c_int(int(blend))))
+
+    def SetSceneParams(self, scene):
+        sc_ = make_c_scene(scene.scene if hasattr(scene, "scene") else scene)
+        _check(self.L.nrc_mc_renderer_set_scene_params(self.h, C.byref(sc_)))
 
     def SetFrameRandom(self, r4):
         r = (C.c_float * 4)(*[float(x) for x in r4])

@@ -216,6 +216,20 @@ struct SceneDev {
         }
         const float tx = 2.0f * size[0], ty = 2.0f * size[1], tz = 2.0f * size[2];
         d.len2size = sqrtf((tx * tx + ty * ty) + tz * tz);
+        set_params(s);
+        d.env = nullptr; d.env_w = d.env_h = 0;
+        if (s.env && s.env_w && s.env_h) {
+            const size_t eb = (size_t)s.env_w * s.env_h * 16;
+            NRC_HIP(hipMalloc(&d_env, eb));
+            NRC_HIP(hipMemcpy(d_env, s.env, eb, hipMemcpyHostToDevice));
+            d.env = (const float*)d_env; d.env_w = s.env_w; d.env_h = s.env_h;
+        }
+    }
+    // the uniform-buffer part of the scene (DirLight / PointLight / VolumeData / HdrEnvMap UBOs: src/DirLight.cpp:31-49,
+    // src/HpmScene.cpp:56-76): kernels take DevScene by value, so the next launch sees the new values
+    void set_params(const nrc_scene& s)
+    {
+        if (!(s.density_factor > 0.0f)) fail("scene density factor must be positive");
         d.density_factor = s.density_factor;
         d.inv_max_density = 1.0f / s.density_factor;
         d.g = s.g;
@@ -227,13 +241,6 @@ struct SceneDev {
         d.dir_light_strength = s.dir_light_strength;
         d.point_light_strength = s.point_light_strength;
         d.env_strength = s.env_strength;
-        d.env = nullptr; d.env_w = d.env_h = 0;
-        if (s.env && s.env_w && s.env_h) {
-            const size_t eb = (size_t)s.env_w * s.env_h * 16;
-            NRC_HIP(hipMalloc(&d_env, eb));
-            NRC_HIP(hipMemcpy(d_env, s.env, eb, hipMemcpyHostToDevice));
-            d.env = (const float*)d_env; d.env_w = s.env_w; d.env_h = s.env_h;
-        }
     }
     ~SceneDev()
     {
@@ -463,6 +470,7 @@ public:
         }
     }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }      // :606-610
+    void set_scene_params(const nrc_scene& s) { scene_.set_params(s); }
     void set_show_nrc(bool s) { show_nrc_ = s ? 1u : 0u; }
     void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
     void set_count_fetches(bool on)
@@ -665,6 +673,7 @@ public:
         blend_index_ = 1;
         NRC_HIP(hipMemsetAsync(d_out_, 0, (size_t)w_ * h_ * 16, stream_));
     }
+    void set_scene_params(const nrc_scene& s) { scene_.set_params(s); }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }
     void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
     void set_count_fetches(bool on) { count_fetches_ = on; NRC_HIP(hipMemsetAsync(d_fetch_, 0, 8, stream_)); }
@@ -842,7 +851,7 @@ int nrc_cache_get_params(nrc_cache_t* c, int which, float* host_out)
 {
     NRC_REQUIRE(c); NRC_REQUIRE(host_out);
     return guarded([&] {
-        NRC_HIP(hipStreamSynchronize(c->impl.stream()));
+        NRC_HIP(hipDeviceSynchronize());      // training may be in flight on a renderer's internal stream
         NRC_HIP(hipMemcpy(host_out, c->impl.mlp().buffer(which), (size_t)c->impl.mlp().n_params() * 4, hipMemcpyDeviceToHost));
     });
 }
@@ -850,7 +859,7 @@ int nrc_cache_set_params(nrc_cache_t* c, int which, const float* host_in)
 {
     NRC_REQUIRE(c); NRC_REQUIRE(host_in);
     return guarded([&] {
-        NRC_HIP(hipStreamSynchronize(c->impl.stream()));
+        NRC_HIP(hipDeviceSynchronize());      // training / inference may be in flight on a renderer's internal streams
         NRC_HIP(hipMemcpy(c->impl.mlp().buffer(which), host_in, (size_t)c->impl.mlp().n_params() * 4, hipMemcpyHostToDevice));
         if (which == 0 || which == 1) { c->impl.mlp().repack(c->impl.stream()); NRC_HIP(hipStreamSynchronize(c->impl.stream())); }
     });
@@ -876,6 +885,16 @@ int nrc_renderer_create(uint32_t w, uint32_t h, int blend, const nrc_camera* cam
 }
 int nrc_renderer_render(nrc_renderer_t* r, int train) { NRC_REQUIRE(r); return guarded([&] { r->impl.render(train != 0); }); }
 int nrc_renderer_set_camera(nrc_renderer_t* r, const nrc_camera* c) { NRC_REQUIRE(r); NRC_REQUIRE(c); return guarded([&] { r->impl.set_camera(*c); }); }
+int nrc_renderer_set_scene_params(nrc_renderer_t* r, const nrc_scene* scene)
+{
+    NRC_REQUIRE(r); NRC_REQUIRE(scene);
+    return guarded([&] { r->impl.set_scene_params(*scene); });
+}
+int nrc_mc_renderer_set_scene_params(nrc_mc_renderer_t* r, const nrc_scene* scene)
+{
+    NRC_REQUIRE(r); NRC_REQUIRE(scene);
+    return guarded([&] { r->impl.set_scene_params(*scene); });
+}
 int nrc_renderer_set_blend(nrc_renderer_t* r, int b) { NRC_REQUIRE(r); r->impl.set_blend(b != 0); return NRC_OK; }
 int nrc_renderer_set_show_nrc(nrc_renderer_t* r, int s) { NRC_REQUIRE(r); r->impl.set_show_nrc(s != 0); return NRC_OK; }
 int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float* v) { NRC_REQUIRE(r); NRC_REQUIRE(v); r->impl.set_frame_random(v); return NRC_OK; }

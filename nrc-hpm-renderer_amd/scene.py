@@ -202,6 +202,34 @@ def make_scene(density_u8, scene_id=4, env=None, g=0.8, dims=None, size=None):
     )
 
 
+class HpmScene:
+    """Host mirror of en::HpmScene (src/HpmScene.cpp:22-100): scene preset + the directional light's angles, with the
+    reference's per-frame `Update(deltaTime)`.  Only preset 3 moves when `dynamic` is set (its directional light's azimuth
+    advances by deltaTime/2, wrapped at 2*3.141 -- the literal of src/HpmScene.cpp:68); the reference ships every preset with
+    dynamic = false (src/AppConfig.cpp:96-150), so this is off unless asked for.  `scene` is the dict make_scene returns;
+    hand it to `NrcHpmRenderer.SetSceneParams` / `McHpmRenderer.SetSceneParams` after an update."""
+
+    def __init__(self, density_u8, scene_id=4, env=None, dynamic=False, **kw):
+        self.scene = make_scene(density_u8, scene_id=scene_id, env=env, **kw)
+        self.scene_id = scene_id
+        self.dynamic = bool(dynamic)
+        self.zenith, self.azimuth = -1.57, 0.0       # src/HpmScene.cpp:28
+
+    def IsDynamic(self):
+        return self.dynamic
+
+    def SetDirLightAngles(self, zenith, azimuth):
+        self.zenith, self.azimuth = float(zenith), float(azimuth)
+        self.scene["dir_light_dir"] = dir_light_dir(self.zenith, self.azimuth)
+
+    def Update(self, delta_time):
+        """returns True when a scene parameter changed"""
+        if not self.dynamic or self.scene_id != 3:
+            return False
+        self.SetDirLightAngles(self.zenith, math.fmod(self.azimuth + delta_time * 0.5, 2.0 * 3.141))
+        return True
+
+
 def frame_randoms(n, seed=1337):
     """Per-frame UniformData.random (src/NrcHpmRenderer.cu:308): n x 4 floats in [0,1), seeded (std::mt19937-like role)."""
     rng = np.random.default_rng(seed)

@@ -45,6 +45,41 @@ def test_mc_frame_matches_oracle(api, orc, sc, cloud16, sphere_scene, torch_gpu,
     mc.Destroy()
 
 
+def test_scene_parameter_update_matches_oracle(api, orc, sc, cloud16, torch_gpu):
+    """HpmScene::Update / the light editors: new light + medium constants take effect with the next Render (textures stay) --
+    MC and NRC renderers against the oracle rendered with the updated scene"""
+    W, H = 96, 54
+    cam = sc.make_camera(aspect=W / H)
+    hs = sc.HpmScene(cloud16, scene_id=3, dynamic=True)
+    mc = api.McHpmRenderer(W, H, 32, False, cam, hs.scene)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=10, log2_infer_batch_size=14, scene_id=3)
+    nrc = api.NeuralRadianceCache(cfg)
+    ren = api.NrcHpmRenderer(W, H, False, cam, cfg, hs.scene, nrc)
+    for step in range(2):
+        if step == 1:
+            assert hs.Update(1.5)                      # azimuth 0.75 rad
+            hs.scene["density_factor"] = 0.5           # VolumeData editor
+            hs.scene["point_light_strength"] = 2.0     # PointLight editor
+            mc.SetSceneParams(hs)
+            ren.SetSceneParams(hs)
+        mc.SetFrameRandom(FRAME_RANDOM)
+        mc.Render()
+        ref, _, _ = orc.mc_render(hs.scene, cam, W, H, 32, FRAME_RANDOM, threads=8)
+        img = mc.GetImage().cpu().numpy()
+        assert frac_close(img.reshape(-1, 4), ref.reshape(-1, 4)) >= 0.995 and rel(img, ref) <= 1e-3
+        ren.SetFrameRandom(FRAME_RANDOM)
+        ren.Render(None, False)
+        o = orc.nrc_gen_rays(hs.scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
+        prim = ren.Buffer("primary").cpu().numpy().reshape(H, W, 4)
+        assert frac_close(prim.reshape(-1, 4), o["primary"].reshape(-1, 4)) >= 0.995
+        if step == 0:
+            first = img.copy()
+    assert rel(img, first) > 0.05                      # the update changed the picture
+    mc.Destroy()
+    ren.Destroy()
+    nrc.Destroy()
+
+
 def test_mc_progressive_blend(api, orc, sc, sphere_scene, torch_gpu):
     """blendFactor = 1/blendIndex, index advances only when blending (src/McHpmRenderer.cpp:124-136)"""
     W = H = 48

@@ -72,3 +72,22 @@ def test_column_tiles_partition_the_frame():
 def test_frame_randoms_deterministic(sc):
     a, b = sc.frame_randoms(5), sc.frame_randoms(5)
     assert np.array_equal(a, b) and a.shape == (5, 4) and (a >= 0).all() and (a < 1).all()
+
+
+def test_hpm_scene_update_rotates_only_the_dynamic_preset(sc):
+    """HpmScene::Update (src/HpmScene.cpp:56-76): preset 3's directional light advances azimuth by dt/2 (wrapped at 2*3.141)
+    when the scene is dynamic; every other case leaves the scene alone"""
+    import math
+    vol = sc.quantize_density(sc.sphere_volume(16))
+    s = sc.HpmScene(vol, scene_id=3, dynamic=True)
+    d0 = np.array(s.scene["dir_light_dir"], np.float32)
+    assert np.allclose(d0, sc.dir_light_dir(-1.57, 0.0))
+    assert s.Update(0.5) and abs(s.azimuth - 0.25) < 1e-7
+    d1 = np.array(s.scene["dir_light_dir"], np.float32)
+    assert np.allclose(d1, sc.dir_light_dir(-1.57, 0.25)) and not np.allclose(d0, d1)
+    assert abs(np.linalg.norm(d1) - 1.0) < 1e-5
+    for _ in range(60):
+        s.Update(0.5)
+    assert 0.0 <= s.azimuth < 2.0 * 3.141 and abs(s.azimuth - math.fmod(0.25 * 61, 2.0 * 3.141)) < 1e-4
+    assert not sc.HpmScene(vol, scene_id=3, dynamic=False).Update(0.5)
+    assert not sc.HpmScene(vol, scene_id=4, dynamic=True).Update(0.5)
