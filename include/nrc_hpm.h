@@ -34,7 +34,7 @@ const char* nrc_version(void);
  * defaults src/main.cu:429-440).  Scene preset values (src/AppConfig.cpp:93-150) are carried explicitly. */
 typedef struct nrc_config {
     char loss_fn[32];              /* "RelativeL2Luminance" | "L2" | "RelativeL2" */
-    char optimizer[32];            /* "Adam" */
+    char optimizer[32];            /* "Adam" (default) | "SGD": nested in the EMA wrapper, src/NeuralRadianceCache.cu:20-28 */
     float learning_rate;
     float ema_decay;
     uint32_t pos_id;               /* 0 HashGrid(16x2, 2^19) | 1 Identity | 2 TriangleWave-12 | 3 Frequency-12 */

@@ -1030,6 +1030,20 @@ __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float
     ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
 }
 
+// tiny-cuda-nn sgd.h nested in the EMA wrapper: w -= lr * (g / loss_scale + l2 * w), l2_reg 1e-8, every parameter
+__global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad, uint32_t n, float lr,
+                          AdamArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float l2 = 1e-8f;
+    float wi = w[i];
+    const float g = grad[i] * a.inv_loss_scale + l2 * wi;
+    wi = wi - lr * g;
+    w[i] = wi;
+    ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+}
+
 // fragment images from the canonical fp32 vectors
 __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ ema, const int32_t* __restrict__ src_fwd,
                        uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd, half_t* __restrict__ pk_infer,
@@ -1060,7 +1074,9 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     if (pos_enc_dims(cfg.pos_id) == 0 || dir_enc_dims(cfg.dir_id) == ~0u) fail("NNEncodingConfig posID/dirID is invalid");
     if (width_ != 64 && width_ != 128) fail("nnWidth must be 64 or 128 (got " + std::to_string(width_) + ")");
     if (depth_ < 1 || depth_ > 16) fail("nnDepth must be in 1..16 (got " + std::to_string(depth_) + ")");
-    if (std::strcmp(cfg.optimizer, "Adam") != 0) fail(std::string("unsupported optimizer ") + cfg.optimizer);
+    if (std::strcmp(cfg.optimizer, "Adam") == 0) sgd_ = false;
+    else if (std::strcmp(cfg.optimizer, "SGD") == 0) sgd_ = true;
+    else fail(std::string("unsupported optimizer ") + cfg.optimizer + " (Adam and SGD are built; both run inside the EMA wrapper)");
     if (std::strcmp(cfg.loss_fn, "RelativeL2Luminance") == 0) loss_id_ = 0;
     else if (std::strcmp(cfg.loss_fn, "L2") == 0) loss_id_ = 1;
     else if (std::strcmp(cfg.loss_fn, "RelativeL2") == 0) loss_id_ = 2;
@@ -1476,8 +1492,12 @@ void Mlp::optimizer_step(hipStream_t s)
     a.ema_old = (float)(d * (1.0 - std::pow(d, t - 1.0)));
     a.ema_new = (float)(1.0 - d);
     a.ema_div = (float)(1.0 - std::pow(d, t));
-    hipLaunchKernelGGL(k_adam_ema, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_,
-                       n_params_, n_mlp_, a);
+    if (sgd_)
+        hipLaunchKernelGGL(k_sgd_ema, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_grad_, n_params_,
+                           cfg_.learning_rate, a);
+    else
+        hipLaunchKernelGGL(k_adam_ema, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_,
+                           n_params_, n_mlp_, a);
     NRC_HIP(hipGetLastError());
     repack(s);
 }

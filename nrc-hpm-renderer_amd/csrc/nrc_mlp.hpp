@@ -48,6 +48,7 @@ private:
     nrc_config cfg_;
     uint32_t width_, depth_, enc_dims_, n_params_;
     uint32_t loss_id_;
+    bool sgd_ = false;           // nested optimizer: Adam (default) or SGD
     bool fused_ = false;         // north-star model (Frequency+OneBlob, 6x64): fully fused kernels; otherwise the generic path
     std::vector<MlpLayer> layers_;
     void* d_feat_[2] = {nullptr, nullptr};     // generic path: fp16 features [n][enc_dims]; [0] inference, [1] training

@@ -32,6 +32,7 @@ class OrcNNConfig(C.Structure):
         ("pos_id", C.c_uint32), ("dir_id", C.c_uint32), ("width", C.c_uint32), ("depth", C.c_uint32),
         ("loss_id", C.c_uint32), ("learning_rate", C.c_float), ("ema_decay", C.c_float), ("seed", C.c_uint32),
         ("hashgrid_log2_size", C.c_uint32),
+        ("optimizer_id", C.c_uint32),
     ]
 
 
@@ -188,8 +189,9 @@ class Oracle:
 
     # ---- NN ----
     def nn_create(self, pos_id=3, dir_id=0, width=64, depth=6, loss_id=0, lr=0.01, ema_decay=0.99, seed=1337,
-                  hashgrid_log2_size=0):
-        cfg = OrcNNConfig(pos_id, dir_id, width, depth, loss_id, lr, ema_decay, seed, hashgrid_log2_size)
+                  hashgrid_log2_size=0, optimizer="Adam"):
+        cfg = OrcNNConfig(pos_id, dir_id, width, depth, loss_id, lr, ema_decay, seed, hashgrid_log2_size,
+                          {"Adam": 0, "SGD": 1}[optimizer])
         h = self.lib.orc_nn_create(C.byref(cfg))
         if not h:
             raise ValueError("unsupported encoding for the oracle")

@@ -934,7 +934,7 @@ float orc_nn_backward(void* p, const float* in, const float* target, uint32_t n,
     return (float)loss_sum;
 }
 
-/* EMA{Adam}: SURVEY App. B (tcnn defaults beta1 .9, beta2 .999, eps 1e-8, l2_reg 1e-8) */
+/* EMA{Adam | SGD}: SURVEY App. B (tcnn defaults beta1 .9, beta2 .999, eps 1e-8, l2_reg 1e-8) */
 void orc_nn_optimizer_step(void* p)
 {
     NN* nn = (NN*)p;
@@ -946,6 +946,17 @@ void orc_nn_optimizer_step(void* p)
     const float ema_old = (float)(d * (1.0 - pow(d, t - 1.0)));
     const float ema_new = (float)(1.0 - d);
     const float ema_div = (float)(1.0 - pow(d, t));
+    if (nn->cfg.optimizer_id == 1u) {
+        /* tiny-cuda-nn sgd.h (defaults l2_reg 1e-8, no bias correction): w -= lr * (g + l2 * w) for every parameter */
+        for (size_t i = 0; i < nn->w.size(); i++) {
+            float w = nn->w[i];
+            const float g = nn->grad[i] + l2 * w;
+            w = w - nn->cfg.learning_rate * g;
+            nn->w[i] = w;
+            nn->ema[i] = (nn->ema[i] * ema_old + w * ema_new) / ema_div;
+        }
+        return;
+    }
     for (size_t i = 0; i < nn->w.size(); i++) {
         float w = nn->w[i];
         /* tiny-cuda-nn Adam: L2 only on matrix (MLP) weights; grid entries with a zero gradient are left untouched */

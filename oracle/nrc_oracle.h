@@ -97,6 +97,7 @@ typedef struct orc_nn_config {
     float learning_rate, ema_decay;
     uint32_t seed;
     uint32_t hashgrid_log2_size; /* posID 0 only: log2_hashmap_size (0 = 19, src/AppConfig.cpp:24) */
+    uint32_t optimizer_id;       /* nested optimizer of the EMA wrapper (src/NeuralRadianceCache.cu:20-28): 0 Adam, 1 SGD */
 } orc_nn_config;
 
 void* orc_nn_create(const orc_nn_config* cfg);
@@ -116,7 +117,7 @@ void orc_nn_forward(void* nn, const float* in, uint32_t n, int use_ema, int mode
  * returns the summed loss (trainer->loss).  accumulate != 0 adds into buffer 4. */
 float orc_nn_backward(void* nn, const float* in, const float* target, uint32_t n, uint32_t n_norm,
                       int accumulate);
-/* Adam (+L2 1e-8) then EMA, from buffer 4 */
+/* Adam or SGD (+L2 1e-8) then EMA, from buffer 4 */
 void orc_nn_optimizer_step(void* nn);
 
 #ifdef __cplusplus

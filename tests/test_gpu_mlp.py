@@ -219,8 +219,37 @@ def test_checkpoint_roundtrip(api, torch_gpu):
     b.Destroy()
 
 
+@pytest.mark.parametrize("model", [dict(), dict(pos_id=0, hashgrid_log2_size=10, nn_depth=3)], ids=["fused", "hashgrid"])
+def test_sgd_optimizer_matches_oracle(api, orc, torch_gpu, model):
+    """optimizer "SGD" (second positional argument of the reference's command line, passed through to tiny-cuda-nn inside the
+    EMA wrapper): w -= lr * (g + 1e-8 w) on every parameter; three steps against the oracle"""
+    cfg = api.AppConfig(optimizer="SGD", learning_rate=0.05, log2_train_batch_size=10, **model)
+    c = api.NeuralRadianceCache(cfg)
+    onn = orc.nn_create(pos_id=cfg.pos_id, dir_id=cfg.dir_id, width=cfg.nn_width, depth=cfg.nn_depth, lr=0.05,
+                        hashgrid_log2_size=model.get("hashgrid_log2_size", 0), optimizer="SGD")
+    rng = np.random.default_rng(11)
+    w = rng.uniform(-0.3, 0.3, c.ParamCount()).astype(np.float32)
+    onn.buffer(0)[:] = w
+    onn.buffer(1)[:] = w
+    c.SetParams(0, w)
+    c.SetParams(1, w)
+    for step in range(3):
+        x = rng.random((1024, 5), dtype=np.float32)
+        t = rng.random((1024, 3), dtype=np.float32)
+        c.Backward(torch_gpu.from_numpy(x).cuda(), torch_gpu.from_numpy(t).cuda())
+        loss_ref = onn.backward(x, t)
+        assert abs(c.GetLoss() - loss_ref) < 5e-3 * abs(loss_ref)
+        c.OptimizerStep()
+        onn.optimizer_step()
+    w3, w3_ref = c.GetParams(0), np.array(onn.buffer(0))
+    assert rel(w3 - w, w3_ref - w) < 3e-2                     # the update itself, not just the weights
+    assert rel(c.GetParams(1), np.array(onn.buffer(1))) < 1e-3
+    assert not np.allclose(w3, w)
+    c.Destroy()
+
+
 def test_unsupported_configurations_fail_loudly(api, torch_gpu):
-    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_depth=0), dict(optimizer="SGD"),
+    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_depth=0), dict(optimizer="Shampoo"),
                dict(loss_fn="Huber")):
         with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
             api.NeuralRadianceCache(api.AppConfig(**kw))

@@ -142,6 +142,27 @@ def test_optimizer_matches_torch_adam(orc):
     assert not np.array_equal(nn.buffer(0), w0)
 
 
+def test_optimizer_sgd_matches_torch(orc):
+    """EMA{SGD} (tiny-cuda-nn sgd.h: l2_reg 1e-8, no momentum) against torch.optim.SGD and the float64 EMA recursion"""
+    nn = orc.nn_create(lr=0.05, ema_decay=0.99, optimizer="SGD")
+    w0 = np.array(nn.buffer(0))
+    p = torch.from_numpy(w0.copy()).requires_grad_(True)
+    opt = torch.optim.SGD([p], lr=0.05, weight_decay=1e-8)
+    rng = np.random.default_rng(4)
+    ema64 = w0.astype(np.float64)
+    for step in range(1, 4):
+        g = (rng.standard_normal(nn.n_params) * 1e-2).astype(np.float32)
+        nn.buffer(4)[:] = g
+        nn.optimizer_step()
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        d = 0.99
+        ema64 = (ema64 * d * (1 - d ** (step - 1)) + np.array(nn.buffer(0), np.float64) * (1 - d)) / (1 - d ** step)
+        assert np.allclose(nn.buffer(0), p.detach().numpy(), atol=1e-7, rtol=0)
+        assert np.allclose(nn.buffer(1), ema64, atol=1e-6, rtol=0)
+    assert not np.array_equal(nn.buffer(0), w0)
+
+
 def test_training_reduces_loss(orc):
     nn = orc.nn_create(lr=0.01)
     x = queries(256, seed=5, nan_frac=0.0)
