@@ -656,7 +656,7 @@ __device__ __forceinline__ void hg_corners(const HashLevels& lv, uint32_t level,
 // 16 lanes per sample, one level each (64 contiguous bytes of features per sample); lane 0 also writes the direction encoding
 template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ in, const uint32_t* __restrict__ table16,
-                                                    half_t* __restrict__ feat, uint32_t n, HashLevels lv)
+                                                    half_t* __restrict__ feat, uint32_t n, HashLevels lv, int skip_zero)
 {
     constexpr int ND = DIR == 1 ? 2 : 8, E16 = 48;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
@@ -664,16 +664,20 @@ __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ i
     if (sample >= n) return;
     const float* p = in + (size_t)sample * 5u;
     const float x[3] = {p[0], p[1], p[2]};
-    uint32_t idx[8];
-    float w8[8];
-    hg_corners(lv, level, x, idx, w8);
     float r0 = 0.0f, r1 = 0.0f;
+    // renderer inference: the query of a pixel that did not scatter is all zero and its output is never read -- no gathers
+    const bool unused = skip_zero != 0 && x[0] == 0.0f && x[1] == 0.0f && x[2] == 0.0f && p[3] == 0.0f && p[4] == 0.0f;
+    if (!unused) {
+        uint32_t idx[8];
+        float w8[8];
+        hg_corners(lv, level, x, idx, w8);
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const uint32_t v = table16[idx[c]];
-        const half2v hv = __builtin_bit_cast(half2v, v);
-        r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
-        r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
+        for (int c = 0; c < 8; c++) {
+            const uint32_t v = table16[idx[c]];
+            const half2v hv = __builtin_bit_cast(half2v, v);
+            r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
+            r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
+        }
     }
     half_t* o = feat + (size_t)sample * E16;
     o[2 * level] = (half_t)r0;
@@ -740,7 +744,8 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 
 template <int WIDTH>
 __global__ __launch_bounds__(256) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
-                                                  const uint4* __restrict__ img, int depth, int ks0)
+                                                  const uint4* __restrict__ img, int depth, int ks0,
+                                                  const float* __restrict__ skip_in)
 {
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -751,6 +756,14 @@ __global__ __launch_bounds__(256) void k_infer_gen(const half_t* __restrict__ fe
     for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
         const uint32_t sidx = tile * 32u + r;
         const bool valid = sidx < n;
+        if (skip_in != nullptr) {      // renderer inference: a tile whose 32 queries are all zero (unscattered pixels) is skipped
+            bool used = false;
+            if (valid) {
+                const float* q = skip_in + (size_t)sidx * 5u;
+                used = q[0] != 0.0f || q[1] != 0.0f || q[2] != 0.0f || q[3] != 0.0f || q[4] != 0.0f;
+            }
+            if (__ballot(used) == 0ull) continue;
+        }
         const half_t* fp = feat + (size_t)(valid ? sidx : n - 1u) * e16 + 8 * h;
         f32x16 acc[MTG];
 #pragma unroll
@@ -1228,7 +1241,7 @@ void Mlp::repack(hipStream_t s)
 
 // generic-path encoding launch: HashGrid gathers from the fp16 table copy that belongs to the weight set in use
 // `slot` 0 = inference, 1 = training: the two may run concurrently on different streams and own separate feature buffers
-void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s)
+void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero)
 {
     ensure_features(n, slot);
     half_t* feat = (half_t*)d_feat_[slot];
@@ -1240,9 +1253,9 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
     const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_[infer_set_] : d_t16_train_);
     const dim3 g(ceil_div(n * 16u, 256));
-    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv);
-    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, feat, n, lv);
-    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv);
+    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
+    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
+    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
 }
 
 static int g_num_cus = 0;
@@ -1284,16 +1297,17 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     if (n == 0) return;
     const uint4* img = (const uint4*)(use_ema ? d_pk_infer_[infer_set_] : d_pk_fwd_);
     if (!fused_) {
-        launch_features(d_in, n, use_ema, 0, s);
+        launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
+        const float* skip_in = skip_zero_queries ? d_in : nullptr;
         uint32_t blocks = ceil_div(ceil_div(n, 32), 4);
         const uint32_t cap = (uint32_t)num_cus() * 8u;
         if (blocks > cap) blocks = cap;
         if (width_ == 64)
             hipLaunchKernelGGL(k_infer_gen<64>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_[0], d_out, n, img, (int)depth_,
-                               (int)enc_dims_ / 16);
+                               (int)enc_dims_ / 16, skip_in);
         else
             hipLaunchKernelGGL(k_infer_gen<128>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_[0], d_out, n, img, (int)depth_,
-                               (int)enc_dims_ / 16);
+                               (int)enc_dims_ / 16, skip_in);
         NRC_HIP(hipGetLastError());
         return;
     }
@@ -1442,7 +1456,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
                            (const uint4*)d_pk_bwd_);
     } else {
-        launch_features(d_in, n, false, 1, s);
+        launch_features(d_in, n, false, 1, s, false);
         if (hash_) NRC_HIP(hipMemsetAsync(d_grad_ + n_mlp_, 0, (size_t)n_grid_entries_ * 2 * sizeof(float), s));
         TrainArgsGen a;
         a.feat = (const half_t*)d_feat_[1];

@@ -41,7 +41,7 @@ public:
 private:
     void ensure_train_workspace(uint32_t n);
     void ensure_features(uint32_t n, int slot);
-    void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s);
+    void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero);
     void infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
                           const void* image);
 
