@@ -198,6 +198,9 @@ struct SceneDev {
         if (!s.density || s.nx == 0 || s.ny == 0 || s.nz == 0) fail("scene has no density volume");
         if (!(s.density_factor > 0.0f)) fail("scene density factor must be positive");
         const size_t nvox = (size_t)s.nx * s.ny * s.nz;
+        // the kernels index voxels with 24-bit multiply-adds and read them through a raw buffer whose out-of-range offset is 2^31
+        if (s.nx >= (1u << 24) || (size_t)s.ny * s.nz >= ((size_t)1 << 24) || nvox >= ((size_t)1 << 31))
+            fail("density volume too large (needs nx < 2^24, ny*nz < 2^24 and fewer than 2^31 voxels)");
         NRC_HIP(hipMalloc(&d_density, nvox));
         NRC_HIP(hipMemcpy(d_density, s.density, nvox, hipMemcpyHostToDevice));
         d.density = (const uint8_t*)d_density;

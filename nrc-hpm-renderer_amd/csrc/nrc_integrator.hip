@@ -188,6 +188,15 @@ __device__ __forceinline__ void find_entry_exit(Ctx& c, V3 ro, V3 rd, V3* entry,
     *exit_ = ro;
 }
 
+// a * b + c on the full-rate 24-bit multiplier (hipcc turns __umul24 of an unbounded operand back into a quarter-rate 32-bit
+// multiply); exact when a, b < 2^24 and the result fits 32 bits -- guaranteed by the size checks at scene upload
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 // volume.glsl:31-39; sampler: R8 UNORM, NEAREST, CLAMP_TO_BORDER black (src/Texture3D.cpp:79-81,221).
 // One byte per voxel, fetched with a 32-bit voxel index (24-bit mads); the per-axis border test is branch-free and
 // out-of-range lanes read voxel 0 and discard it.
@@ -201,8 +210,7 @@ __device__ __forceinline__ float get_density(Ctx& c, V3 p)
     c.fetches++;
     const bool inb = (fx >= 0.0f) & (fx < s.fnx) & (fy >= 0.0f) & (fy < s.fny) & (fz >= 0.0f) & (fz < s.fnz);
     const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
-    uint32_t idx = __umul24(iz, s.ny) + iy;
-    idx = idx * s.nx + ix;
+    uint32_t idx = mad24(mad24(iz, s.ny, iy), s.nx, ix);
     idx = inb ? idx : 0u;
     const uint8_t t = s.density[idx];
     const float d = s.density_factor * ((float)t * (1.0f / 255.0f));
@@ -224,10 +232,8 @@ __device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, f
     // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
     const bool in0 = max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u;
     const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
-    uint32_t idx0 = __umul24((uint32_t)fz.x, s.ny) + (uint32_t)fy.x;
-    uint32_t idx1 = __umul24((uint32_t)fz.y, s.ny) + (uint32_t)fy.y;
-    idx0 = idx0 * s.nx + (uint32_t)fx.x;
-    idx1 = idx1 * s.nx + (uint32_t)fx.y;
+    uint32_t idx0 = mad24(mad24((uint32_t)fz.x, s.ny, (uint32_t)fy.x), s.nx, (uint32_t)fx.x);
+    uint32_t idx1 = mad24(mad24((uint32_t)fz.y, s.ny, (uint32_t)fy.y), s.nx, (uint32_t)fx.y);
     idx0 = in0 ? idx0 : 0x80000000u;
     idx1 = in1 ? idx1 : 0x80000000u;
     const uint8_t b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx0, 0, 0);
