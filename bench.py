@@ -137,7 +137,13 @@ def main():
     nrc = api.NeuralRadianceCache(cfg)
     ren = api.NrcHpmRenderer(local_w, gh, True, cam, cfg, scene, nrc, tile=tile)
     if use_dist and args.train:
-        parallel.attach_gradient_allreduce(nrc, world)      # RCCL all-reduce of the MLP gradients every training step
+        # RCCL all-reduce of the MLP gradients every training step: issued by the library itself on its training stream; if the
+        # library cannot bring up its own communicator the same exchange goes through torch.distributed's RCCL communicator
+        try:
+            parallel.attach_gradient_allreduce(nrc, world)
+        except RuntimeError as e:
+            print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
+            parallel.attach_gradient_allreduce(nrc, world, native=False)
     randoms = sc.frame_randoms((args.steps + args.warmup) * spp + 8, seed=1337)
     ri = [0]
 

@@ -348,6 +348,7 @@ public:
         // HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4): a same-priority second stream
         // can land on the queue of the first one (observed under torch.distributed, where RCCL owns several streams) and then
         // nothing overlaps.  A high-priority stream comes from a separate queue pool.
+        dense_infer_ = getenv("NRC_DENSE_INFER") != nullptr;      // diagnostic: run the network on unscattered pixels too
         if (!getenv("NRC_SINGLE_STREAM")) {
             int lo = 0, hi = 0;
             NRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -437,7 +438,7 @@ public:
         cache_.bind((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
                     (float*)d_train_target_);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
-        cache_.infer_all(nullptr, Cs, !getenv("NRC_DENSE_INFER"));
+        cache_.infer_all(nullptr, Cs, !dense_infer_);
         NRC_HIP(hipEventRecord(ev_[3], Cs));
         NRC_HIP(hipEventRecord(ev_infer_done_[pp], Cs));
         if (train) cache_.train_all(B, (B != Cs && frame_index_ > 0) ? ev_infer_done_[pp ^ 1] : nullptr);
@@ -633,6 +634,7 @@ private:
     float pinned_random_[4] = {0, 0, 0, 0};
     bool have_pinned_random_ = false;
     bool count_fetches_ = false;
+    bool dense_infer_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------------- McRenderer
