@@ -226,6 +226,19 @@ def main():
         if os.path.exists(tf) and (W, H, args.volume, world) == (1920, 1080, 256, 1):
             with open(tf) as f:
                 traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
+        # VALU issue utilisation of k_gen_rays from the committed SQ counter pass (profiles/r01_pmc_sq_counters.txt): busy
+        # quad-cycles x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the bound that actually limits the integrator
+        valu_busy = None
+        sq = os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.txt")
+        if os.path.exists(sq) and (W, H, args.volume, world) == (1920, 1080, 256, 1):
+            vals, on = {}, False
+            for line in open(sq):
+                if not line.startswith(" "):
+                    on = line.startswith("k_gen_rays")
+                elif on and len(line.split()) == 2:
+                    vals[line.split()[0]] = float(line.split()[1])
+            if "SQ_ACTIVE_INST_VALU" in vals and vals.get("GRBM_GUI_ACTIVE"):
+                valu_busy = vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         dominant_is_gen = gen_ms >= mlp_ms
         roof_mlp = dict(bound="mfma", kernel="k_infer (fused encode + 6x64 MLP)", achieved=mlp_tflops, peak=MFMA_F16_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=traffic.get("k_infer"),
@@ -238,7 +251,7 @@ def main():
                         achieved=gen_bytes / (gen_ms * 1e-3) / 1e9 if gen_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(gen_bytes / (gen_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0,
                         traffic=traffic.get("k_gen_rays"), algorithmic_bytes=gen_bytes,
-                        ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px)
+                        ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px, valu_issue_busy_pmc=valu_busy)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -120,6 +120,7 @@ public:
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_renderer_set_camera(h_, camera)); }
     void SetBlend(bool blend) { nrc_check(nrc_renderer_set_blend(h_, blend ? 1 : 0)); }
     void SetSceneParams(const nrc_scene& scene) { nrc_check(nrc_renderer_set_scene_params(h_, &scene)); }   // HpmScene::Update
+    nrc_renderer_t* Handle() const { return h_; }
 
 private:
     nrc_renderer_t* h_ = nullptr;
@@ -147,6 +148,7 @@ public:
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_mc_renderer_set_camera(h_, camera)); }
     void SetBlend(bool blend) { nrc_check(nrc_mc_renderer_set_blend(h_, blend ? 1 : 0)); }
     void SetSceneParams(const nrc_scene& scene) { nrc_check(nrc_mc_renderer_set_scene_params(h_, &scene)); }
+    nrc_mc_renderer_t* Handle() const { return h_; }
 
 private:
     nrc_mc_renderer_t* h_ = nullptr;

@@ -56,3 +56,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "nrc_oracle" not in txt, f
+
+
+def test_headers_compile_standalone():
+    """include/nrc_hpm.h is plain C99 and include/nrc_hpm.hpp is self-contained C++17 (no HIP, no torch in the boundary)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = "-I" + os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", inc,
+                           os.path.join(root, "tests", "cpp", "header_check.c")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", inc,
+                           os.path.join(root, "tests", "cpp", "header_check.cpp")])
+
