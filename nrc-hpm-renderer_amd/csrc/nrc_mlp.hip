@@ -547,7 +547,7 @@ __device__ __forceinline__ void oneblob4(float xd, float (&out)[4])
 // one thread per sample; features in tiny-cuda-nn order: position encoding (dims 0-2) then direction encoding (dims 3-4).
 // POS / DIR are compile-time so that every feature has a static slot.
 template <int POS, int DIR>
-__global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, half_t* __restrict__ feat, uint32_t n)
+__global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, half_t* __restrict__ feat, uint32_t n, int skip_zero)
 {
     constexpr int NP = POS == 3 ? 72 : (POS == 1 ? 3 : 36);
     constexpr int ND = DIR == 1 ? 2 : 8;
@@ -557,6 +557,9 @@ __global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, ha
     float x[5];
 #pragma unroll
     for (int d = 0; d < 5; d++) x[d] = in[(size_t)i * 5u + d];
+    // renderer inference: the all-zero query of an unscattered pixel gets no features -- its MFMA column is computed from
+    // whatever the buffer holds (columns are independent) and its output is never read; saves 64 % of this kernel's stores
+    if (skip_zero != 0 && x[0] == 0.0f && x[1] == 0.0f && x[2] == 0.0f && x[3] == 0.0f && x[4] == 0.0f) return;
     half_t* o = feat + (size_t)i * E16;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -595,18 +598,19 @@ __global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, ha
 }
 
 template <int POS>
-static void launch_encode_pos(uint32_t dir_id, dim3 g, hipStream_t s, const float* in, half_t* feat, uint32_t n)
+static void launch_encode_pos(uint32_t dir_id, dim3 g, hipStream_t s, const float* in, half_t* feat, uint32_t n, int skip)
 {
-    if (dir_id == 0) hipLaunchKernelGGL((k_encode<POS, 0>), g, dim3(256), 0, s, in, feat, n);
-    else if (dir_id == 1) hipLaunchKernelGGL((k_encode<POS, 1>), g, dim3(256), 0, s, in, feat, n);
-    else hipLaunchKernelGGL((k_encode<POS, 2>), g, dim3(256), 0, s, in, feat, n);
+    if (dir_id == 0) hipLaunchKernelGGL((k_encode<POS, 0>), g, dim3(256), 0, s, in, feat, n, skip);
+    else if (dir_id == 1) hipLaunchKernelGGL((k_encode<POS, 1>), g, dim3(256), 0, s, in, feat, n, skip);
+    else hipLaunchKernelGGL((k_encode<POS, 2>), g, dim3(256), 0, s, in, feat, n, skip);
 }
-static void launch_encode(uint32_t pos_id, uint32_t dir_id, hipStream_t s, const float* in, half_t* feat, uint32_t n)
+static void launch_encode(uint32_t pos_id, uint32_t dir_id, hipStream_t s, const float* in, half_t* feat, uint32_t n, bool skip_zero)
 {
     const dim3 g(ceil_div(n, 256));
-    if (pos_id == 3) launch_encode_pos<3>(dir_id, g, s, in, feat, n);
-    else if (pos_id == 1) launch_encode_pos<1>(dir_id, g, s, in, feat, n);
-    else launch_encode_pos<2>(dir_id, g, s, in, feat, n);
+    const int skip = skip_zero ? 1 : 0;
+    if (pos_id == 3) launch_encode_pos<3>(dir_id, g, s, in, feat, n, skip);
+    else if (pos_id == 1) launch_encode_pos<1>(dir_id, g, s, in, feat, n, skip);
+    else launch_encode_pos<2>(dir_id, g, s, in, feat, n, skip);
 }
 
 // ---- HashGrid position encoding (AppConfig posID 0, src/AppConfig.cpp:19-27: 16 levels x 2 features, 2^19 entries per hashed
@@ -742,63 +746,141 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
     return __builtin_bit_cast(half8, v);
 }
 
-template <int WIDTH>
-__global__ __launch_bounds__(256) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
-                                                  const uint4* __restrict__ img, int depth, int ks0,
-                                                  const float* __restrict__ skip_in)
+// Generic inference (any encoding, width 64 / 128, any depth).  The weight image of an 8x128 net (250 KB) does not fit a
+// workgroup's LDS, and fetching every fragment from L2 per 32-sample tile made the kernel L2-bound (7.8 KB per sample).  Here a
+// workgroup (4 waves x NT tiles = 256 samples) streams the image through LDS one layer at a time: while the waves run layer
+// l's MFMAs out of one buffer, layer l+1 arrives in the other one by direct global->LDS loads issued before the MFMAs -- one
+// barrier per layer, no staging registers, 0.5-1 KB of L2 traffic per sample.  Same accumulator-as-
+// operand chain and numerics as k_infer.  skip_in (renderer inference): tiles whose 32 queries are all zero are not computed,
+// a workgroup whose 256 queries are all zero does not even stream the weights.
+template <int WIDTH, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
+                                                      const uint4* __restrict__ img, int depth, int ks0,
+                                                      const float* __restrict__ skip_in)
 {
-    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
+    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, NT = 2, WAVES = THREADS / 64;
+    constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);        // largest stage (layer 0 has ks0 <= 5 k-steps)
+    constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;      // uint4 per thread per stage
+    extern __shared__ uint4 lds_w[];                              // [2][STAGE_FRAGS * 64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = (n + 31u) >> 5;
+    const uint32_t n_groups = (n_tiles + WAVES * NT - 1u) / (WAVES * NT);
     const uint32_t e16 = (uint32_t)ks0 * 16u;
     const int hid_base = MTG * ks0;
-    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
-        const uint32_t sidx = tile * 32u + r;
-        const bool valid = sidx < n;
-        if (skip_in != nullptr) {      // renderer inference: a tile whose 32 queries are all zero (unscattered pixels) is skipped
-            bool used = false;
-            if (valid) {
-                const float* q = skip_in + (size_t)sidx * 5u;
-                used = q[0] != 0.0f || q[1] != 0.0f || q[2] != 0.0f || q[3] != 0.0f || q[4] != 0.0f;
+    // stage st: layer-0 fragments | hidden layer st | output fragments; first fragment and size (in uint4) in the image
+#define NRC_STAGE_FIRST(st) ((st) == 0 ? 0 : hid_base + ((st) - 1) * MTG * KSG)
+#define NRC_STAGE_COUNT(st) (((st) == 0 ? MTG * ks0 : ((st) == depth ? KSG : MTG * KSG)) * 64)
+    // async global -> LDS copy of one stage (global_load_lds_dwordx4: a wave writes 64 x 16 B contiguously = one fragment, which
+    // is exactly the image layout); completion is awaited by the __syncthreads() that ends the current stage
+#define NRC_STAGE_IN(st, buf)                                                                \
+    do {                                                                                     \
+        const uint4* src_ = img + (size_t)NRC_STAGE_FIRST(st) * 64;                          \
+        uint4* dst_ = lds_w + (buf) * (STAGE_FRAGS * 64);                                    \
+        const int cnt_ = NRC_STAGE_COUNT(st);                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < PF; k_++) {                                  \
+            const int i_ = k_ * THREADS + (int)threadIdx.x;                                  \
+            if (i_ < cnt_)                                                                   \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + i_),       \
+                                                 (__attribute__((address_space(3))) void*)(dst_ + i_), 16, 0, 0); \
+        }                                                                                    \
+    } while (0)
+
+    int q = 0;                       // stage counter: stage data lives in buffer q & 1
+    NRC_STAGE_IN(0, 0);
+    __syncthreads();
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        uint32_t sidx[NT];
+        bool valid[NT], run[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint32_t tile = (group * WAVES + (uint32_t)wave) * NT + (uint32_t)t;
+            sidx[t] = tile * 32u + (uint32_t)r;
+            valid[t] = sidx[t] < n;
+            bool used = valid[t];
+            if (skip_in != nullptr && valid[t]) {
+                const float* qv = skip_in + (size_t)sidx[t] * 5u;
+                used = qv[0] != 0.0f || qv[1] != 0.0f || qv[2] != 0.0f || qv[3] != 0.0f || qv[4] != 0.0f;
             }
-            if (__ballot(used) == 0ull) continue;
+            run[t] = __ballot(used) != 0ull;          // wave-uniform
         }
-        const half_t* fp = feat + (size_t)(valid ? sidx : n - 1u) * e16 + 8 * h;
-        f32x16 acc[MTG];
-#pragma unroll
-        for (int m = 0; m < MTG; m++) acc[m] = zero16();
-        for (int s = 0; s < ks0; s++) {
-            const half8 b0 = *reinterpret_cast<const half8*>(fp + 16 * s);
-#pragma unroll
-            for (int m = 0; m < MTG; m++) acc[m] = mfma(ld_frag_g(img, m * ks0 + s, lane), b0, acc[m]);
-        }
-        half8 b[KSG];
-#pragma unroll
-        for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
+        const bool wave_runs = run[0] || run[1];
+        if (__syncthreads_or(wave_runs ? 1 : 0) == 0) continue;       // nothing to do for this group: stage 0 stays staged
+
+        f32x16 acc[NT][MTG];
+        half8 b[NT][KSG];
 #pragma unroll 1
-        for (int l = 1; l < depth; l++) {
-            const int base = hid_base + (l - 1) * MTG * KSG;
+        for (int st = 0; st <= depth; st++) {
+            const uint4* lw = lds_w + (q & 1) * (STAGE_FRAGS * 64);
+            const bool last = st == depth;
+            const bool more = !last || group + gridDim.x < n_groups;       // next stage to stream (stage 0 of the next group)
+            const int next = last ? 0 : st + 1;
+            if (more) NRC_STAGE_IN(next, (q + 1) & 1);
+            if (wave_runs) {
+                if (st == 0) {
 #pragma unroll
-            for (int m = 0; m < MTG; m++) {
-                acc[m] = zero16();
+                    for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int s = 0; s < KSG; s++) acc[m] = mfma(ld_frag_g(img, base + m * KSG + s, lane), b[s], acc[m]);
+                        for (int m = 0; m < MTG; m++) acc[t][m] = zero16();
+#pragma unroll 1
+                    for (int k = 0; k < ks0; k++) {
+                        half8 b0[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            b0[t] = *reinterpret_cast<const half8*>(feat + (size_t)(valid[t] ? sidx[t] : n - 1u) * e16 + 8 * h + 16 * k);
+#pragma unroll
+                        for (int m = 0; m < MTG; m++) {
+                            const half8 a = ld_frag(lw, m * ks0 + k, lane);
+#pragma unroll
+                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, b0[t], acc[t][m]);
+                        }
+                    }
+                } else if (!last) {
+#pragma unroll
+                    for (int m = 0; m < MTG; m++) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++) acc[t][m] = zero16();
+#pragma unroll
+                        for (int k = 0; k < KSG; k++) {
+                            const half8 a = ld_frag(lw, m * KSG + k, lane);
+#pragma unroll
+                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, b[t][k], acc[t][m]);
+                        }
+                    }
+                } else {
+                    f32x16 y[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) y[t] = zero16();
+#pragma unroll
+                    for (int k = 0; k < KSG; k++) {
+                        const half8 a = ld_frag(lw, k, lane);
+#pragma unroll
+                        for (int t = 0; t < NT; t++) y[t] = mfma(a, b[t][k], y[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        if (run[t] && valid[t] && h == 0) {
+                            float* o = out + (size_t)sidx[t] * 3u;
+                            o[0] = y[t][0];
+                            o[1] = y[t][1];
+                            o[2] = y[t][2];
+                        }
+                    }
+                }
+                if (!last) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+#pragma unroll
+                        for (int m = 0; m < MTG; m++) relu_pack(acc[t][m], b[t][2 * m], b[t][2 * m + 1]);
+                }
             }
-#pragma unroll
-            for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
-        }
-        f32x16 y = zero16();
-        const int obase = hid_base + (depth - 1) * MTG * KSG;
-#pragma unroll
-        for (int s = 0; s < KSG; s++) y = mfma(ld_frag_g(img, obase + s, lane), b[s], y);
-        if (valid && h == 0) {
-            float* o = out + (size_t)sidx * 3u;
-            o[0] = y[0];
-            o[1] = y[1];
-            o[2] = y[2];
+            __syncthreads();
+            q++;
         }
     }
+#undef NRC_STAGE_FIRST
+#undef NRC_STAGE_COUNT
+#undef NRC_STAGE_IN
 }
 
 struct TrainArgsGen {
@@ -1246,7 +1328,7 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     ensure_features(n, slot);
     half_t* feat = (half_t*)d_feat_[slot];
     if (!hash_) {
-        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, feat, n);
+        launch_encode(cfg_.pos_id, cfg_.dir_id, s, d_in, feat, n, skip_zero);
         return;
     }
     HashLevels lv;
@@ -1299,15 +1381,26 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     if (!fused_) {
         launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
         const float* skip_in = skip_zero_queries ? d_in : nullptr;
-        uint32_t blocks = ceil_div(ceil_div(n, 32), 4);
-        const uint32_t cap = (uint32_t)num_cus() * 8u;
-        if (blocks > cap) blocks = cap;
-        if (width_ == 64)
-            hipLaunchKernelGGL(k_infer_gen<64>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_[0], d_out, n, img, (int)depth_,
-                               (int)enc_dims_ / 16, skip_in);
-        else
-            hipLaunchKernelGGL(k_infer_gen<128>, dim3(blocks), dim3(256), 0, s, (const half_t*)d_feat_[0], d_out, n, img, (int)depth_,
-                               (int)enc_dims_ / 16, skip_in);
+        if (width_ == 64) {                  // 4 waves x 2 tiles = 256 samples per workgroup pass, 20 KB of LDS
+            uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
+            const uint32_t cap = (uint32_t)num_cus() * 4u;
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL((k_infer_gen<64, 256>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0], d_out,
+                               n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+        } else {                             // 8 waves x 2 tiles = 512 samples per pass, 64 KB of LDS, one workgroup per CU
+            uint32_t blocks = ceil_div(ceil_div(n, 32), 16);
+            const uint32_t cap = (uint32_t)num_cus();
+            if (blocks > cap) blocks = cap;
+            const size_t lds = 2 * 32 * 1024;
+            static bool attr_set = false;
+            if (!attr_set) {
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_infer_gen<128, 512>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n, img,
+                               (int)depth_, (int)enc_dims_ / 16, skip_in);
+        }
         NRC_HIP(hipGetLastError());
         return;
     }
