@@ -706,6 +706,54 @@ __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ i
     }
 }
 
+// Inference variant, level-major: blockIdx.y = feature slot (0..15 hash levels, 16.. direction features / padding, one half2
+// each), a thread = one sample.  Workgroups are dispatched slot by slot, so the chip gathers from ONE level's table at a time
+// (2 MB at the default 2^19 entries: resident in every XCD's 4 MB L2) instead of from all 16 at once (28 MB, every gather a
+// fabric round trip for 4 useful bytes).  Output layout [slot][n] half2 -- coalesced stores; k_infer_gen<..., true> builds its
+// layer-0 operands from it.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict__ in, const uint32_t* __restrict__ table16,
+                                                       uint32_t* __restrict__ feat_lm, uint32_t n, HashLevels lv, int skip_zero)
+{
+    constexpr int ND = DIR == 1 ? 2 : 8;
+    const uint32_t sample = blockIdx.x * 256u + threadIdx.x, slot = blockIdx.y;
+    if (sample >= n) return;
+    const float* p = in + (size_t)sample * 5u;
+    const float x[3] = {p[0], p[1], p[2]};
+    const float d0 = p[3], d1 = p[4];
+    const bool unused = skip_zero != 0 && x[0] == 0.0f && x[1] == 0.0f && x[2] == 0.0f && d0 == 0.0f && d1 == 0.0f;
+    if (unused) return;                  // unscattered pixel: its column of the MLP is never read
+    float r0 = 1.0f, r1 = 1.0f;          // padding slots hold ones
+    if (slot < HG_LEVELS) {
+        uint32_t idx[8];
+        float w8[8];
+        hg_corners(lv, slot, x, idx, w8);
+        r0 = 0.0f; r1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const half2v hv = __builtin_bit_cast(half2v, table16[idx[c]]);
+            r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
+            r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
+        }
+    } else {
+        const int k0 = 2 * ((int)slot - (int)HG_LEVELS);         // direction feature index of r0 (r1 = k0 + 1)
+        if (k0 < ND) {
+            if (DIR == 0) {
+                float b[4];
+                oneblob4(k0 < 4 ? d0 : d1, b);
+                r0 = b[k0 & 3]; r1 = b[(k0 & 3) + 1];
+            } else if (DIR == 1) {
+                r0 = d0; r1 = d1;
+            } else {
+                const float v = k0 < 4 ? d0 : d1;
+                r0 = tri_wave(v, k0 & 3); r1 = tri_wave(v, (k0 & 3) + 1);
+            }
+        }
+    }
+    float2v f = {r0, r1};
+    feat_lm[(size_t)slot * n + sample] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2v));
+}
+
 // dL/d(table): every (sample, level) scatters weight * dL/d(feature) to its 8 corners with fp32 atomics (the sum order, hence
 // the last bits, vary from run to run -- unlike the MLP's slab reduction; tiny-cuda-nn uses fp16 atomics here)
 __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
@@ -753,7 +801,7 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 // barrier per layer, no staging registers, 0.5-1 KB of L2 traffic per sample.  Same accumulator-as-
 // operand chain and numerics as k_infer.  skip_in (renderer inference): tiles whose 32 queries are all zero are not computed,
 // a workgroup whose 256 queries are all zero does not even stream the weights.
-template <int WIDTH, int THREADS>
+template <int WIDTH, int THREADS, bool FEAT_LM>
 __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                       const uint4* __restrict__ img, int depth, int ks0,
                                                       const float* __restrict__ skip_in)
@@ -826,8 +874,18 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
                     for (int k = 0; k < ks0; k++) {
                         half8 b0[NT];
 #pragma unroll
-                        for (int t = 0; t < NT; t++)
-                            b0[t] = *reinterpret_cast<const half8*>(feat + (size_t)(valid[t] ? sidx[t] : n - 1u) * e16 + 8 * h + 16 * k);
+                        for (int t = 0; t < NT; t++) {
+                            const size_t si = valid[t] ? sidx[t] : n - 1u;
+                            if (FEAT_LM) {       // [slot][n] half2 (k_encode_hash_lm): features 16k+8h+2i, +1 = slot 8k+4h+i
+                                const uint32_t* fl = reinterpret_cast<const uint32_t*>(feat) + (size_t)(8 * k + 4 * h) * n + si;
+                                uint4v v;
+#pragma unroll
+                                for (int i = 0; i < 4; i++) v[i] = fl[(size_t)i * n];
+                                b0[t] = __builtin_bit_cast(half8, v);
+                            } else {
+                                b0[t] = *reinterpret_cast<const half8*>(feat + si * e16 + 8 * h + 16 * k);
+                            }
+                        }
 #pragma unroll
                         for (int m = 0; m < MTG; m++) {
                             const half8 a = ld_frag(lw, m * ks0 + k, lane);
@@ -1334,6 +1392,14 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     HashLevels lv;
     for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
     const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_[infer_set_] : d_t16_train_);
+    if (slot == 0) {         // inference: level-major gathers and feature layout (k_encode_hash_lm / k_infer_gen<..., true>)
+        const dim3 g(ceil_div(n, 256), enc_dims_ / 2);
+        const int sk = skip_zero ? 1 : 0;
+        if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash_lm<0>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, sk);
+        else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash_lm<1>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, sk);
+        else hipLaunchKernelGGL(k_encode_hash_lm<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, sk);
+        return;
+    }
     const dim3 g(ceil_div(n * 16u, 256));
     if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
     else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
@@ -1385,8 +1451,12 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
             const uint32_t cap = (uint32_t)num_cus() * 4u;
             if (blocks > cap) blocks = cap;
-            hipLaunchKernelGGL((k_infer_gen<64, 256>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0], d_out,
-                               n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            if (hash_)
+                hipLaunchKernelGGL((k_infer_gen<64, 256, true>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0],
+                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            else
+                hipLaunchKernelGGL((k_infer_gen<64, 256, false>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0],
+                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
         } else {                             // 8 waves x 2 tiles = 512 samples per pass, 64 KB of LDS, one workgroup per CU
             uint32_t blocks = ceil_div(ceil_div(n, 32), 16);
             const uint32_t cap = (uint32_t)num_cus();
@@ -1394,12 +1464,18 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             const size_t lds = 2 * 32 * 1024;
             static bool attr_set = false;
             if (!attr_set) {
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512>),
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_set = true;
             }
-            hipLaunchKernelGGL((k_infer_gen<128, 512>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n, img,
-                               (int)depth_, (int)enc_dims_ / 16, skip_in);
+            if (hash_)
+                hipLaunchKernelGGL((k_infer_gen<128, 512, true>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
+                                   img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            else
+                hipLaunchKernelGGL((k_infer_gen<128, 512, false>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
+                                   img, (int)depth_, (int)enc_dims_ / 16, skip_in);
         }
         NRC_HIP(hipGetLastError());
         return;
