@@ -754,10 +754,12 @@ __global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict_
     feat_lm[(size_t)slot * n + sample] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2v));
 }
 
-// dL/d(table): every (sample, level) scatters weight * dL/d(feature) to its 8 corners with fp32 atomics (the sum order, hence
-// the last bits, vary from run to run -- unlike the MLP's slab reduction; tiny-cuda-nn uses fp16 atomics here)
+// dL/d(table): every (sample, level) scatters weight * dL/d(feature) to its 8 corners with one packed fp16 atomic per corner
+// (global_atomic_pk_add_f16 on a half2-per-entry table: tiny-cuda-nn does the same for 2 features per level; the values carry
+// the loss scale).  The sum order, hence the last bits, vary from run to run -- unlike the MLP's slab reduction.
+// k_grid_grad_f32 then widens the table into the fp32 gradient vector (what the all-reduce and the optimizer read).
 __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
-                                                      float* __restrict__ grad_table, uint32_t n, HashLevels lv)
+                                                      uint32_t* __restrict__ grad16, uint32_t n, HashLevels lv)
 {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
@@ -771,9 +773,19 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
     hg_corners(lv, level, x, idx, w8);
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        if (de0 != 0.0f) atomicAdd(grad_table + (size_t)idx[c] * 2u, w8[c] * de0);
-        if (de1 != 0.0f) atomicAdd(grad_table + (size_t)idx[c] * 2u + 1u, w8[c] * de1);
+        const float2v g = {w8[c] * de0, w8[c] * de1};
+        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(grad16 + idx[c]),
+                                                  __builtin_convertvector(g, half2v));
     }
+}
+
+__global__ void k_grid_grad_f32(const uint32_t* __restrict__ grad16, float* __restrict__ grad, uint32_t n_entries)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const half2v h = __builtin_bit_cast(half2v, grad16[i]);
+    grad[2 * (size_t)i] = (float)h[0];
+    grad[2 * (size_t)i + 1] = (float)h[1];
 }
 #pragma clang fp contract(fast)
 
@@ -1336,6 +1348,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     if (hash_) {
         NRC_HIP(hipMalloc(&d_t16_train_, (size_t)n_grid_entries_ * 4));
         for (auto& p : d_t16_ema_) NRC_HIP(hipMalloc(&p, (size_t)n_grid_entries_ * 4));
+        NRC_HIP(hipMalloc(&d_grad16_, (size_t)n_grid_entries_ * 4));
     }
     repack(nullptr);
     NRC_HIP(hipStreamSynchronize(nullptr));
@@ -1345,7 +1358,7 @@ Mlp::~Mlp()
 {
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_[0], d_feat_[1], d_t16_train_,
-                    d_t16_ema_[0], d_t16_ema_[1], d_denc_};
+                    d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -1626,7 +1639,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
                            (const uint4*)d_pk_bwd_);
     } else {
         launch_features(d_in, n, false, 1, s, false);
-        if (hash_) NRC_HIP(hipMemsetAsync(d_grad_ + n_mlp_, 0, (size_t)n_grid_entries_ * 2 * sizeof(float), s));
+        if (hash_) NRC_HIP(hipMemsetAsync(d_grad16_, 0, (size_t)n_grid_entries_ * 4, s));
         TrainArgsGen a;
         a.feat = (const half_t*)d_feat_[1];
         a.target = d_target;
@@ -1649,7 +1662,9 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
             hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
-                               d_grad_ + n_mlp_, n, lv);
+                               (uint32_t*)d_grad16_, n, lv);
+            hipLaunchKernelGGL(k_grid_grad_f32, dim3(ceil_div(n_grid_entries_, 256)), dim3(256), 0, s, (const uint32_t*)d_grad16_,
+                               d_grad_ + n_mlp_, n_grid_entries_);
         }
     }
     NRC_HIP(hipGetLastError());

@@ -60,6 +60,7 @@ private:
     uint32_t n_grid_entries_ = 0;
     void *d_t16_train_ = nullptr, *d_t16_ema_[2] = {nullptr, nullptr};   // half2-per-entry gather copies of the table
     void* d_denc_ = nullptr;     // fp16 [n][32] dL/d(grid features)
+    void* d_grad16_ = nullptr;   // half2 per table entry: target of the packed gradient atomics
 
     float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)
