@@ -359,6 +359,40 @@ def test_full_size_frame_against_reference_exr_statistics(api, sc, cloud16, exr_
     mc.Destroy()
 
 
+def test_full_size_nrc_frame_rows_bitwise_against_oracle(api, orc, sc, cloud16, torch_gpu):
+    """BASELINE size (1920x1080, configs[1]): three bands of rows of the gen_rays outputs -- top edge, image centre through the
+    cloud, bottom edge -- are bit-identical to the oracle (same hash RNG, same specified fp32 math), query buffer included"""
+    W, H = 1920, 1080
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(64, 32))
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, log2_train_batch_size=14, log2_infer_batch_size=21)
+    ren.SetFrameRandom(FRAME_RANDOM)
+    ren.Render(None, False)
+    prim = ren.Buffer("primary").cpu().numpy().reshape(H, W, 4)
+    info = ren.Buffer("info").cpu().numpy().reshape(H, W)
+    q = ren.Buffer("infer_input").cpu().numpy().reshape(W, H, 5)
+    scattered = 0
+    for y0, y1 in ((0, 8), (536, 548), (1072, 1080)):
+        o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, rows=(y0, y1), threads=8)
+        assert np.array_equal(info[y0:y1], o["info"][y0:y1])
+        assert np.array_equal(prim[y0:y1].view(np.uint32), o["primary"][y0:y1].view(np.uint32))
+        oq = o["infer_input"].reshape(W, H, 5)[:, y0:y1]
+        gq = q[:, y0:y1]
+        same = (gq.view(np.uint32) == oq.view(np.uint32)) | (np.isnan(gq) & np.isnan(oq))      # quirk Q5: NaN phi
+        assert same.all()
+        scattered += int(o["info"][y0:y1].sum())
+    assert scattered > 2000
+    ren.Destroy()
+    nrc.Destroy()
+    # the ground-truth renderer (mc/render.comp, PATH_LENGTH 32) at the same size: one band through the cloud
+    mc = api.McHpmRenderer(W, H, 32, False, cam, scene)
+    mc.SetFrameRandom(FRAME_RANDOM)
+    mc.Render()
+    img = mc.GetImage().cpu().numpy()
+    ref, _, _ = orc.mc_render(scene, cam, W, H, 32, FRAME_RANDOM, rows=(540, 546), threads=8)
+    assert np.array_equal(img[540:546].view(np.uint32), ref[540:546].view(np.uint32))
+    mc.Destroy()
+
+
 def test_cli_main_loop_and_benchmark_log(torch_gpu, tmp_path):
     """headless main loop (src/main.cu:248-391): 17 positional args, Render(queue, true) per frame, per-frame
     `frame mse relBias CV` log in `output/ <config name>/log.txt`, EXR export"""
