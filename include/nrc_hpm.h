@@ -182,15 +182,17 @@ const float* nrc_renderer_framebuffer(nrc_renderer_t* r);
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
 /* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be
  * NULL or float[8] = {clear(0), gen_rays, prep_infer(0: fused into gen_rays), train, prep_train, inference, composite,
- * total}.  train-ray generation and training run on a second stream concurrently with inference + compositing, so the
- * stages overlap and do not add up to total. */
+ * total}.  The renderer pipelines frames over four streams (train-ray generation, training, inference + compositing of
+ * frame N run beside gen_rays of frame N+1; DESIGN.md section 4 "Frame graph"), so the stages overlap, include the time they
+ * wait for each other, and do not add up; total = latency of the frame, which exceeds the frame interval. */
 float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
-/* the same stage times averaged over every frame rendered since the last reset (HIP events on the render stream);
+/* the same stage times averaged over every frame rendered since the last reset (HIP events on the renderer's streams);
  * *frames = number of frames covered */
 int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frames, int reset);
 /* NrcHpmRenderer::Destroy */
 int nrc_renderer_destroy(nrc_renderer_t* r);
-/* intermediate device buffers (tests / multi-GPU): 0 primary colour+throughput [h][w][4], 1 primary info [h][w],
+/* intermediate device buffers of the most recent frame, after synchronising all of the renderer's streams (tests /
+ * multi-GPU; the sets rotate, so ask again after every Render): 0 primary colour+throughput [h][w][4], 1 primary info [h][w],
  * 2 nrc ray origin [h][w][4], 3 nrc ray dir [h][w][4], 4 infer input [w*h][5], 5 infer output [w*h][3],
  * 6 train input [T][5], 7 train target [T][3], 8 train ring {head, tail, RayInfo[ring]} */
 void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes);
