@@ -59,7 +59,8 @@ typedef struct nrc_config {
 #define NRC_FIX_Q1_TRAIN_Y_DIST 1u
 #define NRC_FIX_Q2_TRAIN_RAY_LEN 2u
 
-/* fills the defaults of src/main.cu:432-439 with the north-star encoding (posID 3, dirID 0) */
+/* fills the defaults of src/main.cu:432-439, except for the position encoding: posID 3 (Frequency, the north-star model with
+ * the fully fused kernels) instead of the reference's 0 (HashGrid) -- set pos_id = 0 for the reference's exact default */
 void nrc_config_default(nrc_config* cfg);
 
 /* ---------------------------------------------------------------------------------------------------------

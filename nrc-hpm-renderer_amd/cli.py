@@ -2,8 +2,8 @@
 
     python -m nrc_hpm_renderer_amd.cli [17 positional AppConfig args] [--frames N] [--vdb FILE | --volume N] ...
 
-The 17 positional arguments are the reference's (src/AppConfig.cpp:154-182, defaults src/main.cu:432-439 -- with posID 3 as
-default instead of the not-yet-built HashGrid).  Every frame is `NrcHpmRenderer::Render(queue, true)` (src/main.cu:287); with
+The 17 positional arguments are the reference's (src/AppConfig.cpp:154-182); without any, the reference's own defaults apply
+(src/main.cu:428-439: HashGrid position encoding, OneBlob direction encoding, 6x64, 4 train batches of 2^14).  Every frame is `NrcHpmRenderer::Render(queue, true)` (src/main.cu:287); with
 --benchmark each frame is also evaluated like `Benchmark()` (src/main.cu:140-150): the NRC image without training from the same
 camera against a reference image, one line `frame mse relBias CV` in `output/ <config-name>/log.txt` (the literal space is the
 reference's, src/main.cu:240,446).  The reference image is `--reference FILE.exr` or, like Reference::GenRefImages
@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-DEFAULT_ARGV = ["RelativeL2Luminance", "Adam", "0.01", "0.99", "3", "0", "64", "6", "21", "14", "4", "4", "1.0", "1", "1", "0.0", "32"]
+DEFAULT_ARGV = ["RelativeL2Luminance", "Adam", "0.01", "0.99", "0", "0", "64", "6", "21", "14", "4", "4", "1.0", "1", "1", "0.0", "32"]
 
 
 def main(argv=None):
