@@ -110,9 +110,10 @@ def _nrc_setup(api, sc, scene, W, H, **cfg_kw):
     return cfg, nrc, cam, ren
 
 
-def test_gen_rays_and_query_packing_match_oracle(api, orc, sc, cloud16, torch_gpu):
-    """nrc/gen_rays.comp + prep_infer_rays.comp: primary colour/throughput, didScatter, NRC vertex, packed queries"""
-    W, H = 128, 80
+@pytest.mark.parametrize("W,H", [(128, 80), (100, 52), (8, 6)], ids=["128x80", "ragged100x52", "tiny8x6"])
+def test_gen_rays_and_query_packing_match_oracle(api, orc, sc, cloud16, torch_gpu, W, H):
+    """nrc/gen_rays.comp + prep_infer_rays.comp: primary colour/throughput, didScatter, NRC vertex, packed queries; also on
+    frames whose width / height are not multiples of the 8x8 wave tile (partial tiles, odd tile-row counts)"""
     scene = sc.make_scene(cloud16, scene_id=4)
     cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
     ren.SetFrameRandom(FRAME_RANDOM)
@@ -120,15 +121,16 @@ def test_gen_rays_and_query_packing_match_oracle(api, orc, sc, cloud16, torch_gp
     o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
     prim = ren.Buffer("primary").cpu().numpy().reshape(H, W, 4)
     info = ren.Buffer("info").cpu().numpy().reshape(H, W)
-    assert np.array_equal(info, o["info"]) and 0.1 < info.mean() < 0.9
-    assert frac_close(prim.reshape(-1, 4), o["primary"].reshape(-1, 4)) >= 0.995
+    big = W * H >= 4096
+    assert np.array_equal(info, o["info"]) and (not big or 0.1 < info.mean() < 0.9)
+    assert np.array_equal(prim.view(np.uint32), o["primary"].view(np.uint32))        # bit-identical, every pixel
     m = info.reshape(-1) == 1
     org = ren.Buffer("origin").cpu().numpy()
     dr = ren.Buffer("dir").cpu().numpy()
     assert frac_close(org[m], o["origin"].reshape(-1, 4)[m]) >= 0.995 and frac_close(dr[m], o["dir"].reshape(-1, 4)[m]) >= 0.995
     q = ren.Buffer("infer_input").cpu().numpy()
     assert frac_close(q, o["infer_input"]) >= 0.995         # NaN phi (quirk Q5) compares equal_nan
-    assert np.isnan(q[:, 4]).any()                          # the quirk is reproduced
+    assert not big or np.isnan(q[:, 4]).any()               # the quirk is reproduced
     assert (q[lin(info[..., None], W, H)[:, 0] == 0] == 0).all()     # unscattered slots are zero (vkCmdFillBuffer)
     # throughput: 0.25 after two vertices, 0.5 if the second segment left the volume
     thr = prim[..., 3][info == 1]
