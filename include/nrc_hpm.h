@@ -179,6 +179,9 @@ int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float random4[4]);
  * on an internal stream; this call makes the stream passed to nrc_renderer_create wait (on the device) for the latest frame's
  * compositing, so work enqueued on that stream afterwards sees the finished image.  Call it again after every Render. */
 const float* nrc_renderer_framebuffer(nrc_renderer_t* r);
+/* same image, but orders `consumer_stream` (a display or read-back stream of the caller) behind the latest compositing
+ * instead of the render stream: reading every frame then does not hold back the next frame's ray generation */
+const float* nrc_renderer_framebuffer_on(nrc_renderer_t* r, void* consumer_stream);
 /* ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493): scan-line EXR, FLOAT RGBA */
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
 /* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be

@@ -115,6 +115,7 @@ public:
     void ExportOutputImageToFile(void* /*queue*/, const std::string& filePath) const { nrc_check(nrc_renderer_export_exr(h_, filePath.c_str())); }
     void EvaluateTimestampQueries() { (void)nrc_renderer_frame_time_ms(h_, stage_ms_); }
     const float* GetImage() const { return nrc_renderer_framebuffer(h_); }     // RGBA32F [height][width]
+    const float* GetImage(void* consumerStream) const { return nrc_renderer_framebuffer_on(h_, consumerStream); }
     float GetFrameTimeMS() const { return nrc_renderer_frame_time_ms(h_, nullptr); }
     const float* GetStageTimesMS() const { return stage_ms_; }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_renderer_set_camera(h_, camera)); }

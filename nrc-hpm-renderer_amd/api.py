@@ -68,7 +68,8 @@ ABI_SYMBOLS = [
     "nrc_cache_get_step", "nrc_cache_set_step",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
     "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
-    "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_export_exr",
+    "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_framebuffer_on",
+    "nrc_renderer_export_exr",
     "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
     "nrc_renderer_train_grid",
     "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
@@ -104,6 +105,7 @@ def load_library():
     L.nrc_cache_loss_ptr.restype = C.c_void_p
     L.nrc_cache_param_count.restype = C.c_uint32
     L.nrc_renderer_framebuffer.restype = C.c_void_p
+    L.nrc_renderer_framebuffer_on.restype = C.c_void_p
     L.nrc_renderer_buffer.restype = C.c_void_p
     L.nrc_renderer_frame_time_ms.restype = C.c_float
     L.nrc_mc_renderer_framebuffer.restype = C.c_void_p
@@ -134,7 +136,7 @@ def _stream_ptr(stream):
     if stream is None:
         import torch
         stream = torch.cuda.current_stream().cuda_stream
-    return C.c_void_p(int(stream))
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -418,10 +420,14 @@ class NrcHpmRenderer:
         d["frames"] = n.value
         return d
 
-    def GetImage(self):
-        """RGBA32F framebuffer as a torch CUDA tensor view [height, width, 4]."""
+    def GetImage(self, stream=None):
+        """RGBA32F framebuffer as a torch CUDA tensor view [height, width, 4].  The stream given at construction (default) or
+        `stream` (a torch stream / raw handle of the consumer) is ordered behind the frame's compositing."""
         import torch
-        p = self.L.nrc_renderer_framebuffer(self.h)
+        if stream is None:
+            p = self.L.nrc_renderer_framebuffer(self.h)
+        else:
+            p = self.L.nrc_renderer_framebuffer_on(self.h, _stream_ptr(stream))
         return _wrap_device(p, self.width * self.height * 16, torch.float32, (self.height, self.width, 4))
 
     def Buffer(self, name):

@@ -569,10 +569,17 @@ public:
     // it passed in -- a copy, a display blit, CompareImages -- sees the finished frame, as with the reference's single queue.
     const float* framebuffer()
     {
-        if (stream_c_ && frame_index_ > 0)
-            NRC_HIP(hipStreamWaitEvent(stream_, ev_comp_done_[(frame_index_ - 1) % (uint64_t)kGenSets], 0));
+        wait_frame(stream_);
         return (const float*)d_out_;
     }
+    // orders any stream of the caller behind the latest compositing pass: a display / read-back stream can follow the frames
+    // without stalling the render stream (which framebuffer() does)
+    void wait_frame(hipStream_t consumer)
+    {
+        if (stream_c_ && frame_index_ > 0)
+            NRC_HIP(hipStreamWaitEvent(consumer, ev_comp_done_[(frame_index_ - 1) % (uint64_t)kGenSets], 0));
+    }
+    const float* framebuffer_unordered() const { return (const float*)d_out_; }
     const TrainGrid& train_grid() const { return tg_; }
     hipStream_t stream() const { return stream_; }
 
@@ -904,6 +911,13 @@ int nrc_renderer_set_blend(nrc_renderer_t* r, int b) { NRC_REQUIRE(r); r->impl.s
 int nrc_renderer_set_show_nrc(nrc_renderer_t* r, int s) { NRC_REQUIRE(r); r->impl.set_show_nrc(s != 0); return NRC_OK; }
 int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float* v) { NRC_REQUIRE(r); NRC_REQUIRE(v); r->impl.set_frame_random(v); return NRC_OK; }
 const float* nrc_renderer_framebuffer(nrc_renderer_t* r) { return r ? r->impl.framebuffer() : nullptr; }
+const float* nrc_renderer_framebuffer_on(nrc_renderer_t* r, void* consumer_stream)
+{
+    if (!r) return nullptr;
+    const float* p = nullptr;
+    if (guarded([&] { r->impl.wait_frame((hipStream_t)consumer_stream); p = r->impl.framebuffer_unordered(); }) != NRC_OK) return nullptr;
+    return p;
+}
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path) { NRC_REQUIRE(r); NRC_REQUIRE(path); return guarded([&] { r->impl.export_exr(path); }); }
 float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms)
 {

@@ -254,6 +254,35 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
         assert np.array_equal(base[4].view(np.uint32), other[4].view(np.uint32))
 
 
+def test_framebuffer_on_a_consumer_stream(api, sc, cloud16, torch_gpu):
+    """GetImage(stream): a read-back stream of the caller is ordered behind each frame's compositing while the render stream runs
+    ahead; the copies it makes equal the frames of a renderer that is read synchronously"""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    frs = sc.frame_randoms(6, seed=33)
+    side = torch_gpu.cuda.Stream()
+    copies = []
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+    for f in range(6):
+        ren.SetFrameRandom(frs[f])
+        ren.Render(None, True)
+        img = ren.GetImage(side)
+        with torch_gpu.cuda.stream(side):
+            copies.append(img.clone())          # the framebuffer is overwritten by the next frame's compositing
+        side.synchronize()                      # (a real consumer would double-buffer instead of blocking the host)
+    got = [c.cpu().numpy() for c in copies]
+    ren.Destroy()
+    nrc.Destroy()
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+    for f in range(6):
+        ren.SetFrameRandom(frs[f])
+        ren.Render(None, True)
+        ref = ren.GetImage().cpu().numpy()
+        assert np.array_equal(ref.view(np.uint32), got[f].view(np.uint32))
+    ren.Destroy()
+    nrc.Destroy()
+
+
 def test_column_tiles_reproduce_the_whole_frame(api, sc, cloud16, torch_gpu):
     """pixel-tile sharding: N interleaved column tiles == the single-GPU frame, bit for bit (integrator)"""
     from nrc_hpm_renderer_amd import parallel
