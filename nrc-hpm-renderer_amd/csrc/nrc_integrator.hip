@@ -118,7 +118,14 @@ __device__ unsigned long long g_wave_times[4 * 65536];
 #define NRC_PROF(c, k)                                                                    \
     do {                                                                                  \
         (c).useful[k]++;                                                                  \
-        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) (c).issued[k] += 64u; \
+        const unsigned long long m_ = __ballot(1);                                        \
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1) {                     \
+            (c).issued[k] += 64u;                                                         \
+            if ((k) == 2 || (k) == 3) {      /* tracking loops: trips issued with <= 32 / <= 16 lanes active (kinds 6, 7) */ \
+                if (__popcll(m_) <= 32) (c).issued[6] += 64u;                             \
+                if (__popcll(m_) <= 16) (c).issued[7] += 64u;                             \
+            }                                                                             \
+        }                                                                                 \
     } while (0)
 #else
 #define NRC_PROF(c, k) do { } while (0)
@@ -536,7 +543,6 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_gen_rays(DevSce
         V3 entry, ex;
 #ifdef NRC_LOOP_PROFILE
         c.fee_kind = 0;
-        NRC_PROF(c, 6);
 #endif
         find_entry_exit(c, ro, rd, &entry, &ex);
 #ifdef NRC_LOOP_PROFILE

@@ -43,9 +43,13 @@ def main():
     assert L.nrc_debug_loop_profile(out, 0) == 0
     px = W * H * frames
     print("%-28s %14s %14s %8s %12s" % ("kind", "useful", "issued", "util", "issued/px"))
-    for k, name in enumerate(KINDS[:7]):
+    for k, name in enumerate(KINDS[:6]):
         u, i = out[k], out[8 + k]
         print("%-28s %14d %14d %8.3f %12.2f" % (name, u, i, u / max(i, 1), i / px))
+    trk = out[8 + 2] + out[8 + 3]
+    if trk:
+        print("tracking-loop trips issued with <= 32 lanes active: %.1f %%, with <= 16: %.1f %% (issued kinds 6/7 of the "
+              "counter build)" % (100.0 * out[8 + 6] / trk, 100.0 * out[8 + 7] / trk))
 
 
     # occupancy over time of the last gen_rays launch (one 8x8 tile per wave)
