@@ -39,7 +39,7 @@ typedef struct nrc_config {
     float ema_decay;
     uint32_t pos_id;               /* 0 HashGrid(16x2, 2^19) | 1 Identity | 2 TriangleWave-12 | 3 Frequency-12 */
     uint32_t dir_id;               /* 0 OneBlob-4 | 1 Identity | 2 TriangleWave-4 */
-    uint32_t nn_width;             /* 64 */
+    uint32_t nn_width;             /* 64 (32, 64, 128) */
     uint32_t nn_depth;             /* n_hidden_layers, 6 */
     uint32_t log2_infer_batch_size;
     uint32_t log2_train_batch_size;

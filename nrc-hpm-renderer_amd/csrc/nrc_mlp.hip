@@ -1237,7 +1237,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     width_ = cfg.nn_width;
     depth_ = cfg.nn_depth;
     if (pos_enc_dims(cfg.pos_id) == 0 || dir_enc_dims(cfg.dir_id) == ~0u) fail("NNEncodingConfig posID/dirID is invalid");
-    if (width_ != 64 && width_ != 128) fail("nnWidth must be 64 or 128 (got " + std::to_string(width_) + ")");
+    if (width_ != 32 && width_ != 64 && width_ != 128) fail("nnWidth must be 32, 64 or 128 (got " + std::to_string(width_) + ")");
     if (depth_ < 1 || depth_ > 16) fail("nnDepth must be in 1..16 (got " + std::to_string(depth_) + ")");
     if (std::strcmp(cfg.optimizer, "Adam") == 0) sgd_ = false;
     else if (std::strcmp(cfg.optimizer, "SGD") == 0) sgd_ = true;
@@ -1460,7 +1460,17 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     if (!fused_) {
         launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
         const float* skip_in = skip_zero_queries ? d_in : nullptr;
-        if (width_ == 64) {                  // 4 waves x 2 tiles = 256 samples per workgroup pass, 20 KB of LDS
+        if (width_ == 32) {
+            uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
+            const uint32_t cap = (uint32_t)num_cus() * 4u;
+            if (blocks > cap) blocks = cap;
+            if (hash_)
+                hipLaunchKernelGGL((k_infer_gen<32, 256, true>), dim3(blocks), dim3(256), 2 * 5 * 1024, s, (const half_t*)d_feat_[0],
+                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            else
+                hipLaunchKernelGGL((k_infer_gen<32, 256, false>), dim3(blocks), dim3(256), 2 * 5 * 1024, s, (const half_t*)d_feat_[0],
+                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+        } else if (width_ == 64) {           // 4 waves x 2 tiles = 256 samples per workgroup pass, 20 KB of LDS
             uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
             const uint32_t cap = (uint32_t)num_cus() * 4u;
             if (blocks > cap) blocks = cap;
@@ -1654,7 +1664,9 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
         const uint32_t cap = (uint32_t)num_cus() * 4u;
         if (blocks > cap) blocks = cap;
-        if (width_ == 64)
+        if (width_ == 32)
+            hipLaunchKernelGGL(k_train_gen<32>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+        else if (width_ == 64)
             hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
         else
             hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);

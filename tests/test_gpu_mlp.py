@@ -249,7 +249,7 @@ def test_sgd_optimizer_matches_oracle(api, orc, torch_gpu, model):
 
 
 def test_unsupported_configurations_fail_loudly(api, torch_gpu):
-    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_depth=0), dict(optimizer="Shampoo"),
+    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_width=16), dict(nn_depth=0), dict(optimizer="Shampoo"),
                dict(loss_fn="Huber")):
         with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
             api.NeuralRadianceCache(api.AppConfig(**kw))
@@ -271,6 +271,7 @@ def test_full_size_inference_properties(cache, orc, torch_gpu):
 
 GENERIC = [  # (posID, dirID, width, depth): everything except the fused 3/0/64/6 model runs the generic kernels
     (1, 0, 64, 6), (2, 2, 64, 4), (3, 1, 64, 2), (3, 0, 64, 5), (3, 0, 128, 8), (1, 1, 128, 3), (2, 0, 128, 1),
+    (3, 0, 32, 4), (2, 1, 32, 2),
 ]
 
 
