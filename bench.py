@@ -38,7 +38,7 @@ def global_frame(n_gpus, w, h):
     return (n_gpus * w, h)
 
 
-def cpu_baseline(scene, W, H, budget_s=20.0):
+def cpu_baseline(scene, W, H, budget_s=float(os.environ.get("NRC_BENCH_CPU_BUDGET_S", "20"))):
     """The reference has no CPU renderer (McHpmRenderer dispatches mc/render.comp, src/McHpmRenderer.cpp:93,875):
     the baseline is the oracle's restatement of mc/render.comp (PATH_LENGTH 32) on this box's host cores."""
     import numpy as np

@@ -1,0 +1,33 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (task contract): metric / value / unit / n_gpus / steps /
+warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, plus `roofline` for the
+dominant kernel and `cpu_baseline`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_line(torch_gpu):
+    env = dict(os.environ, NRC_BENCH_CPU_BUDGET_S="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "Msamples/s" and d["value"] > 100 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "1920x1080" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["ms_per_step"] - 1920 * 1080 * 4 / d["value"] / 1e3) < 1e-6 * d["ms_per_step"] + 1e-9
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof
+    assert 0.2 < d["roofline_mlp"]["frac"] < 0.7
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "Msamples/s" and cpu["sample"]
+    assert d["value"] / cpu["value"] >= 10        # north star: >= 10x the CPU McHpmRenderer path
