@@ -851,7 +851,7 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
     __syncthreads();
     for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
         uint32_t sidx[NT];
-        bool valid[NT], run[NT];
+        bool valid[NT], run[NT], mine[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const uint32_t tile = (group * WAVES + (uint32_t)wave) * NT + (uint32_t)t;
@@ -862,6 +862,7 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
                 const float* qv = skip_in + (size_t)sidx[t] * 5u;
                 used = qv[0] != 0.0f || qv[1] != 0.0f || qv[2] != 0.0f || qv[3] != 0.0f || qv[4] != 0.0f;
             }
+            mine[t] = used;                           // this lane's own query is live
             run[t] = __ballot(used) != 0ull;          // wave-uniform
         }
         const bool wave_runs = run[0] || run[1];
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
                     }
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
-                        if (run[t] && valid[t] && h == 0) {
+                        if (mine[t] && h == 0) {      // unscattered pixels keep their previous output (their features were skipped)
                             float* o = out + (size_t)sidx[t] * 3u;
                             o[0] = y[t][0];
                             o[1] = y[t][1];
