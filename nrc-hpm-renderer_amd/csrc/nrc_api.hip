@@ -117,7 +117,7 @@ public:
     // Train, :147-156, on stream `st` (backward, gradient hook, optimizer).  When `st` is not the stream inference runs on,
     // the optimizer additionally waits for ev_infer_done -- the inference pass BEFORE the latest one: the fp16 inference image
     // is double-buffered (Mlp::repack) and the optimizer overwrites the set that pass read.
-    void train_all(hipStream_t st, hipEvent_t ev_infer_done)
+    void train_all(hipStream_t st, hipEvent_t ev_infer_prev, hipEvent_t ev_infer_cur = nullptr)
     {
         if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
         for (uint32_t b = 0; b < train_batch_count_; b++) {
@@ -129,7 +129,10 @@ public:
             if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
                                                                ncclSum, comm_, st), "ncclAllReduce");
             if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
-            if (b == 0 && ev_infer_done) NRC_HIP(hipStreamWaitEvent(st, ev_infer_done, 0));
+            // the two inference weight sets alternate with every optimizer step: step 0 overwrites the set the PREVIOUS
+            // inference pass read, step 1 the set the CURRENT pass is reading, later steps only sets no pass reads any more
+            if (b == 0 && ev_infer_prev) NRC_HIP(hipStreamWaitEvent(st, ev_infer_prev, 0));
+            if (b == 1 && ev_infer_cur) NRC_HIP(hipStreamWaitEvent(st, ev_infer_cur, 0));
             mlp_->optimizer_step(st);
         }
         loss_dirty_ = true;
@@ -441,7 +444,8 @@ public:
         cache_.infer_all(nullptr, Cs, !dense_infer_);
         NRC_HIP(hipEventRecord(ev_[3], Cs));
         NRC_HIP(hipEventRecord(ev_infer_done_[pp], Cs));
-        if (train) cache_.train_all(B, (B != Cs && frame_index_ > 0) ? ev_infer_done_[pp ^ 1] : nullptr);
+        if (train) cache_.train_all(B, (B != Cs && frame_index_ > 0) ? ev_infer_done_[pp ^ 1] : nullptr,
+                                    B != Cs ? ev_infer_done_[pp] : nullptr);
         NRC_HIP(hipEventRecord(ev_[5], B));
         NRC_HIP(hipEventRecord(ev_train_done_[pp], B));
         launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,

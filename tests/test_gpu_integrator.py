@@ -227,7 +227,7 @@ def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu
     nrc.Destroy()
 
 
-@pytest.mark.parametrize("model", [(3, 0, 64, 6), (2, 2, 64, 3)], ids=["fused", "generic"])
+@pytest.mark.parametrize("model", [(3, 0, 64, 6, 1), (2, 2, 64, 3, 1), (3, 0, 64, 6, 4)], ids=["fused", "generic", "fused-4-train-batches"])
 def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_gpu, model, monkeypatch):
     """the four-stream frame graph (train rays, training and inference of frame N beside gen_rays of frame N+1; triple-buffered
     gen_rays outputs, double-buffered train rays and inference weights) is pure scheduling: after 8 trained, blended frames the
@@ -241,7 +241,8 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
             monkeypatch.delenv(k, raising=False)
         if mode:
             monkeypatch.setenv(mode, "1")
-        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3])
+        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
+                                        train_batch_count=model[4], log2_train_batch_size=10 if model[4] == 1 else 8)
         ren.SetBlend(True)
         for f in range(8):
             ren.SetFrameRandom(frs[f])
