@@ -144,6 +144,25 @@ def test_gen_rays_and_query_packing_match_oracle(api, orc, sc, cloud16, torch_gp
     nrc.Destroy()
 
 
+@pytest.mark.parametrize("length,prob", [(3, 0.6), (0, 0.0), (2, 1.0)], ids=["len3-p0.6", "len0", "len2-p1(128-vertex cap)"])
+def test_gen_rays_primary_path_length_and_probability(api, orc, sc, cloud16, torch_gpu, length, prob):
+    """PRIMARY_RAY_LENGTH / PRIMARY_RAY_PROB (arguments 15/16 of the command line; gen_rays.comp:39-42): longer primary paths with
+    Russian-roulette-like continuation, down to the 128-vertex cap when the probability is 1"""
+    W, H = 96, 64
+    scene = sc.make_scene(cloud16, scene_id=4)
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, primary_ray_length=length, primary_ray_prob=prob)
+    ren.SetFrameRandom(FRAME_RANDOM)
+    ren.Render(None, False)
+    o = orc.nrc_gen_rays(scene, cam, W, H, length, prob, FRAME_RANDOM, threads=8)
+    assert same_bits(ren.Buffer("primary").cpu().numpy().reshape(H, W, 4), o["primary"])
+    assert same_bits(ren.Buffer("info").cpu().numpy().reshape(H, W), o["info"])
+    assert same_bits(ren.Buffer("infer_input").cpu().numpy(), o["infer_input"])
+    thr = o["primary"][..., 3][o["info"] == 1]
+    assert thr.min() < (0.5 if length == 0 else 0.25) or prob == 0.0
+    ren.Destroy()
+    nrc.Destroy()
+
+
 @pytest.mark.parametrize("fix_q1", [0, 1])
 def test_prep_train_and_ring_buffer_match_oracle(api, orc, sc, cloud16, torch_gpu, fix_q1):
     """nrc/clear.comp + prep_train_rays.comp over two frames: train inputs/targets and the ring buffer state"""
