@@ -777,8 +777,10 @@ __global__ void k_ring_push(DevFrame fr, TrainGrid tg, const float4* __restrict_
     const uint32_t T = tg.tw * tg.th;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (tg.ring_size == 0) return;
-    const uint32_t head = scratch[2 * T + 2];
-    if (i < T && scratch[i] != 0u) {
+    const uint32_t head = scratch[2 * T + 2], n_push = scratch[2 * T];
+    // pushes are applied in linear train-index order; when a frame pushes more entries than the ring holds, a slot is written
+    // several times and the last push in that order must win: only the final ring_size pushes are written at all
+    if (i < T && scratch[i] != 0u && scratch[T + i] + tg.ring_size >= n_push) {
         const uint32_t tx = i % tg.tw, ty = i / tg.tw;
         const size_t p = (size_t)(ty * tg.y_dist) * fr.w + tx * tg.x_dist;
         const float4 o = origin[p], d = dirs[p];

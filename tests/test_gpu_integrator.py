@@ -196,6 +196,35 @@ def test_prep_train_and_ring_buffer_match_oracle(api, orc, sc, cloud16, torch_gp
     nrc.Destroy()
 
 
+def test_prep_train_spp_ray_length_and_small_ring(api, orc, sc, cloud16, torch_gpu):
+    """TRAIN_SPP 3, TRAIN_RAY_LENGTH 4 (reachable with the quirk-Q2 fix), a ring buffer a quarter of the train grid (wraps within
+    a frame) over three frames: train rays and ring state bit-identical to the oracle"""
+    W, H = 128, 80
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(64, 32))
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, compat_fix=3, train_spp=3, train_ray_length=4, train_ring_buf_size=0.25)
+    tg = ren.TrainGrid()
+    T = tg["tw"] * tg["th"]
+    assert tg["ring_size"] == T // 4
+    head_tail = np.zeros(2, np.uint32)
+    ring = np.zeros((T, 6), np.float32)
+    ring[:, 5] = 1.0
+    frs = sc.frame_randoms(3, seed=8)
+    for f in range(3):
+        ren.SetFrameRandom(frs[f])
+        ren.Render(None, False)
+        o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, frs[f], threads=8)
+        tin, tgt = orc.nrc_prep_train(scene, W, H, tg["tw"], tg["th"], tg["x_dist"], tg["y_dist"], 3, 4, tg["ring_size"],
+                                      frs[f], o["info"], o["origin"], o["dir"], head_tail, ring, threads=8)
+        assert same_bits(ren.Buffer("train_input").cpu().numpy(), tin)
+        assert same_bits(ren.Buffer("train_target").cpu().numpy(), tgt)
+        rb = ren.Buffer("ring").cpu().numpy()
+        assert rb[0].view(np.uint32) == head_tail[0] and rb[1].view(np.uint32) == head_tail[1]
+        assert same_bits(rb[2:].view(np.float32).reshape(-1, 6)[:tg["ring_size"]], ring[:tg["ring_size"]])
+    assert tgt.max() > 0
+    ren.Destroy()
+    nrc.Destroy()
+
+
 @pytest.mark.parametrize("model", [(3, 0, 64, 6), (3, 0, 128, 8), (2, 0, 64, 3), (0, 0, 64, 6)])
 def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu, model):
     """NrcHpmRenderer::Render(queue, true): gen_rays -> prep_train -> InferAndTrain -> render.comp, two frames with
