@@ -221,7 +221,9 @@ struct SceneDev {
             d.inv_size[k] = 1.0f / size[k];
         }
         const float tx = 2.0f * size[0], ty = 2.0f * size[1], tz = 2.0f * size[2];
-        d.len2size = sqrtf((tx * tx + ty * ty) + tz * tz);
+        // length(2 * skySize) with the math spec's dot product (a chain of single-rounding FMAs, nrc_math.h) -- what the oracle and
+        // the device code compute; a plain (x*x + y*y) + z*z can differ in the last bit and with it every exit point
+        d.len2size = sqrtf(fmaf(tz, tz, fmaf(ty, ty, tx * tx)));
         set_params(s);
         d.env = nullptr; d.env_w = d.env_h = 0;
         if (s.env && s.env_w && s.env_h) {

@@ -85,6 +85,61 @@ def test_scene_parameter_update_matches_oracle(api, orc, sc, cloud16, torch_gpu)
     nrc.Destroy()
 
 
+CASES = {
+    "camera-inside-volume": dict(cam=dict(pos=(5.0, 2.0, -3.0), view_dir=(-0.7, 0.1, 0.7)), scene_id=4),
+    "camera-looking-away": dict(cam=dict(pos=(64.0, 0.0, 0.0), view_dir=(1.0, 0.0, 0.0)), scene_id=4),
+    "oblique-camera": dict(cam=dict(pos=(40.0, 35.0, -50.0), view_dir=(-0.6, -0.5, 0.7)), scene_id=0),
+    "empty-volume": dict(volume="zeros", scene_id=4),
+    "solid-volume": dict(volume="full", scene_id=4),
+    "point-light-scene2": dict(scene_id=2),
+    "env-only-scene5-sky": dict(scene_id=5, sky=True),
+    "thin-medium": dict(scene_id=4, density_factor=0.01),
+    "anisotropy-0": dict(scene_id=4, g=0.0),          # NewRayDir's isotropic branch (|g| < 0.001)
+    "back-scatter": dict(scene_id=0, g=-0.6),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_unusual_scenes_and_cameras_match_oracle_bitwise(api, orc, sc, cloud16, torch_gpu, case):
+    """both renderers on scenes off the beaten path -- camera inside / beside / facing away from the volume, empty and solid
+    volumes, every light type alone, isotropic and back-scattering phase functions, a very thin medium"""
+    k = CASES[case]
+    W, H = 72, 48
+    vol = cloud16
+    if k.get("volume") == "zeros":
+        vol = np.zeros((12, 10, 14), np.uint8)
+    elif k.get("volume") == "full":
+        vol = np.full((12, 10, 14), 255, np.uint8)
+    env = sc.procedural_sky(32, 16) if k.get("sky") else None
+    scene = sc.make_scene(vol, scene_id=k["scene_id"], env=env, g=k.get("g", 0.8))
+    if "density_factor" in k:
+        scene["density_factor"] = k["density_factor"]
+    cam = sc.make_camera(aspect=W / H, **k.get("cam", {}))
+    mc = api.McHpmRenderer(W, H, 16, False, cam, scene)
+    mc.SetFrameRandom(FRAME_RANDOM)
+    mc.Render()
+    ref, ref_info, _ = orc.mc_render(scene, cam, W, H, 16, FRAME_RANDOM, threads=8)
+    img = mc.GetImage().cpu().numpy()
+    assert same_bits(img, ref)
+    mc.Destroy()
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=12, scene_id=k["scene_id"])
+    nrc = api.NeuralRadianceCache(cfg)
+    ren = api.NrcHpmRenderer(W, H, False, cam, cfg, scene, nrc)
+    ren.SetFrameRandom(FRAME_RANDOM)
+    ren.Render(None, True)
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
+    assert same_bits(ren.Buffer("primary").cpu().numpy().reshape(H, W, 4), o["primary"])
+    assert same_bits(ren.Buffer("info").cpu().numpy().reshape(H, W), o["info"])
+    assert same_bits(ren.Buffer("infer_input").cpu().numpy(), o["infer_input"])
+    assert np.isfinite(ren.GetImage().cpu().numpy()).all() and np.isfinite(nrc.GetLoss())
+    if case == "empty-volume":
+        assert o["info"].sum() == 0
+    if case == "solid-volume":
+        assert o["info"].mean() > 0.2
+    ren.Destroy()
+    nrc.Destroy()
+
+
 def test_mc_progressive_blend(api, orc, sc, sphere_scene, torch_gpu):
     """blendFactor = 1/blendIndex, index advances only when blending (src/McHpmRenderer.cpp:124-136)"""
     W = H = 48
