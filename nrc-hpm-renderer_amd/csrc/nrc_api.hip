@@ -321,6 +321,7 @@ public:
         : w_(w), h_(h), blend_(blend), cam_(to_dev(cam)), cfg_(cfg), cache_(cache), stream_(s), rng_(cfg.seed)
     {
         if (w == 0 || h == 0) fail("render size must be non-zero");
+        if (((size_t)w * h) % 16 != 0) fail("NRC requires inferCount to be a multiple of 16");   // before anything is allocated
         frame_ = make_frame(w, h, tile);
         scene_.upload(scene);
         calc_train_subset(cfg.train_batch_count * cache.train_batch_size());

@@ -140,6 +140,25 @@ def test_unusual_scenes_and_cameras_match_oracle_bitwise(api, orc, sc, cloud16, 
     nrc.Destroy()
 
 
+def test_renderer_argument_errors(api, sc, sphere_scene, torch_gpu):
+    """Log::Error semantics at the boundary: a message starting with "SkyRenderer ERROR", no crash, nothing left half-built"""
+    cam = sc.make_camera(aspect=1.0)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=12)
+    nrc = api.NeuralRadianceCache(cfg)
+    with pytest.raises(RuntimeError, match="SkyRenderer ERROR.*multiple of 16"):
+        api.NrcHpmRenderer(10, 10, False, cam, cfg, sphere_scene, nrc)
+    with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
+        api.NrcHpmRenderer(0, 16, False, cam, cfg, sphere_scene, nrc)
+    bad = dict(sphere_scene, density_factor=0.0)
+    with pytest.raises(RuntimeError, match="SkyRenderer ERROR.*density"):
+        api.McHpmRenderer(16, 16, 4, False, cam, bad)
+    ren = api.NrcHpmRenderer(16, 16, False, cam, cfg, sphere_scene, nrc)     # the cache is still usable afterwards
+    ren.Render(None, True)
+    assert np.isfinite(nrc.GetLoss())
+    ren.Destroy()
+    nrc.Destroy()
+
+
 def test_mc_progressive_blend(api, orc, sc, sphere_scene, torch_gpu):
     """blendFactor = 1/blendIndex, index advances only when blending (src/McHpmRenderer.cpp:124-136)"""
     W = H = 48
