@@ -312,18 +312,22 @@ def test_random_model_configurations_match_oracle(api, orc, torch_gpu):
     loss x optimizer: inference, loss, gradients and the first optimizer step against the oracle"""
     rng = np.random.default_rng(123)
     losses = ["RelativeL2Luminance", "L2", "RelativeL2"]
-    for _ in range(16):
-        pos, d = int(rng.choice([1, 2, 3])), int(rng.integers(0, 3))
+    for k in range(20):
+        pos, d = (0 if k >= 16 else int(rng.choice([1, 2, 3]))), int(rng.integers(0, 3))       # the last four: HashGrid
         w, depth = int(rng.choice([32, 64, 128])), int(rng.integers(1, 10))
         loss, opt = int(rng.integers(0, 3)), str(rng.choice(["Adam", "SGD"]))
-        tag = (pos, d, w, depth, losses[loss], opt)
-        c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos, dir_id=d, nn_width=w, nn_depth=depth, loss_fn=losses[loss], optimizer=opt))
-        onn = orc.nn_create(pos_id=pos, dir_id=d, width=w, depth=depth, loss_id=loss, optimizer=opt)
+        hg = int(rng.integers(8, 14)) if pos == 0 else 0
+        tag = (pos, d, w, depth, losses[loss], opt, hg)
+        c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos, dir_id=d, nn_width=w, nn_depth=depth, loss_fn=losses[loss], optimizer=opt,
+                                                  hashgrid_log2_size=hg))
+        onn = orc.nn_create(pos_id=pos, dir_id=d, width=w, depth=depth, loss_id=loss, optimizer=opt, hashgrid_log2_size=hg)
         randomize(c, onn, seed=3, scale=1.0)
         n = 512 + 37
         x = queries(n, seed=pos * 7 + d, nan_frac=0.1 if d == 0 else 0.0)
         if pos == 1:
             x[:, :3] -= 31.0
+        if pos == 0:
+            x[:, :3] = np.random.default_rng(k).random((n, 3), dtype=np.float32)       # the grid is designed for [0,1)
         out = torch_gpu.empty((n, 3), device="cuda")
         c.Infer(torch_gpu.from_numpy(x).cuda(), out, useEma=True)
         assert rel(out.cpu().numpy(), onn.forward(x, True, 1)) < 3e-3, tag
@@ -331,11 +335,11 @@ def test_random_model_configurations_match_oracle(api, orc, torch_gpu):
         c.Backward(torch_gpu.from_numpy(x[:512].copy()).cuda(), torch_gpu.from_numpy(t).cuda())
         loss_ref = onn.backward(x[:512], t)
         assert abs(c.GetLoss() - loss_ref) < 3e-3 * abs(loss_ref), tag
-        assert rel(c.GetParams(4) / 128.0, np.array(onn.buffer(4))) < 2e-2, tag
+        assert rel(c.GetParams(4) / 128.0, np.array(onn.buffer(4))) < (5e-2 if pos == 0 else 2e-2), tag     # fp16 table atomics
         w0 = c.GetParams(0).copy()
         c.OptimizerStep()
         onn.optimizer_step()
-        assert rel(c.GetParams(0) - w0, np.array(onn.buffer(0)) - w0) < (6e-2 if opt == "Adam" else 2e-2), tag
+        assert rel(c.GetParams(0) - w0, np.array(onn.buffer(0)) - w0) < (1e-1 if pos == 0 else 6e-2 if opt == "Adam" else 2e-2), tag
         c.Destroy()
 
 
