@@ -583,7 +583,7 @@ public:
     // without stalling the render stream (which framebuffer() does)
     void wait_frame(hipStream_t consumer)
     {
-        if (stream_c_ && frame_index_ > 0)
+        if (frame_index_ > 0)      // recorded on whichever stream composited (the render stream itself in the reduced modes)
             NRC_HIP(hipStreamWaitEvent(consumer, ev_comp_done_[(frame_index_ - 1) % (uint64_t)kGenSets], 0));
     }
     const float* framebuffer_unordered() const { return (const float*)d_out_; }
