@@ -114,17 +114,7 @@ def main():
 
     W, H, spp = args.width, args.height, args.spp
     # ---- synthetic inputs: seeded 256^3 fBm cloud, procedural HDR sky, scene preset 4 values
-    cache_file = "/tmp/nrc_%s_%d_1337.npy" % ("smoke" if args.smoke_volume else "cloud", args.volume)
-    if os.path.exists(cache_file):
-        vol = np.load(cache_file)
-    else:
-        gen = sc.smoke_volume if args.smoke_volume else sc.fbm_cloud_volume
-        vol = sc.quantize_density(gen(args.volume, seed=1337))
-        try:
-            np.save(cache_file + ".%d.tmp.npy" % os.getpid(), vol)
-            os.replace(cache_file + ".%d.tmp.npy" % os.getpid(), cache_file)
-        except OSError:
-            pass
+    vol = sc.cached_volume("smoke" if args.smoke_volume else "cloud", args.volume, seed=1337)
     scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky())
     gw, gh = global_frame(world, W, H)
     tile = parallel.column_tile(rank, world, gw, gh)          # (x_offset, x_stride, global_w, global_h), local width

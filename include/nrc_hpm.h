@@ -73,13 +73,27 @@ int nrc_cache_create(const nrc_config* cfg, nrc_cache_t** out);
  * (src/NeuralRadianceCache.cu:42-95).  Buffers are caller-owned DEVICE memory: [n][5] / [n][3] fp32 AoS. */
 int nrc_cache_init(nrc_cache_t* c, uint32_t infer_count, float* d_infer_input, float* d_infer_output,
                    float* d_train_input, float* d_train_target, void* stream);
+/* The same Init with the reference's semaphore pair kept in HIP terms (include/engine/graphics/NeuralRadianceCache.hpp:15-22:
+ * cudaExternalSemaphore_t cudaStartSemaphore, cudaFinishedSemaphore): start_event / finished_event are hipEvent_t of the caller
+ * (either may be NULL).  Every InferAndTrain first makes its stream wait for start_event (AwaitCudaStartSemaphore,
+ * src/NeuralRadianceCache.cu:158-167) and records finished_event behind its last kernel (SignalCudaFinishedSemaphore, :169-177). */
+int nrc_cache_init_events(nrc_cache_t* c, uint32_t infer_count, float* d_infer_input, float* d_infer_output,
+                          float* d_train_input, float* d_train_target, void* stream, void* start_event, void* finished_event);
 /* NeuralRadianceCache::InferAndTrain(const uint32_t* inferFilter, bool train) (src/NeuralRadianceCache.cu:97-103).
  * infer_filter: HOST array, one entry per inference batch, >0 => run; NULL => run every batch. */
 int nrc_cache_infer_and_train(nrc_cache_t* c, const uint32_t* infer_filter, int train);
 /* NeuralRadianceCache::Destroy (src/NeuralRadianceCache.cu:105-107); frees the object */
 int nrc_cache_destroy(nrc_cache_t* c);
-/* GetLoss / Get{Infer,Train}Batch{Count,Size} (src/NeuralRadianceCache.cu:109-132).  get_loss synchronises the stream. */
+/* GetLoss / Get{Infer,Train}Batch{Count,Size} (src/NeuralRadianceCache.cu:109-132).
+ * The reference reads the loss back synchronously inside every training step (trainer->loss, :154) and GetLoss() returns that
+ * value; its main loop polls it every frame (src/main.cu:303,376).  Here every training step copies its loss to pinned host
+ * memory behind an event on the training stream:
+ *   nrc_cache_get_loss           the loss of the most recent training step that has COMPLETED; never blocks and never drains
+ *                                the renderer's frame pipeline (it lags the enqueued work by at most the pipeline depth, three
+ *                                frames).  NaN/Inf polling as in src/main.cu:380-384 works unchanged.
+ *   nrc_cache_get_loss_blocking  waits for the last training step that was enqueued (for that step only, not for the device). */
 float nrc_cache_get_loss(nrc_cache_t* c);
+float nrc_cache_get_loss_blocking(nrc_cache_t* c);
 size_t nrc_cache_get_infer_batch_count(nrc_cache_t* c);
 size_t nrc_cache_get_train_batch_count(nrc_cache_t* c);
 uint32_t nrc_cache_get_infer_batch_size(nrc_cache_t* c);
@@ -104,6 +118,8 @@ float* nrc_cache_loss_ptr(nrc_cache_t* c);
  * gradient vector + loss cell with ncclAllReduce on the training stream and normalises the loss by the global batch. */
 int nrc_comm_unique_id(void* out128);
 int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world);
+/* rank / size as the library's own RCCL communicator reports them (ncclCommUserRank / ncclCommCount); world = 0: none */
+int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world);
 /* multi-GPU: the loss normaliser of InferAndTrain's train batches becomes 3 * trainBatchSize * factor (factor = world size) */
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor);
 /* move the cache's work to another hipStream_t (Init binds the first one) */
@@ -180,8 +196,18 @@ int nrc_renderer_set_frame_random(nrc_renderer_t* r, const float random4[4]);
  * compositing, so work enqueued on that stream afterwards sees the finished image.  Call it again after every Render. */
 const float* nrc_renderer_framebuffer(nrc_renderer_t* r);
 /* same image, but orders `consumer_stream` (a display or read-back stream of the caller) behind the latest compositing
- * instead of the render stream: reading every frame then does not hold back the next frame's ray generation */
+ * instead of the render stream: reading every frame then does not hold back the next frame's ray generation.  Pair it with
+ * nrc_renderer_release_frame once the reads are enqueued. */
 const float* nrc_renderer_framebuffer_on(nrc_renderer_t* r, void* consumer_stream);
+/* The framebuffer is ONE image that every frame's compositing blends in place (as the reference's m_OutputImage).  A consumer
+ * that reads it on a stream of its own (framebuffer_on) must say when it is done: release_frame records the end of the reads
+ * enqueued so far on consumer_stream, and the next frame's compositing waits for it on the device (nothing else of the next
+ * frame does).  Without the call, a read that is still running when the next frame composites sees a torn image.
+ * Not needed for nrc_renderer_framebuffer(): reads enqueued on the render stream are ordered before the next frame by
+ * stream order. */
+int nrc_renderer_release_frame(nrc_renderer_t* r, void* consumer_stream);
+/* NrcHpmRenderer::IsBlending (include/engine/graphics/renderer/NrcHpmRenderer.hpp:37) */
+int nrc_renderer_is_blending(nrc_renderer_t* r);
 /* ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493): scan-line EXR, FLOAT RGBA */
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
 /* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be
@@ -217,6 +243,7 @@ int nrc_mc_renderer_create(uint32_t width, uint32_t height, uint32_t path_length
 int nrc_mc_renderer_render(nrc_mc_renderer_t* r);
 int nrc_mc_renderer_set_camera(nrc_mc_renderer_t* r, const nrc_camera* camera);
 int nrc_mc_renderer_set_blend(nrc_mc_renderer_t* r, int blend);
+int nrc_mc_renderer_is_blending(nrc_mc_renderer_t* r);          /* include/engine/graphics/renderer/McHpmRenderer.hpp */
 int nrc_mc_renderer_set_scene_params(nrc_mc_renderer_t* r, const nrc_scene* scene);   /* see nrc_renderer_set_scene_params */
 int nrc_mc_renderer_set_frame_random(nrc_mc_renderer_t* r, const float random4[4]);
 const float* nrc_mc_renderer_framebuffer(nrc_mc_renderer_t* r);   /* RGBA32F, alpha = blended didScatter */

@@ -5,12 +5,16 @@
 //   en::NeuralRadianceCache   include/engine/graphics/NeuralRadianceCache.hpp:13-32
 //   en::NrcHpmRenderer        include/engine/graphics/renderer/NrcHpmRenderer.hpp:16-41
 //   en::McHpmRenderer         include/engine/graphics/renderer/McHpmRenderer.hpp:16-31
+//   en::Camera                include/engine/graphics/Camera.hpp:18-60, src/Camera.cpp:164-174   (values only, no Vulkan)
+//   en::HpmScene              include/engine/HpmScene.hpp:12-43, src/HpmScene.cpp:24-76          (values only, no Vulkan)
 // with the Vulkan/CUDA-interop types replaced: VkQueue -> hipStream_t (as void*), the two cudaExternalSemaphore_t of
-// Init() dropped (stream order), VkImage/VkImageView -> device pointer to the RGBA32F framebuffer.
+// Init() -> two hipEvent_t (as void*; the overload without them relies on stream order), VkImage/VkImageView -> device
+// pointer to the RGBA32F framebuffer, glm::vec3 -> en::vec3.
 // Errors throw std::runtime_error("SkyRenderer ERROR: ...") exactly like Log::Error(msg, true) (src/Log.cpp:16-20).
 // Ownership as in the reference: the NRC does not own the four I/O buffers; the renderer holds a reference to the NRC,
 // which must outlive it; Destroy() is explicit and idempotent, destructors call it.
 #pragma once
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -25,10 +29,38 @@ inline void nrc_check(int status)
     if (status != NRC_OK) throw std::runtime_error(nrc_last_error());
 }
 
-struct AppConfig {
-    nrc_config c;
+// glm::vec3 stand-in for the few host-side values the path takes (camera pose, light angles)
+struct vec3 {
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    vec3() = default;
+    vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+    explicit vec3(float s) : x(s), y(s), z(s) {}
+};
+inline float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }      // glm::radians
 
-    AppConfig() { nrc_config_default(&c); }
+struct AppConfig {
+    // AppConfig::HpmSceneConfig (include/engine/AppConfig.hpp:23-36, presets src/AppConfig.cpp:93-150)
+    struct HpmSceneConfig {
+        uint32_t id = UINT32_MAX;
+        float dirLightStrength = 0.0f, pointLightStrength = 0.0f;
+        std::string hdrEnvMapPath;
+        float hdrEnvMapStrength = 0.0f, density = 0.0f;
+        bool dynamic = false;
+        HpmSceneConfig() = default;
+        explicit HpmSceneConfig(uint32_t id_) : id(id_)
+        {
+            static const float presets[6][4] = {{16.0f, 0.0f, 0.0f, 0.6f}, {0.0f, 64.0f, 0.0f, 0.6f}, {0.0f, 128.0f, 0.0f, 1.0f},
+                                                {16.0f, 0.0f, 0.0f, 0.25f}, {8.0f, 0.0f, 0.1f, 0.6f}, {0.0f, 0.0f, 1.0f, 1.6f}};
+            if (id > 5) throw std::runtime_error("SkyRenderer ERROR: HpmSceneConfig ID is invalid");
+            dirLightStrength = presets[id][0]; pointLightStrength = presets[id][1];
+            hdrEnvMapStrength = presets[id][2]; density = presets[id][3];
+        }
+    };
+
+    nrc_config c;
+    HpmSceneConfig scene;
+
+    AppConfig() { nrc_config_default(&c); scene = HpmSceneConfig(c.scene_id); }
 
     // the reference's 18-entry argv: program name + 17 positional arguments (src/AppConfig.cpp:154-182)
     explicit AppConfig(const std::vector<char*>& argv)
@@ -53,6 +85,7 @@ struct AppConfig {
         c.primary_ray_length = (uint32_t)std::stoi(argv[i++]);
         c.primary_ray_prob = std::stof(argv[i++]);
         c.train_ray_length = (uint32_t)std::stoi(argv[i++]);
+        scene = HpmSceneConfig(c.scene_id);
     }
 
     std::string GetName() const      // src/AppConfig.cpp:184-205
@@ -65,6 +98,161 @@ struct AppConfig {
         s += std::to_string(c.primary_ray_length) + "_" + std::to_string(c.primary_ray_prob) + "_" + std::to_string(c.train_ray_length);
         return s;
     }
+};
+
+// en::Camera (src/Camera.cpp): pose + projection -> CameraMatrices.invProjView and camera.pos, the two things the shaders read
+// (nrc-descriptors.glsl:1-11).  UpdateUniformBuffer restates src/Camera.cpp:164-174 with glm's own fp32 formulas:
+// glm::perspective (right-handed, depth -1..1), glm::lookAt (right-handed), glm::inverse (cofactor expansion).
+class Camera {
+public:
+    Camera(const vec3& pos, const vec3& viewDir, const vec3& up, float aspectRatio, float fov, float nearPlane, float farPlane)
+        : m_Pos(pos), m_ViewDir(viewDir), m_Up(up), m_AspectRatio(aspectRatio), m_Fov(fov), m_NearPlane(nearPlane), m_FarPlane(farPlane)
+    {
+        UpdateUniformBuffer();
+    }
+    void Destroy() {}
+    void UpdateUniformBuffer()
+    {
+        float proj[16] = {0}, view[16] = {0}, pv[16];      // column-major, m[4*col + row]
+        const float t = std::tan(m_Fov / 2.0f);
+        proj[0] = 1.0f / (m_AspectRatio * t);
+        proj[5] = 1.0f / t;
+        proj[10] = -(m_FarPlane + m_NearPlane) / (m_FarPlane - m_NearPlane);
+        proj[11] = -1.0f;
+        proj[14] = -(2.0f * m_FarPlane * m_NearPlane) / (m_FarPlane - m_NearPlane);
+        const vec3 f = normalize(m_ViewDir);               // normalize(center - eye), center = pos + viewDir
+        const vec3 s = normalize(cross(f, m_Up));
+        const vec3 u = cross(s, f);
+        view[0] = s.x; view[4] = s.y; view[8] = s.z;
+        view[1] = u.x; view[5] = u.y; view[9] = u.z;
+        view[2] = -f.x; view[6] = -f.y; view[10] = -f.z;
+        view[12] = -dot(s, m_Pos); view[13] = -dot(u, m_Pos); view[14] = dot(f, m_Pos);
+        view[15] = 1.0f;
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) {
+                float acc = 0.0f;
+                for (int k = 0; k < 4; k++) acc += proj[4 * k + r] * view[4 * c + k];
+                pv[4 * c + r] = acc;
+            }
+        invert(pv, m_Matrices.inv_proj_view);
+        m_Matrices.pos[0] = m_Pos.x; m_Matrices.pos[1] = m_Pos.y; m_Matrices.pos[2] = m_Pos.z;
+        m_Changed = true;
+    }
+    const vec3& GetPos() const { return m_Pos; }
+    void SetPos(const vec3& pos) { m_Pos = pos; m_Changed = true; }
+    const vec3& GetViewDir() const { return m_ViewDir; }
+    void SetViewDir(const vec3& viewDir) { m_ViewDir = viewDir; m_Changed = true; }
+    const vec3& GetUp() const { return m_Up; }
+    void SetUp(const vec3& up) { m_Up = up; m_Changed = true; }
+    bool HasChanged() const { return m_Changed; }
+    void SetChanged(bool changed) { m_Changed = changed; }
+    float GetAspectRatio() const { return m_AspectRatio; }
+    void SetAspectRatio(float aspectRatio) { m_AspectRatio = aspectRatio; }
+    void SetAspectRatio(uint32_t width, uint32_t height) { m_AspectRatio = (float)width / (float)height; }
+    float GetFov() const { return m_Fov; }
+    void SetFov(float fov) { m_Fov = fov; }
+    float GetNearPlane() const { return m_NearPlane; }
+    void SetNearPlane(float nearPlane) { m_NearPlane = nearPlane; }
+    float GetFarPlane() const { return m_FarPlane; }
+    void SetFarPlane(float farPlane) { m_FarPlane = farPlane; }
+    void Move(const vec3& move) { m_Pos = vec3(m_Pos.x + move.x, m_Pos.y + move.y, m_Pos.z + move.z); m_Changed = true; }
+    // what the renderers take in place of the camera's descriptor set
+    const nrc_camera* Matrices() const { return &m_Matrices; }
+
+private:
+    static float dot(const vec3& a, const vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+    static vec3 cross(const vec3& a, const vec3& b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+    static vec3 normalize(const vec3& a)
+    {
+        const float inv = 1.0f / std::sqrt(dot(a, a));
+        return vec3(a.x * inv, a.y * inv, a.z * inv);
+    }
+    static void invert(const float* m, float* out)      // glm::inverse(mat4): adjugate / determinant
+    {
+        float inv[16];
+        inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+        inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+        inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+        inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+        inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+        inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+        inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+        inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+        inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+        inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+        inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+        inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+        inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+        inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+        inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+        inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+        const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+        if (det == 0.0f) throw std::runtime_error("SkyRenderer ERROR: camera matrix is singular");
+        const float id = 1.0f / det;
+        for (int i = 0; i < 16; i++) out[i] = inv[i] * id;
+    }
+
+    vec3 m_Pos, m_ViewDir, m_Up;
+    bool m_Changed = true;
+    float m_AspectRatio, m_Fov, m_NearPlane, m_FarPlane;
+    nrc_camera m_Matrices{};
+};
+
+// en::HpmScene (src/HpmScene.cpp:24-76): the scene preset of the AppConfig (light strengths, medium density), the directional
+// light at zenith -1.57 / azimuth 0 (src/HpmScene.cpp:28, VecFromAngles src/DirLight.cpp:5-14), a white point light at the origin
+// (:30), g = 0.8 (:45), and the density volume.  The reference loads "data/volume/wdas_cloud_quarter.vdb" through OpenVDB inside
+// this constructor; here the caller hands over the dense R8 volume (what Texture3D::FromVDB produces, src/Texture3D.cpp:12-82 --
+// io_vdb.py parses the file) and, optionally, an RGBA32F environment map (default: the 1x1 map the reference ends up with for an
+// empty hdrEnvMapPath: black, src/read_file.cpp:85-90; pass a 1x1 white texel for quirk Q9).  The scene does not own the arrays.
+class HpmScene {
+public:
+    HpmScene(const AppConfig& appConfig, const uint8_t* density, uint32_t nx, uint32_t ny, uint32_t nz, const float* envRgba = nullptr,
+             uint32_t envWidth = 0, uint32_t envHeight = 0)
+        : m_ID(appConfig.scene.id), m_Dynamic(appConfig.scene.dynamic)
+    {
+        m_Scene.density = density; m_Scene.nx = nx; m_Scene.ny = ny; m_Scene.nz = nz;
+        m_Scene.size[0] = m_Scene.size[1] = m_Scene.size[2] = 0.0f;      // normalize(extent) * 107.5, src/NrcHpmRenderer.cu:910-912
+        m_Scene.density_factor = appConfig.scene.density;
+        m_Scene.g = 0.8f;
+        m_Scene.dir_light_strength = appConfig.scene.dirLightStrength;
+        m_Scene.point_light_pos[0] = m_Scene.point_light_pos[1] = m_Scene.point_light_pos[2] = 0.0f;
+        m_Scene.point_light_color[0] = m_Scene.point_light_color[1] = m_Scene.point_light_color[2] = 1.0f;
+        m_Scene.point_light_strength = appConfig.scene.pointLightStrength;
+        m_Scene.env_strength = appConfig.scene.hdrEnvMapStrength;
+        if (envRgba) { m_Scene.env = envRgba; m_Scene.env_w = envWidth; m_Scene.env_h = envHeight; }
+        else { m_Scene.env = m_BlackEnv; m_Scene.env_w = 1; m_Scene.env_h = 1; }
+        SetDirLightAngles(-1.57f, 0.0f);
+    }
+    HpmScene(const HpmScene&) = delete;
+    HpmScene& operator=(const HpmScene&) = delete;
+    // HpmScene::Update(renderImgui, deltaTime), src/HpmScene.cpp:56-76: only a dynamic scene 3 moves (azimuth += dt / 2,
+    // wrapped at 2 * 3.141); returns true when a value changed -- hand Scene() to the renderers' SetSceneParams then
+    bool Update(bool /*renderImgui*/, float deltaTime)
+    {
+        if (!m_Dynamic || m_ID != 3) return false;
+        SetDirLightAngles(m_Zenith, (float)std::fmod((double)(m_Azimuth + deltaTime * 0.5f), 2.0 * 3.141));
+        return true;
+    }
+    void SetDirLightAngles(float zenith, float azimuth)     // VecFromAngles: Ry(azimuth) * Rx(zenith) * (0, 1, 0)
+    {
+        m_Zenith = zenith; m_Azimuth = azimuth;
+        const double cz = std::cos((double)zenith), sz = std::sin((double)zenith), ca = std::cos((double)azimuth), sa = std::sin((double)azimuth);
+        m_Scene.dir_light_dir[0] = (float)(sa * sz);
+        m_Scene.dir_light_dir[1] = (float)cz;
+        m_Scene.dir_light_dir[2] = (float)(ca * sz);
+    }
+    void Destroy() {}
+    bool IsDynamic() const { return m_Dynamic; }
+    void SetDynamic(bool dynamic) { m_Dynamic = dynamic; }
+    const nrc_scene& Scene() const { return m_Scene; }
+    nrc_scene& Scene() { return m_Scene; }
+
+private:
+    uint32_t m_ID;
+    bool m_Dynamic;
+    float m_Zenith = -1.57f, m_Azimuth = 0.0f;
+    float m_BlackEnv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    nrc_scene m_Scene{};
 };
 
 class NeuralRadianceCache {
@@ -80,12 +268,23 @@ public:
     {
         nrc_check(nrc_cache_init(h_, inferCount, dInferInput, dInferOutput, dTrainInput, dTrainTarget, stream));
     }
+    // the reference's signature (include/engine/graphics/NeuralRadianceCache.hpp:15-22) with its two external semaphores as
+    // hipEvent_t: InferAndTrain waits for cudaStartEvent and records cudaFinishedEvent (either may be null)
+    void Init(uint32_t inferCount, float* dInferInput, float* dInferOutput, float* dTrainInput, float* dTrainTarget,
+              void* cudaStartEvent, void* cudaFinishedEvent, void* stream)
+    {
+        nrc_check(nrc_cache_init_events(h_, inferCount, dInferInput, dInferOutput, dTrainInput, dTrainTarget, stream, cudaStartEvent,
+                                        cudaFinishedEvent));
+    }
     void InferAndTrain(const uint32_t* inferFilter, bool train) { nrc_check(nrc_cache_infer_and_train(h_, inferFilter, train ? 1 : 0)); }
     void Destroy()
     {
         if (h_) { nrc_cache_destroy(h_); h_ = nullptr; }
     }
+    // loss of the most recent training step that has completed: never blocks, so the per-frame poll of src/main.cu:303,376 does
+    // not drain the frame pipeline; GetLossBlocking() waits for the last step enqueued
     float GetLoss() const { return nrc_cache_get_loss(h_); }
+    float GetLossBlocking() const { return nrc_cache_get_loss_blocking(h_); }
     size_t GetInferBatchCount() const { return nrc_cache_get_infer_batch_count(h_); }
     size_t GetTrainBatchCount() const { return nrc_cache_get_train_batch_count(h_); }
     uint32_t GetInferBatchSize() const { return nrc_cache_get_infer_batch_size(h_); }
@@ -103,6 +302,12 @@ public:
     {
         nrc_check(nrc_renderer_create(width, height, blend ? 1 : 0, camera, &appConfig.c, &hpmScene, nrc.Handle(), tile, stream, &h_));
     }
+    // the reference's own argument list (include/engine/graphics/renderer/NrcHpmRenderer.hpp:19-26)
+    NrcHpmRenderer(uint32_t width, uint32_t height, bool blend, const Camera* camera, const AppConfig& appConfig,
+                   const HpmScene& hpmScene, NeuralRadianceCache& nrc, void* stream = nullptr, const nrc_tile* tile = nullptr)
+        : NrcHpmRenderer(width, height, blend, camera->Matrices(), appConfig, hpmScene.Scene(), nrc, stream, tile)
+    {
+    }
     ~NrcHpmRenderer() { Destroy(); }
     NrcHpmRenderer(const NrcHpmRenderer&) = delete;
     NrcHpmRenderer& operator=(const NrcHpmRenderer&) = delete;
@@ -116,11 +321,16 @@ public:
     void EvaluateTimestampQueries() { (void)nrc_renderer_frame_time_ms(h_, stage_ms_); }
     const float* GetImage() const { return nrc_renderer_framebuffer(h_); }     // RGBA32F [height][width]
     const float* GetImage(void* consumerStream) const { return nrc_renderer_framebuffer_on(h_, consumerStream); }
+    // the reads of the image enqueued on consumerStream end here: the next frame's compositing waits for them
+    void ReleaseImage(void* consumerStream) { nrc_check(nrc_renderer_release_frame(h_, consumerStream)); }
+    bool IsBlending() const { return nrc_renderer_is_blending(h_) != 0; }
     float GetFrameTimeMS() const { return nrc_renderer_frame_time_ms(h_, nullptr); }
     const float* GetStageTimesMS() const { return stage_ms_; }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_renderer_set_camera(h_, camera)); }
+    void SetCamera(void* queue, const Camera* camera) { SetCamera(queue, camera->Matrices()); }
     void SetBlend(bool blend) { nrc_check(nrc_renderer_set_blend(h_, blend ? 1 : 0)); }
     void SetSceneParams(const nrc_scene& scene) { nrc_check(nrc_renderer_set_scene_params(h_, &scene)); }   // HpmScene::Update
+    void SetSceneParams(const HpmScene& scene) { SetSceneParams(scene.Scene()); }
     nrc_renderer_t* Handle() const { return h_; }
 
 private:
@@ -135,6 +345,11 @@ public:
     {
         nrc_check(nrc_mc_renderer_create(width, height, pathLength, blend ? 1 : 0, camera, &scene, tile, stream, &h_));
     }
+    McHpmRenderer(uint32_t width, uint32_t height, uint32_t pathLength, bool blend, const Camera* camera, const HpmScene& scene,
+                  void* stream = nullptr, const nrc_tile* tile = nullptr)
+        : McHpmRenderer(width, height, pathLength, blend, camera->Matrices(), scene.Scene(), stream, tile)
+    {
+    }
     ~McHpmRenderer() { Destroy(); }
     McHpmRenderer(const McHpmRenderer&) = delete;
     McHpmRenderer& operator=(const McHpmRenderer&) = delete;
@@ -147,8 +362,11 @@ public:
     void ExportOutputImageToFile(void* /*queue*/, const std::string& filePath) const { nrc_check(nrc_mc_renderer_export_exr(h_, filePath.c_str())); }
     const float* GetImage() const { return nrc_mc_renderer_framebuffer(h_); }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_mc_renderer_set_camera(h_, camera)); }
+    void SetCamera(void* queue, const Camera* camera) { SetCamera(queue, camera->Matrices()); }
     void SetBlend(bool blend) { nrc_check(nrc_mc_renderer_set_blend(h_, blend ? 1 : 0)); }
+    bool IsBlending() const { return nrc_mc_renderer_is_blending(h_) != 0; }
     void SetSceneParams(const nrc_scene& scene) { nrc_check(nrc_mc_renderer_set_scene_params(h_, &scene)); }
+    void SetSceneParams(const HpmScene& scene) { SetSceneParams(scene.Scene()); }
     nrc_mc_renderer_t* Handle() const { return h_; }
 
 private:

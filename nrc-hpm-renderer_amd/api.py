@@ -59,7 +59,8 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.
 # every symbol include/nrc_hpm.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
     "nrc_last_error", "nrc_version", "nrc_config_default",
-    "nrc_cache_create", "nrc_cache_init", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
+    "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
+    "nrc_cache_get_loss_blocking", "nrc_cache_comm_info", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -97,6 +98,7 @@ def load_library():
     L.nrc_last_error.restype = C.c_char_p
     L.nrc_version.restype = C.c_char_p
     L.nrc_cache_get_loss.restype = C.c_float
+    L.nrc_cache_get_loss_blocking.restype = C.c_float
     L.nrc_cache_get_infer_batch_count.restype = C.c_size_t
     L.nrc_cache_get_train_batch_count.restype = C.c_size_t
     L.nrc_cache_get_infer_batch_size.restype = C.c_uint32
@@ -110,7 +112,8 @@ def load_library():
     L.nrc_renderer_frame_time_ms.restype = C.c_float
     L.nrc_mc_renderer_framebuffer.restype = C.c_void_p
     L.nrc_mc_renderer_frame_time_ms.restype = C.c_float
-    for name in ("nrc_cache_get_loss", "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count",
+    for name in ("nrc_cache_get_loss", "nrc_cache_get_loss_blocking", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
+                 "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count",
                  "nrc_cache_get_infer_batch_size", "nrc_cache_get_train_batch_size", "nrc_cache_grad_ptr",
                  "nrc_cache_loss_ptr", "nrc_cache_param_count", "nrc_renderer_framebuffer", "nrc_mc_renderer_framebuffer",
                  "nrc_mc_renderer_frame_time_ms"):
@@ -236,11 +239,19 @@ class NeuralRadianceCache:
         self._hook_keep = None
         self._bufs = None
 
-    def Init(self, inferCount, dInferInput, dInferOutput, dTrainInput, dTrainTarget, stream=None):
-        """Buffers: torch CUDA float32 tensors [n,5] / [n,3] (caller-owned, as in the reference)."""
-        self._bufs = (dInferInput, dInferOutput, dTrainInput, dTrainTarget)
-        _check(self.L.nrc_cache_init(self.h, C.c_uint32(inferCount), _dev_ptr(dInferInput), _dev_ptr(dInferOutput),
-                                     _dev_ptr(dTrainInput), _dev_ptr(dTrainTarget), _stream_ptr(stream)))
+    def Init(self, inferCount, dInferInput, dInferOutput, dTrainInput, dTrainTarget, stream=None, cudaStartEvent=None,
+             cudaFinishedEvent=None):
+        """Buffers: torch CUDA float32 tensors [n,5] / [n,3] (caller-owned, as in the reference).  cudaStartEvent /
+        cudaFinishedEvent: torch.cuda.Event objects standing in for the reference's two external semaphores
+        (include/engine/graphics/NeuralRadianceCache.hpp:15-22): InferAndTrain waits for the first and records the second."""
+        self._bufs = (dInferInput, dInferOutput, dTrainInput, dTrainTarget, cudaStartEvent, cudaFinishedEvent)
+        if cudaStartEvent is None and cudaFinishedEvent is None:
+            _check(self.L.nrc_cache_init(self.h, C.c_uint32(inferCount), _dev_ptr(dInferInput), _dev_ptr(dInferOutput),
+                                         _dev_ptr(dTrainInput), _dev_ptr(dTrainTarget), _stream_ptr(stream)))
+            return
+        ev = [C.c_void_p(int(e.cuda_event)) if e is not None else None for e in (cudaStartEvent, cudaFinishedEvent)]
+        _check(self.L.nrc_cache_init_events(self.h, C.c_uint32(inferCount), _dev_ptr(dInferInput), _dev_ptr(dInferOutput),
+                                            _dev_ptr(dTrainInput), _dev_ptr(dTrainTarget), _stream_ptr(stream), ev[0], ev[1]))
 
     def InferAndTrain(self, inferFilter, train):
         f = None
@@ -254,7 +265,12 @@ class NeuralRadianceCache:
             _check(self.L.nrc_cache_destroy(self.h))
             self.h = None
 
-    def GetLoss(self):
+    def GetLoss(self, wait=True):
+        """wait=True: the loss of the last training step enqueued (waits for that step; what the parity tests compare).
+        wait=False: en::NeuralRadianceCache::GetLoss() of the C++ surface -- the most recent COMPLETED step, never blocks (the
+        per-frame poll of src/main.cu:303,376)."""
+        if wait:
+            return float(self.L.nrc_cache_get_loss_blocking(self.h))
         return float(self.L.nrc_cache_get_loss(self.h))
 
     def GetInferBatchCount(self):
@@ -300,6 +316,12 @@ class NeuralRadianceCache:
         """native RCCL gradient exchange: unique_id = 128 bytes from comm_unique_id() of rank 0 (collective call)"""
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         _check(self.L.nrc_cache_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))
+
+    def CommInfo(self):
+        """(rank, world) as the library's RCCL communicator reports them; world 0 = no native communicator"""
+        r, w = C.c_int(0), C.c_int(0)
+        _check(self.L.nrc_cache_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def SetLossNormFactor(self, factor):
         _check(self.L.nrc_cache_set_loss_norm_factor(self.h, C.c_uint32(factor)))
@@ -430,6 +452,13 @@ class NrcHpmRenderer:
             p = self.L.nrc_renderer_framebuffer_on(self.h, _stream_ptr(stream))
         return _wrap_device(p, self.width * self.height * 16, torch.float32, (self.height, self.width, 4))
 
+    def ReleaseImage(self, stream):
+        """the consumer's reads of GetImage(stream) enqueued so far end here; the next frame's compositing waits for them"""
+        _check(self.L.nrc_renderer_release_frame(self.h, _stream_ptr(stream)))
+
+    def IsBlending(self):
+        return bool(self.L.nrc_renderer_is_blending(self.h))
+
     def Buffer(self, name):
         import torch
         nbytes = C.c_size_t(0)
@@ -488,6 +517,9 @@ class McHpmRenderer:
 
     def SetBlend(self, blend):
         _check(self.L.nrc_mc_renderer_set_blend(self.h, C.c_int(int(blend))))
+
+    def IsBlending(self):
+        return bool(self.L.nrc_mc_renderer_is_blending(self.h))
 
     def SetSceneParams(self, scene):
         sc_ = make_c_scene(scene.scene if hasattr(scene, "scene") else scene)

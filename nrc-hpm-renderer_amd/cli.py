@@ -74,7 +74,7 @@ def main(argv=None):
 
     for frame in range(args.frames):
         nrc_renderer.Render(None, True)
-        loss = nrc.GetLoss()
+        loss = nrc.GetLoss(wait=False)          # src/main.cu:376: polled every frame, never blocks the frame pipeline
         if math.isnan(loss) or math.isinf(loss):                    # src/main.cu:380-384
             print("SkyRenderer ERROR: NRC Loss is %s" % loss, file=sys.stderr)
             break

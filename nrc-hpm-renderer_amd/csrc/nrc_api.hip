@@ -34,6 +34,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
     static Rccl& get()
     {
         static Rccl r = [] {
@@ -48,6 +50,8 @@ struct Rccl {
             x.comm_destroy = (decltype(x.comm_destroy))dlsym(x.handle, "ncclCommDestroy");
             x.all_reduce = (decltype(x.all_reduce))dlsym(x.handle, "ncclAllReduce");
             x.error_string = (decltype(x.error_string))dlsym(x.handle, "ncclGetErrorString");
+            x.comm_count = (decltype(x.comm_count))dlsym(x.handle, "ncclCommCount");
+            x.comm_user_rank = (decltype(x.comm_user_rank))dlsym(x.handle, "ncclCommUserRank");
             if (!x.get_unique_id || !x.comm_init_rank || !x.comm_destroy || !x.all_reduce) fail("librccl lacks the expected entry points");
             return x;
         }();
@@ -61,23 +65,41 @@ struct Rccl {
 
 // ---------------------------------------------------------------------------------------------------- Cache
 class Cache {
+    // validated before any size is derived from it: 2 << (log2 - 1) with log2 = 0 would shift by 0xFFFFFFFF
+    static const nrc_config& checked(const nrc_config& cfg)
+    {
+        if (cfg.log2_infer_batch_size == 0 || cfg.log2_infer_batch_size > 30 || cfg.log2_train_batch_size < 5 ||
+            cfg.log2_train_batch_size > 30)
+            fail("log2 batch sizes out of range");
+        if (cfg.train_batch_count == 0 || ((uint64_t)cfg.train_batch_count << cfg.log2_train_batch_size) > (1ull << 30))
+            fail("trainBatchCount x trainBatchSize must be in 1..2^30");
+        if (!(cfg.train_ring_buf_size >= 0.0f) || cfg.train_ring_buf_size > 1024.0f) fail("trainRingBufSize must be in 0..1024");
+        return cfg;
+    }
+
 public:
     explicit Cache(const nrc_config& cfg)
-        : cfg_(cfg),
+        : cfg_(checked(cfg)),
           infer_batch_size_(2u << (cfg.log2_infer_batch_size - 1)),      // src/NeuralRadianceCache.cu:12-14
           train_batch_size_(2u << (cfg.log2_train_batch_size - 1)),
           train_batch_count_(cfg.train_batch_count),
           mlp_(new Mlp(cfg))
     {
-        if (cfg.log2_infer_batch_size == 0 || cfg.log2_infer_batch_size > 30 || cfg.log2_train_batch_size < 5 ||
-            cfg.log2_train_batch_size > 30)
-            fail("log2 batch sizes out of range");
+        for (auto& e : ev_loss_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        NRC_HIP(hipHostMalloc((void**)&h_loss_, sizeof(float) * kLossSlots, hipHostMallocDefault));
+        for (int k = 0; k < kLossSlots; k++) h_loss_[k] = 0.0f;
+        NRC_HIP(hipEventCreateWithFlags(&ev_owner_infer_, hipEventDisableTiming));
+        NRC_HIP(hipEventCreateWithFlags(&ev_owner_train_, hipEventDisableTiming));
     }
 
-    void init(uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_ttarget, hipStream_t s)
+    void init(uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_ttarget, hipStream_t s,
+              hipEvent_t ev_start = nullptr, hipEvent_t ev_finished = nullptr)
     {
         bind(infer_count, d_in, d_out, d_tin, d_ttarget);
         stream_ = s;
+        // the reference's cudaStartSemaphore / cudaFinishedSemaphore pair (src/NeuralRadianceCache.cu:158-177) as HIP events
+        ev_start_ = ev_start;
+        ev_finished_ = ev_finished;
     }
 
     // (re)bind the caller-owned I/O buffers without touching the stream of the stand-alone entry points: the renderer does
@@ -98,8 +120,37 @@ public:
 
     void infer_and_train(const uint32_t* filter, bool train)       // :97-103
     {
+        acquire(this, stream_, stream_);
+        if (ev_start_) NRC_HIP(hipStreamWaitEvent(stream_, ev_start_, 0));           // AwaitCudaStartSemaphore, :158-167
         infer_all(filter, stream_);
         if (train) train_all(stream_, nullptr);
+        if (ev_finished_) NRC_HIP(hipEventRecord(ev_finished_, stream_));            // SignalCudaFinishedSemaphore, :169-177
+    }
+
+    // Several users may drive one cache -- a training renderer and an evaluation renderer (Reference::CompareNrc,
+    // src/Reference.cpp:71-107), or a renderer and the stand-alone entry points -- each with streams of its own.  A user's own
+    // frames are ordered by its own events; when the user CHANGES, the new user's inference and training streams wait (on the
+    // device) for everything the previous user had enqueued on its two cache streams, so weight images, feature buffers and
+    // the gradient vector are never shared between two users in flight.  Costs nothing while the user stays the same.
+    void acquire(const void* who, hipStream_t infer_stream, hipStream_t train_stream)
+    {
+        if (owner_ != nullptr && owner_ != who) {
+            NRC_HIP(hipEventRecord(ev_owner_infer_, owner_infer_stream_));
+            NRC_HIP(hipEventRecord(ev_owner_train_, owner_train_stream_));
+            for (hipStream_t s : {infer_stream, train_stream}) {
+                NRC_HIP(hipStreamWaitEvent(s, ev_owner_infer_, 0));
+                NRC_HIP(hipStreamWaitEvent(s, ev_owner_train_, 0));
+                if (train_stream == infer_stream) break;
+            }
+        }
+        owner_ = who;
+        owner_infer_stream_ = infer_stream;
+        owner_train_stream_ = train_stream;
+    }
+    // a user whose streams are about to disappear (renderer destruction; it has synchronised them)
+    void forget(const void* who)
+    {
+        if (owner_ == who) owner_ = nullptr;
     }
 
     // skip_zero: device-side replacement of the reference's per-batch host filter (src/NrcHpmRenderer.cu:332-337,
@@ -129,21 +180,48 @@ public:
             if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
                                                                ncclSum, comm_, st), "ncclAllReduce");
             if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
+            push_loss(st);
             // the two inference weight sets alternate with every optimizer step: step 0 overwrites the set the PREVIOUS
             // inference pass read, step 1 the set the CURRENT pass is reading, later steps only sets no pass reads any more
             if (b == 0 && ev_infer_prev) NRC_HIP(hipStreamWaitEvent(st, ev_infer_prev, 0));
             if (b == 1 && ev_infer_cur) NRC_HIP(hipStreamWaitEvent(st, ev_infer_cur, 0));
             mlp_->optimizer_step(st);
         }
-        loss_dirty_ = true;
     }
 
-    float get_loss()
+    // m_Loss = trainer->loss(*ctx) after every training step (src/NeuralRadianceCache.cu:154) is a device->host sync in the
+    // reference.  Here every step's loss cell is copied to a pinned host slot on the training stream, followed by an event:
+    //   get_loss(false)  the loss of the most recent step that has COMPLETED -- never blocks, never drains the frame pipeline
+    //                    (what a per-frame GetLoss() poll needs: src/main.cu:303,376; it lags the enqueued work by the
+    //                    pipeline depth, at most three frames);
+    //   get_loss(true)   waits for the last step that was enqueued (only for that step, not for the device).
+    void push_loss(hipStream_t st)
     {
-        if (loss_dirty_) {
-            NRC_HIP(hipDeviceSynchronize());      // training may run on the renderer's second stream
-            NRC_HIP(hipMemcpy(&loss_, mlp_->loss_ptr(), sizeof(float), hipMemcpyDeviceToHost));
-            loss_dirty_ = false;
+        const int slot = (int)(loss_pushed_ % kLossSlots);
+        NRC_HIP(hipMemcpyAsync(&h_loss_[slot], mlp_->loss_ptr(), sizeof(float), hipMemcpyDeviceToHost, st));
+        NRC_HIP(hipEventRecord(ev_loss_[slot], st));
+        loss_pushed_++;
+    }
+    float get_loss(bool wait)
+    {
+        if (loss_pushed_ == 0) return loss_;
+        const uint64_t newest = loss_pushed_ - 1;
+        if (wait) {
+            NRC_HIP(hipEventSynchronize(ev_loss_[newest % kLossSlots]));
+            loss_ = h_loss_[newest % kLossSlots];
+            loss_seen_ = newest + 1;
+            return loss_;
+        }
+        // newest first; a slot older than the ring has been re-armed by a younger step and is covered by that one
+        const uint64_t oldest = newest + 1 > (uint64_t)kLossSlots ? newest + 1 - kLossSlots : 0;
+        for (uint64_t k = newest + 1; k-- > std::max(oldest, loss_seen_);) {
+            const hipError_t q = hipEventQuery(ev_loss_[k % kLossSlots]);
+            if (q == hipSuccess) {
+                loss_ = h_loss_[k % kLossSlots];
+                loss_seen_ = k + 1;
+                break;
+            }
+            if (q != hipErrorNotReady) NRC_HIP(q);
         }
         return loss_;
     }
@@ -165,12 +243,25 @@ public:
         Rccl::get().check(Rccl::get().comm_init_rank(&comm_, world, id, rank), "ncclCommInitRank");
         loss_norm_factor_ = (uint32_t)world;
     }
+    // what the communicator itself reports (bench.py prints it: proof that the native exchange path is the one in use)
+    void comm_info(int* rank, int* world)
+    {
+        *rank = 0; *world = 0;
+        if (!comm_) return;
+        Rccl& r = Rccl::get();
+        if (!r.comm_count || !r.comm_user_rank) fail("librccl lacks ncclCommCount / ncclCommUserRank");
+        r.check(r.comm_count(comm_, world), "ncclCommCount");
+        r.check(r.comm_user_rank(comm_, rank), "ncclCommUserRank");
+    }
     ~Cache()
     {
         if (comm_) (void)Rccl::get().comm_destroy(comm_);
+        for (auto& e : ev_loss_) if (e) (void)hipEventDestroy(e);
+        if (ev_owner_infer_) (void)hipEventDestroy(ev_owner_infer_);
+        if (ev_owner_train_) (void)hipEventDestroy(ev_owner_train_);
+        if (h_loss_) (void)hipHostFree(h_loss_);
     }
     void set_loss_norm_factor(uint32_t f) { loss_norm_factor_ = f ? f : 1; }
-    void mark_loss_dirty() { loss_dirty_ = true; }
     const nrc_config& config() const { return cfg_; }
 
 private:
@@ -180,14 +271,21 @@ private:
     uint32_t infer_count_ = 0;
     float *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;
     hipStream_t stream_ = nullptr;
+    hipEvent_t ev_start_ = nullptr, ev_finished_ = nullptr;      // caller-owned (Init overload), may be null
     std::vector<std::pair<uint32_t, uint32_t>> infer_batches_;
     bool initialised_ = false;
     nrc_grad_hook hook_ = nullptr;
     void* hook_user_ = nullptr;
     ncclComm_t comm_ = nullptr;
     uint32_t loss_norm_factor_ = 1;
+    static constexpr int kLossSlots = 8;
     float loss_ = 0.0f;
-    bool loss_dirty_ = false;
+    float* h_loss_ = nullptr;                 // pinned
+    hipEvent_t ev_loss_[kLossSlots] = {};
+    uint64_t loss_pushed_ = 0, loss_seen_ = 0;
+    const void* owner_ = nullptr;
+    hipStream_t owner_infer_stream_ = nullptr, owner_train_stream_ = nullptr;
+    hipEvent_t ev_owner_infer_ = nullptr, ev_owner_train_ = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------------- scene upload
@@ -386,6 +484,8 @@ public:
         for (auto& e : ev_infer_done_) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_train_done_) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_comp_done_) if (e) (void)hipEventDestroy(e);
+        if (ev_consumer_) (void)hipEventDestroy(ev_consumer_);
+        cache_.forget(this);
     }
 
     void render(bool train)      // NrcHpmRenderer::Render, :299-353
@@ -441,6 +541,7 @@ public:
         if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
         // same NRC from another camera, src/Reference.cpp:71-107)
+        cache_.acquire(this, Cs, B);
         cache_.bind((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
                     (float*)d_train_target_);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
@@ -451,6 +552,12 @@ public:
                                     B != Cs ? ev_infer_done_[pp] : nullptr);
         NRC_HIP(hipEventRecord(ev_[5], B));
         NRC_HIP(hipEventRecord(ev_train_done_[pp], B));
+        // the framebuffer is ONE image that compositing blends in place: a consumer stream that was handed the previous frame
+        // (framebuffer_on) and announced the end of its read (release_frame) holds this frame's compositing back until then
+        if (consumer_pending_) {
+            NRC_HIP(hipStreamWaitEvent(Cs, ev_consumer_, 0));
+            consumer_pending_ = false;
+        }
         launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
                          (const float*)d_infer_out_, (float*)d_out_, Cs);
         NRC_HIP(hipEventRecord(ev_[4], Cs));
@@ -586,6 +693,14 @@ public:
         if (frame_index_ > 0)      // recorded on whichever stream composited (the render stream itself in the reduced modes)
             NRC_HIP(hipStreamWaitEvent(consumer, ev_comp_done_[(frame_index_ - 1) % (uint64_t)kGenSets], 0));
     }
+    // the consumer's reads of the framebuffer enqueued so far on `consumer` finish before the next frame is composited
+    void release_frame(hipStream_t consumer)
+    {
+        if (!ev_consumer_) NRC_HIP(hipEventCreateWithFlags(&ev_consumer_, hipEventDisableTiming));
+        NRC_HIP(hipEventRecord(ev_consumer_, consumer));
+        consumer_pending_ = true;
+    }
+    bool is_blending() const { return blend_; }
     const float* framebuffer_unordered() const { return (const float*)d_out_; }
     const TrainGrid& train_grid() const { return tg_; }
     hipStream_t stream() const { return stream_; }
@@ -649,6 +764,8 @@ private:
     bool have_pinned_random_ = false;
     bool count_fetches_ = false;
     bool dense_infer_ = false;
+    hipEvent_t ev_consumer_ = nullptr;
+    bool consumer_pending_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------------- McRenderer
@@ -694,6 +811,7 @@ public:
     }
     void set_scene_params(const nrc_scene& s) { scene_.set_params(s); }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }
+    bool is_blending() const { return blend_; }
     void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
     void set_count_fetches(bool on) { count_fetches_ = on; NRC_HIP(hipMemsetAsync(d_fetch_, 0, 8, stream_)); }
     unsigned long long fetches()
@@ -796,6 +914,13 @@ int nrc_cache_init(nrc_cache_t* c, uint32_t infer_count, float* d_in, float* d_o
     NRC_REQUIRE(c);
     return guarded([&] { c->impl.init(infer_count, d_in, d_out, d_tin, d_tt, (hipStream_t)stream); });
 }
+int nrc_cache_init_events(nrc_cache_t* c, uint32_t infer_count, float* d_in, float* d_out, float* d_tin, float* d_tt, void* stream,
+                          void* start_event, void* finished_event)
+{
+    NRC_REQUIRE(c);
+    return guarded([&] { c->impl.init(infer_count, d_in, d_out, d_tin, d_tt, (hipStream_t)stream, (hipEvent_t)start_event,
+                                      (hipEvent_t)finished_event); });
+}
 int nrc_cache_infer_and_train(nrc_cache_t* c, const uint32_t* filter, int train)
 {
     NRC_REQUIRE(c);
@@ -809,7 +934,13 @@ int nrc_cache_destroy(nrc_cache_t* c)
 float nrc_cache_get_loss(nrc_cache_t* c)
 {
     float v = NAN;
-    if (c) guarded([&] { v = c->impl.get_loss(); });
+    if (c) guarded([&] { v = c->impl.get_loss(false); });
+    return v;
+}
+float nrc_cache_get_loss_blocking(nrc_cache_t* c)
+{
+    float v = NAN;
+    if (c) guarded([&] { v = c->impl.get_loss(true); });
     return v;
 }
 size_t nrc_cache_get_infer_batch_count(nrc_cache_t* c) { return c ? c->impl.infer_batch_count() : 0; }
@@ -825,17 +956,27 @@ int nrc_cache_set_stream(nrc_cache_t* c, void* stream)
 int nrc_cache_infer(nrc_cache_t* c, const float* d_in, float* d_out, uint32_t n, int use_ema)
 {
     NRC_REQUIRE(c); NRC_REQUIRE(d_in); NRC_REQUIRE(d_out);
-    return guarded([&] { c->impl.mlp().infer(d_in, d_out, n, use_ema != 0, c->impl.stream()); });
+    return guarded([&] {
+        c->impl.acquire(&c->impl, c->impl.stream(), c->impl.stream());
+        c->impl.mlp().infer(d_in, d_out, n, use_ema != 0, c->impl.stream());
+    });
 }
 int nrc_cache_backward(nrc_cache_t* c, const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm)
 {
     NRC_REQUIRE(c); NRC_REQUIRE(d_in); NRC_REQUIRE(d_target);
-    return guarded([&] { c->impl.mlp().backward(d_in, d_target, n, n_norm ? n_norm : n, c->impl.stream()); c->impl.mark_loss_dirty(); });
+    return guarded([&] {
+        c->impl.acquire(&c->impl, c->impl.stream(), c->impl.stream());
+        c->impl.mlp().backward(d_in, d_target, n, n_norm ? n_norm : n, c->impl.stream());
+        c->impl.push_loss(c->impl.stream());
+    });
 }
 int nrc_cache_optimizer_step(nrc_cache_t* c)
 {
     NRC_REQUIRE(c);
-    return guarded([&] { c->impl.mlp().optimizer_step(c->impl.stream()); });
+    return guarded([&] {
+        c->impl.acquire(&c->impl, c->impl.stream(), c->impl.stream());
+        c->impl.mlp().optimizer_step(c->impl.stream());
+    });
 }
 float* nrc_cache_grad_ptr(nrc_cache_t* c) { return c ? c->impl.mlp().grad_ptr() : nullptr; }
 uint32_t nrc_cache_param_count(nrc_cache_t* c) { return c ? c->impl.mlp().n_params() : 0; }
@@ -859,6 +1000,11 @@ int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int 
 {
     NRC_REQUIRE(c); NRC_REQUIRE(unique_id128);
     return guarded([&] { c->impl.comm_init(unique_id128, rank, world); });
+}
+int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(rank); NRC_REQUIRE(world);
+    return guarded([&] { c->impl.comm_info(rank, world); });
 }
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor)
 {
@@ -925,6 +1071,13 @@ const float* nrc_renderer_framebuffer_on(nrc_renderer_t* r, void* consumer_strea
     if (guarded([&] { r->impl.wait_frame((hipStream_t)consumer_stream); p = r->impl.framebuffer_unordered(); }) != NRC_OK) return nullptr;
     return p;
 }
+int nrc_renderer_release_frame(nrc_renderer_t* r, void* consumer_stream)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.release_frame((hipStream_t)consumer_stream); });
+}
+int nrc_renderer_is_blending(nrc_renderer_t* r) { return r && r->impl.is_blending() ? 1 : 0; }
+int nrc_mc_renderer_is_blending(nrc_mc_renderer_t* r) { return r && r->impl.is_blending() ? 1 : 0; }
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path) { NRC_REQUIRE(r); NRC_REQUIRE(path); return guarded([&] { r->impl.export_exr(path); }); }
 float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms)
 {

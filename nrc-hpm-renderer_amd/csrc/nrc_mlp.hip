@@ -1420,17 +1420,17 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
 }
 
-static int g_num_cus = 0;
-static int num_cus()
+// CU count of the device this Mlp lives on (one instance per GPU: no process-wide cache)
+int Mlp::num_cus()
 {
-    if (g_num_cus == 0) {
+    if (num_cus_ == 0) {
         int dev = 0;
         NRC_HIP(hipGetDevice(&dev));
         hipDeviceProp_t prop;
         NRC_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    return g_num_cus;
+    return num_cus_;
 }
 
 template <int THREADS, int NT>
@@ -1486,13 +1486,12 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             const uint32_t cap = (uint32_t)num_cus();
             if (blocks > cap) blocks = cap;
             const size_t lds = 2 * 32 * 1024;
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!attr_infer_set_) {      // per instance = per device: the attribute belongs to the device's code object
                 NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
+                attr_infer_set_ = true;
             }
             if (hash_)
                 hipLaunchKernelGGL((k_infer_gen<128, 512, true>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
@@ -1504,22 +1503,28 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
         NRC_HIP(hipGetLastError());
         return;
     }
-    // persistent workgroups sharing one 54 KB weight image in LDS.  Tunables (env, read once): workgroup size,
-    // tiles per wave iteration, workgroups per CU.
-    static const int threads = [] { const char* e = getenv("NRC_INFER_THREADS"); return e ? atoi(e) : 512; }();
-    static const int nt = [] { const char* e = getenv("NRC_INFER_NT"); return e ? atoi(e) : 2; }();
-    static const int bpc = [] { const char* e = getenv("NRC_INFER_BPC"); return e ? atoi(e) : 2; }();
+    // persistent workgroups sharing one 54 KB weight image in LDS: 8 waves x 2 tiles per iteration, two workgroups per CU.
+    // The shape sweeps and ablations that led here (256...1024 threads, 1...4 tiles, no-encode / no-ReLU variants, in-kernel
+    // clock stamps) exist only in the diagnostic build (make EXTRA=-DNRC_DIAG OUT=../lib_diag; tools/bench_mlp.py).
+    int threads = 512, nt = 2, bpc = 2;
+#ifdef NRC_DIAG
+    static const int e_threads = [] { const char* e = getenv("NRC_INFER_THREADS"); return e ? atoi(e) : 512; }();
+    static const int e_nt = [] { const char* e = getenv("NRC_INFER_NT"); return e ? atoi(e) : 2; }();
+    static const int e_bpc = [] { const char* e = getenv("NRC_INFER_BPC"); return e ? atoi(e) : 2; }();
+    threads = e_threads; nt = e_nt; bpc = e_bpc;
+#endif
     const uint32_t n_tiles = ceil_div(n, 32);
     const uint32_t max_blocks = (uint32_t)num_cus() * (uint32_t)bpc;
     uint32_t blocks = ceil_div(n_tiles, (uint32_t)(threads / 64) * (uint32_t)nt);
     if (blocks > max_blocks) blocks = max_blocks;
     const size_t lds = (size_t)n_frag_fwd_ * 1024;
+    const int sz = skip_zero_queries ? 1 : 0;
+#ifdef NRC_DIAG
     static const int abl = [] { const char* e = getenv("NRC_INFER_ABL"); return e ? atoi(e) : 0; }();
-    if (abl != 0) {       // diagnostic builds only (ablations / in-kernel clock): tools/bench_mlp.py
+    if (abl != 0) {       // ablations / in-kernel clock: tools/bench_mlp.py
         infer_diagnostic(abl, blocks, lds, s, d_in, d_out, n, img);
         return;
     }
-    const int sz = skip_zero_queries ? 1 : 0;
     if (threads == 1024 && nt == 1) launch_infer<1024, 1>(blocks, lds, s, d_in, d_out, n, img, sz);
     else if (threads == 256 && nt == 1) launch_infer<256, 1>(blocks, lds, s, d_in, d_out, n, img, sz);
     else if (threads == 256 && nt == 2) launch_infer<256, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
@@ -1528,10 +1533,13 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     else if (threads == 512 && nt == 3) launch_infer<512, 3>(blocks, lds, s, d_in, d_out, n, img, sz);
     else if (threads == 256 && nt == 3) launch_infer<256, 3>(blocks, lds, s, d_in, d_out, n, img, sz);
     else if (threads == 256 && nt == 4) launch_infer<256, 4>(blocks, lds, s, d_in, d_out, n, img, sz);
-    else launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
+    else
+#endif
+    launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
     NRC_HIP(hipGetLastError());
 }
 
+#ifdef NRC_DIAG
 // diagnostics of the fused inference kernel (never on the product path): ABL 1/2/3 drop the encoding / ReLU-convert work,
 // ABL 4 stamps s_memtime / s_memrealtime per workgroup and prints the in-kernel clock and inter-kernel gaps
 void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
@@ -1574,6 +1582,7 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
     else hipLaunchKernelGGL((k_infer<6, 512, 1, 3>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
     NRC_HIP(hipGetLastError());
 }
+#endif
 
 void Mlp::ensure_train_workspace(uint32_t n)
 {
@@ -1633,18 +1642,17 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.in = d_in;
         a.target = d_target;
         a.n = n;
-        a.inv_n_total = 1.0f / (float)(3u * n_norm);
+        a.inv_n_total = (float)(1.0 / (3.0 * (double)n_norm));      // 3 * n_norm can exceed 32 bits
         a.loss_id = loss_id_;
         a.acts = (half_t*)d_acts_;
         a.deltas = (half_t*)d_deltas_;
         a.loss_part = d_loss_part_;
         if (blocks > (uint32_t)num_cus()) blocks = (uint32_t)num_cus();
         const size_t lds = ((size_t)n_frag_fwd_ + n_frag_bwd_) * 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!attr_train_set_) {
             NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_fwd_bwd<6, THREADS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_train_set_ = true;
         }
         hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
                            (const uint4*)d_pk_bwd_);
@@ -1655,7 +1663,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.feat = (const half_t*)d_feat_[1];
         a.target = d_target;
         a.n = n;
-        a.inv_n_total = 1.0f / (float)(3u * n_norm);
+        a.inv_n_total = (float)(1.0 / (3.0 * (double)n_norm));      // 3 * n_norm can exceed 32 bits
         a.loss_id = loss_id_;
         a.acts = (half_t*)d_acts_;
         a.deltas = (half_t*)d_deltas_;

@@ -39,11 +39,16 @@ public:
     static constexpr float kLossScale = 128.0f;
 
 private:
+    int num_cus();
+    int num_cus_ = 0;
+    bool attr_infer_set_ = false, attr_train_set_ = false;     // hipFuncSetAttribute done on this instance's device
     void ensure_train_workspace(uint32_t n);
     void ensure_features(uint32_t n, int slot);
     void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero);
+#ifdef NRC_DIAG
     void infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
                           const void* image);
+#endif
 
     nrc_config cfg_;
     uint32_t width_, depth_, enc_dims_, n_params_;

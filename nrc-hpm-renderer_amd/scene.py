@@ -181,6 +181,24 @@ def smoke_volume(n=512, seed=1337):
     return d
 
 
+def cached_volume(kind, n, seed=1337, cache_dir="/tmp"):
+    """quantised synthetic volume (`kind`: "cloud" = fbm_cloud_volume, "smoke" = smoke_volume, "sphere"), generated once per
+    box and kept as an .npy under `cache_dir` (the 512^3 smoke takes about a minute and 5 GB of host memory to generate)"""
+    import os
+    gen = {"cloud": fbm_cloud_volume, "smoke": smoke_volume, "sphere": lambda n, seed=0: sphere_volume(n)}[kind]
+    path = os.path.join(cache_dir, "nrc_%s_%d_%d.npy" % (kind, n, seed))
+    if os.path.exists(path):
+        return np.load(path)
+    vol = quantize_density(gen(n, seed=seed))
+    try:
+        tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+        np.save(tmp, vol)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return vol
+
+
 def make_scene(density_u8, scene_id=4, env=None, g=0.8, dims=None, size=None):
     """Bundle scene inputs.  density_u8: uint8 array in texture memory order [k][j][i] (see quantize_density)."""
     dl, pl, env_s, rho = SCENE_PRESETS[scene_id]

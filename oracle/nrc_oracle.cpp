@@ -861,7 +861,7 @@ float orc_nn_backward(void* p, const float* in, const float* target, uint32_t n,
     std::vector<std::vector<float>> acts(depth);
     std::vector<float> delta, prev;
     double loss_sum = 0.0;
-    const float n_total = (float)(3u * n_norm);
+    const float n_total = (float)(3.0 * (double)n_norm);
     for (uint32_t i = 0; i < n; i++) {
         float y[3];
         encode_one(*nn, in + 5 * (size_t)i, enc.data(), table, true);

@@ -1,15 +1,16 @@
 // A host program written against the reference's C++ surface (include/nrc_hpm.hpp, namespace en) the way src/main.cu uses
-// it: AppConfig from the 17 positional arguments, NeuralRadianceCache, NrcHpmRenderer, Render(queue, true) per frame,
-// GetLoss(), GetImage().  tests/test_gpu_cpp_dropin.py feeds it a scene file, and compares what it writes with the same
-// frames rendered through the Python mirror.
+// it (:152-419): AppConfig from the 17 positional arguments, NeuralRadianceCache, HpmScene(appConfig), Camera(pos, viewDir, up,
+// aspect, fov, near, far), NrcHpmRenderer(width, height, blend, &camera, appConfig, hpmScene, nrc), Render(queue, true) and a
+// GetLoss() poll per frame, IsBlending(), GetImage().  tests/test_gpu_cpp_dropin.py feeds it a volume, and compares what it
+// writes with the same frames rendered through the Python mirror.
 //
 //   dropin_main <scene.bin> <out.bin> <frames> <17 positional AppConfig arguments>
 //
-// scene.bin: u32 width,height,nx,ny,nz; f32 size[3], density_factor, g, dir_light_dir[3], dir_light_strength,
-//            point_light_pos[3], point_light_strength, point_light_color[3], env_strength, env rgba (1x1), inv_proj_view[16],
-//            cam_pos[3]; f32 frame_random[frames][4]; u8 density[nx*ny*nz]
+// scene.bin: u32 width,height,nx,ny,nz; f32 env rgba (1x1); f32 frame_random[frames][4]; u8 density[nx*ny*nz]
+// out.bin:   f32 loss; f32 inv_proj_view[16], cam_pos[3] (what en::Camera computed); f32 dir_light_dir[3]; f32 image[h][w][4]
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -36,34 +37,34 @@ int main(int argc, char** argv)
         uint32_t dims[5];
         rd(f, dims, 5);
         const uint32_t W = dims[0], H = dims[1];
-        nrc_scene scene{};
-        nrc_camera camera{};
-        scene.nx = dims[2]; scene.ny = dims[3]; scene.nz = dims[4];
-        rd(f, scene.size, 3); rd(f, &scene.density_factor, 1); rd(f, &scene.g, 1);
-        rd(f, scene.dir_light_dir, 3); rd(f, &scene.dir_light_strength, 1);
-        rd(f, scene.point_light_pos, 3); rd(f, &scene.point_light_strength, 1);
-        rd(f, scene.point_light_color, 3); rd(f, &scene.env_strength, 1);
+        const uint32_t nx = dims[2], ny = dims[3], nz = dims[4];
         float env[4];
         rd(f, env, 4);
-        rd(f, camera.inv_proj_view, 16); rd(f, camera.pos, 3);
         std::vector<float> randoms((size_t)frames * 4);
         rd(f, randoms.data(), randoms.size());
-        std::vector<uint8_t> density((size_t)scene.nx * scene.ny * scene.nz);
+        std::vector<uint8_t> density((size_t)nx * ny * nz);
         rd(f, density.data(), density.size());
         std::fclose(f);
-        scene.density = density.data();
-        scene.env = env; scene.env_w = 1; scene.env_h = 1;
 
         // src/main.cu:175,203-210: the cache first, then the renderer that holds a reference to it
         en::NeuralRadianceCache nrc(appConfig);
-        en::NrcHpmRenderer nrcHpmRenderer(W, H, false, &camera, appConfig, scene, nrc);
+        en::HpmScene hpmScene(appConfig, density.data(), nx, ny, nz, env, 1, 1);          // src/main.cu:177
+        const float aspectRatio = static_cast<float>(W) / static_cast<float>(H);
+        en::Camera camera(en::vec3(64.0f, 0.0f, 0.0f), en::vec3(-1.0f, 0.0f, 0.0f), en::vec3(0.0f, 1.0f, 0.0f), aspectRatio,
+                          en::radians(60.0f), 0.1f, 100.0f);                                // src/main.cu:180-187
+        en::NrcHpmRenderer nrcHpmRenderer(W, H, false, &camera, appConfig, hpmScene, nrc);  // src/main.cu:203-210
+        if (nrcHpmRenderer.IsBlending()) throw std::runtime_error("IsBlending() after blend = false");
         nrcHpmRenderer.SetBlend(true);
-        float loss = 0.0f;
+        if (!nrcHpmRenderer.IsBlending()) throw std::runtime_error("IsBlending() after SetBlend(true)");
+        float polled = 0.0f;
         for (int i = 0; i < frames; i++) {
             en::nrc_check(nrc_renderer_set_frame_random(nrcHpmRenderer.Handle(), &randoms[(size_t)i * 4]));
+            if (hpmScene.Update(false, 0.016f)) nrcHpmRenderer.SetSceneParams(hpmScene);  // src/main.cu:264 (static presets: no-op)
             nrcHpmRenderer.Render(nullptr, true);                 // src/main.cu:287
-            loss = nrc.GetLoss();                                   // src/main.cu:376
+            polled = nrc.GetLoss();                                 // src/main.cu:376 -- non-blocking: last completed step
+            if (std::isnan(polled) || std::isinf(polled)) throw std::runtime_error("NaN loss");   // src/main.cu:380-384
         }
+        const float loss = nrc.GetLossBlocking();
         nrcHpmRenderer.EvaluateTimestampQueries();
         std::vector<float> image((size_t)W * H * 4);
         const float* d_image = nrcHpmRenderer.GetImage();
@@ -72,6 +73,9 @@ int main(int argc, char** argv)
         FILE* o = std::fopen(argv[2], "wb");
         if (!o) throw std::runtime_error("cannot open output file");
         std::fwrite(&loss, sizeof(float), 1, o);
+        std::fwrite(camera.Matrices()->inv_proj_view, sizeof(float), 16, o);
+        std::fwrite(camera.Matrices()->pos, sizeof(float), 3, o);
+        std::fwrite(hpmScene.Scene().dir_light_dir, sizeof(float), 3, o);
         std::fwrite(image.data(), sizeof(float), image.size(), o);
         std::fclose(o);
         std::printf("frames %d loss %.9g frame %.3f ms name %s\n", frames, loss, nrcHpmRenderer.GetFrameTimeMS(), appConfig.GetName().c_str());

@@ -25,12 +25,7 @@ def test_cpp_host_program_matches_python_mirror(api, sc, torch_gpu, tmp_path):
     frs = sc.frame_randoms(frames, seed=5)
     with open(tmp_path / "scene.bin", "wb") as f:
         f.write(struct.pack("5I", W, H, *scene["dims"]))
-        for key in ("size", "density_factor", "g", "dir_light_dir", "dir_light_strength", "point_light_pos", "point_light_strength",
-                    "point_light_color", "env_strength"):
-            f.write(np.asarray(scene[key], np.float32).tobytes())
         f.write(np.asarray(scene["env"], np.float32).reshape(-1)[:4].tobytes())
-        f.write(np.asarray(cam["inv_proj_view"], np.float32).tobytes())
-        f.write(np.asarray(cam["pos"], np.float32).tobytes())
         f.write(np.asarray(frs, np.float32).tobytes())
         f.write(np.ascontiguousarray(scene["density"], np.uint8).tobytes())
     r = subprocess.run([exe, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(frames)] + ARGS,
@@ -38,7 +33,14 @@ def test_cpp_host_program_matches_python_mirror(api, sc, torch_gpu, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "name RelativeL2Luminance_Adam_0.010000_0.990000_3_0_64_6_14_10_1_4_1.000000_1_1_0.000000_32" in r.stdout
     raw = np.fromfile(tmp_path / "out.bin", np.float32)
-    loss_cpp, img_cpp = raw[0], raw[1:].reshape(H, W, 4)
+    loss_cpp, cam_cpp, light_cpp, img_cpp = raw[0], raw[1:20], raw[20:23], raw[23:].reshape(H, W, 4)
+    # en::Camera (glm's fp32 perspective * lookAt, cofactor inverse) agrees with the Python mirror's float64 construction to
+    # fp32 rounding; en::HpmScene places the directional light like scene.dir_light_dir().  The frames are then compared bit for
+    # bit for the camera the C++ program actually used.
+    assert np.allclose(cam_cpp[:16], cam["inv_proj_view"], rtol=2e-6, atol=1e-6) and np.array_equal(cam_cpp[16:], cam["pos"])
+    assert np.allclose(light_cpp, scene["dir_light_dir"], atol=1e-7)
+    cam = dict(inv_proj_view=cam_cpp[:16].copy(), pos=cam_cpp[16:19].copy())
+    scene = dict(scene, dir_light_dir=light_cpp.copy())
 
     cfg = api.AppConfig(["NRC-HPM-Renderer"] + ARGS)
     nrc = api.NeuralRadianceCache(cfg)

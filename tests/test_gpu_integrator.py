@@ -494,28 +494,57 @@ def test_set_camera_resets_accumulation(api, sc, sphere_scene, torch_gpu):
     fresh.Destroy()
 
 
-def test_full_size_frame_against_reference_exr_statistics(api, sc, cloud16, exr_stats, torch_gpu):
-    """BASELINE size: 1920x1080 MC (PATH_LENGTH 32, 32 blended frames) of the reference's own cloud and scene 4 against
-    reference/4/0.exr: mean radiance within 2 %, mean alpha within 0.01, silhouette IoU on the
-    240x135 down-sample > 0.93"""
-    W, H = 1920, 1080
-    scene = sc.make_scene(cloud16, scene_id=4)
-    cam = sc.make_camera(aspect=W / H)
-    mc = api.McHpmRenderer(W, H, 32, True, cam, scene)
-    for _ in range(32):
-        mc.Render()
-    img = mc.GetImage().cpu().numpy()
-    st = exr_stats["4"]
-    assert np.isfinite(img).all()
-    assert abs(img[..., :3].mean() / st["mean_rgb_all"] - 1.0) < 0.02
-    assert abs(img[..., 3].mean() - st["mean_alpha"]) < 0.01
-    ds = img.reshape(135, 8, 240, 8, 4).mean(axis=(1, 3))
-    ref = np.load(os.path.join(GOLDEN, "exr_4_240x135.npz"))["rgba"]
-    a, b = ds[..., 3] > 0.5, ref[..., 3] > 0.5
-    assert (a & b).sum() / (a | b).sum() > 0.93
-    bg = img[img[..., 3] == 0]
-    assert np.allclose(bg[:, :3], st["background"], atol=2e-4)
-    mc.Destroy()
+def _gpu_pair(api, sc, cloud16, name, frames, seed=7):
+    import exr_pin
+    cam = sc.make_camera(aspect=1920 / 1080)
+    out = []
+    for scene in exr_pin.perturbed(sc, cloud16, name):
+        mc = api.McHpmRenderer(1920, 1080, 32, True, cam, scene)
+        frs = sc.frame_randoms(frames, seed=seed)
+        for f in range(frames):
+            mc.SetFrameRandom(frs[f])
+            mc.Render()
+        out.append(mc.GetImage().cpu().numpy())
+        mc.Destroy()
+    return out
+
+
+def test_reference_exr_pin_per_pixel_and_it_bites(api, sc, cloud16, exr_stats, torch_gpu):
+    """The reference-held pin at full size (tests/exr_pin.py): McHpmRenderer at 1920x1080, PATH_LENGTH 32, 2048 blended frames of
+    the reference's cloud, scenes 0 and 4, down-sampled 8x8 like the fixtures and compared with reference/0/0.exr and
+    reference/4/0.exr per pixel: directional term within -2.5 %...+2.5 % (measured -1.95 %: the sixteenth-resolution cloud
+    transmits less than the quarter-resolution one the EXRs were rendered with), env term within 1.5 % (measured -0.1 %),
+    interior pattern correlation >= 0.98 and per-pixel L2 <= 13 %, silhouette, centre block, maximum, background, relBias.
+    The same bounds REJECT renders with one term of the estimator changed (a biting pin): directional light x1.05 / x0.98,
+    env x1.1 / x0.8, g 0.75 / 0.85 / -0.8, density x1.1 / x0.9, the light from the opposite side / from above."""
+    import exr_pin
+    b = exr_pin.bounds()
+    own0, own4 = _gpu_pair(api, sc, cloud16, "none", 2048)
+    assert np.isfinite(own0).all() and np.isfinite(own4).all()
+    st = exr_pin.pin_statistics(exr_pin.downsample8(own0), exr_pin.downsample8(own4))
+    assert exr_pin.violations(st, b) == [], st
+    # full-resolution facts of SURVEY App. E that need no down-sampling
+    assert abs(own4[..., :3].mean() / exr_stats["4"]["mean_rgb_all"] - 1.0) < 0.02
+    assert abs(own0[..., :3].mean() / exr_stats["0"]["mean_rgb_all"] - 1.0) < 0.025
+    assert abs(own0[..., 3].mean() - exr_stats["0"]["mean_alpha"]) < 0.006
+    assert np.allclose(own4[own4[..., 3] == 0][:, :3], exr_stats["4"]["background"], atol=2e-4)
+    assert (own0[own0[..., 3] == 0][:, :3] == 0).all()
+    # Reference::Result through the product's own metric kernels (nrc_compare_images) on the down-sampled pair
+    ref0, ref4 = exr_pin.load_refs()
+    for ref, own in ((ref0, exr_pin.downsample8(own0)), (ref4, exr_pin.downsample8(own4))):
+        r = api.CompareImages(torch_gpu.from_numpy(ref).cuda(), torch_gpu.from_numpy(own).cuda())
+        m = exr_pin.result_metrics(ref, own)
+        assert abs(r["mse"] - m["mse"]) < 1e-5 * max(1.0, m["mse"]) and r["valid"] == m["valid"]
+        assert abs((r["own_mean"] - r["ref_mean"]) / r["ref_mean"]) < 0.03            # GetRelBias
+        assert r["mse"] < 0.01                                                         # measured 0.0048 / 0.0012
+    flagged = {}
+    for name, must_flag in (("dir_x1.05", "dir_ratio"), ("dir_x0.98", "dir_ratio"), ("env_x1.1", "env_ratio"), ("env_x0.8", "env_ratio"),
+                            ("g=0.75", "dir_ratio"), ("g=0.85", "dir_ratio"), ("g=-0.8", "corr0"), ("density_x1.1", "dir_ratio"),
+                            ("density_x0.9", "centre0"), ("light_from_opposite_side", "corr0"), ("light_from_above", "corr0")):
+        p0, p4 = _gpu_pair(api, sc, cloud16, name, 768)
+        bad = exr_pin.violations(exr_pin.pin_statistics(exr_pin.downsample8(p0), exr_pin.downsample8(p4)), b)
+        flagged[name] = bad
+        assert any(v.startswith(must_flag) for v in bad), (name, bad)
 
 
 def test_full_size_nrc_frame_rows_bitwise_against_oracle(api, orc, sc, cloud16, torch_gpu):

@@ -343,10 +343,12 @@ def test_random_model_configurations_match_oracle(api, orc, torch_gpu):
         c.Destroy()
 
 
-@pytest.mark.parametrize("dir_id,width,depth,log2", [(0, 64, 6, 12), (1, 64, 2, 10), (0, 128, 4, 14)])
+@pytest.mark.parametrize("dir_id,width,depth,log2", [(0, 64, 6, 12), (1, 64, 2, 10), (0, 128, 4, 14), (0, 64, 6, 19)],
+                         ids=["2^12", "2^10-identity-dir", "2^14-128wide", "reference-default-2^19"])
 def test_hashgrid_model_matches_oracle(api, orc, torch_gpu, dir_id, width, depth, log2):
     """reference default encoding, AppConfig posID 0 (src/AppConfig.cpp:19-27, src/main.cu:435): HashGrid forward,
-    dL/d(table) scatter, Adam that skips untouched entries, EMA table for inference"""
+    dL/d(table) scatter, Adam that skips untouched entries, EMA table for inference.  The last case is the reference's real
+    model -- 2^19 entries per hashed level, 14.2 M table parameters, 6x64 network -- against the oracle on 2 048 samples"""
     c = api.NeuralRadianceCache(api.AppConfig(pos_id=0, dir_id=dir_id, nn_width=width, nn_depth=depth, hashgrid_log2_size=log2))
     onn = orc.nn_create(pos_id=0, dir_id=dir_id, width=width, depth=depth, hashgrid_log2_size=log2)
     assert c.ParamCount() == onn.n_params

@@ -50,6 +50,35 @@ def test_mc_render_matches_reference_exr_statistics(orc, sc, cloud16, exr_stats,
     assert (a[::-1] & b).sum() / (a[::-1] | b).sum() < 0.7
 
 
+def _oracle_pair(orc, sc, cloud16, name, frames):
+    import exr_pin
+    cam = sc.make_camera(aspect=1920 / 1080)
+    out = []
+    for scene in exr_pin.perturbed(sc, cloud16, name):
+        img = np.zeros((exr_pin.DS_H, exr_pin.DS_W, 4), np.float32)
+        frs = sc.frame_randoms(frames, seed=7)
+        for f in range(frames):
+            img, _, _ = orc.mc_render(scene, cam, exr_pin.DS_W, exr_pin.DS_H, 32, frs[f], blend=1.0 / (f + 1), out=img, threads=8)
+        out.append(img)
+    return out
+
+
+def test_reference_exr_pin_per_pixel_and_it_bites(orc, sc, cloud16):
+    """The reference-held pin, made to bite (tests/exr_pin.py): the oracle's renders of scenes 0 and 4 against the two EXRs per
+    pixel on the 240x135 grid -- directional term, env term (scene 4 - scene 0 / 2), shading pattern, silhouette, centre block,
+    maximum, background, Reference::Result relBias -- inside bounds centred on agreement; and the same check REJECTS renders in
+    which one term of the estimator is off: directional light x1.05, env x1.25, g 0.75 instead of 0.8, density x1.1, the light
+    from above.  (The GPU test of the same name runs the tight bounds at 1920x1080 and more variants.)"""
+    import exr_pin
+    b = exr_pin.bounds(wide=True)
+    st = exr_pin.pin_statistics(*_oracle_pair(orc, sc, cloud16, "none", 512))
+    assert exr_pin.violations(st, b) == [], st
+    for name, must_flag in (("dir_x1.05", "dir_ratio"), ("env_x1.25", "env_ratio"), ("g=0.75", "dir_ratio"),
+                            ("density_x1.1", "dir_ratio"), ("light_from_above", "corr0")):
+        bad = exr_pin.violations(exr_pin.pin_statistics(*_oracle_pair(orc, sc, cloud16, name, 128)), b)
+        assert any(v.startswith(must_flag) for v in bad), (name, bad)
+
+
 def test_background_is_env_times_strength(orc, sc, cloud16):
     scene = sc.make_scene(cloud16, scene_id=4)
     cam = sc.make_camera()

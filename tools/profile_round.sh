@@ -1,0 +1,47 @@
+#!/bin/bash
+# One GPU session's worth of measurements for profiles/rNN_* (run on the MI355X box from the repo root):
+#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin   (default: all)
+# Output goes to gpurun_out/<tag>/ ; copy the summaries worth keeping into profiles/ afterwards (tools/profile_collect.py).
+# rocprofv3 is always given the interpreter binary itself after `--` (no env / bash -c / shebang hop) and counters are
+# collected in passes of their own (no trace domains beside --pmc).
+set -o pipefail
+TAG=${1:-r02}; shift
+STEPS=${*:-micro mlp bench pmc pin}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+PY=$(readlink -f "$(command -v python3)")
+has() { [[ " $STEPS " == *" $1 "* ]]; }
+
+if has micro; then
+  echo "== micro" && timeout -k 10 120 tools/_build/valu_rate > "$OUT/valu_rate.txt" 2>&1 || exit 1
+fi
+if has mlp; then
+  echo "== mlp kernel trace (dense k_infer alone)"
+  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_mlp" -o mlp -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 20) > "$OUT/prof_mlp.log" 2>&1 || exit 1
+  echo "== mlp MFMA counters"
+  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+      -d "$OUT/pmc_mlp_mfma" -o mlp -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 4) > "$OUT/pmc_mlp_mfma.log" 2>&1 || exit 1
+  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES SQ_VALU_MFMA_COEXEC_CYCLES \
+      -d "$OUT/pmc_mlp_sq" -o mlp -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 4) > "$OUT/pmc_mlp_sq.log" 2>&1 || exit 1
+fi
+if has bench; then
+  echo "== bench (plain)" && timeout -k 10 400 "$PY" bench.py --steps 100 --warmup 10 > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+  echo "== bench kernel trace"
+  (cd /tmp && timeout -k 10 400 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_bench" -o bench -- "$PY" "$REPO/bench.py" --steps 25 --warmup 2 --no-cpu-baseline) > "$OUT/prof_bench.log" 2>&1 || exit 1
+fi
+if has pmc; then
+  B="$PY $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+  echo "== pmc FETCH_SIZE";  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o b -- $B) > "$OUT/pmc_fetch.log" 2>&1 || exit 1
+  echo "== pmc WRITE_SIZE";  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o b -- $B) > "$OUT/pmc_write.log" 2>&1 || exit 1
+  echo "== pmc TCC";         (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tcc" -o b -- $B) > "$OUT/pmc_tcc.log" 2>&1 || exit 1
+  echo "== pmc SQ";          (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o b -- $B) > "$OUT/pmc_sq.log" 2>&1 || exit 1
+fi
+if has pin; then
+  echo "== exr pin calibration" && timeout -k 10 600 "$PY" tools/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
+fi
+# keep the merge-back small: the raw rocprofv3 databases are large, the CSVs are what gets read
+find "$OUT" -name "*.db" -delete 2>/dev/null
+du -sh "$OUT"
+echo "== done"
