@@ -7,10 +7,15 @@ sub-frame is what one reference frame is, `NrcHpmRenderer::Render(queue, true)` 
 NRC inference for every pixel, train-ray generation, 16 384 train rays + one Adam step (configs[2]), compositing.
 `--train 0` drops the training step.  One sample = one pixel path.
 
-  python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; the frame is sharded by interleaved pixel columns
-(weak scaling: every rank keeps a 1920x1080-pixel tile of a larger frame) and the MLP gradients are all-reduced
-over RCCL each training step.  Rank 0 prints ONE JSON line.
+  python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
+N > 1: launched by torch.distributed.run, one rank per GPU; the frame is sharded by interleaved pixel columns and the MLP
+gradients are all-reduced over RCCL each training step (by the library itself: nrc_cache_comm_init).  Rank 0 prints ONE JSON line.
+
+  --config c2 (default)  configs[1]+[2]: 1920x1080 per GPU, 256^3 cloud, 4 spp, 6x64; N > 1 is WEAK scaling (every rank keeps a
+                         1920x1080-pixel tile of a larger frame, 16 384 train rays per rank)
+  --config c4            configs[3]: ONE 3840x2160 frame, 8 spp, sharded over the N ranks; STRONG scaling (the global frame and the
+                         global train batch of 16 384 rays are fixed: each rank gets 1/N of both)
+  --config c5            configs[4]: 512^3 seeded smoke, 8x128 MLP + one-blob, 1920x1080 per GPU, 4 spp (weak scaling like c2)
 """
 import argparse
 import json
@@ -30,12 +35,32 @@ MLP_FLOP_PER_SAMPLE = 51584.0      # 2*(80*64 + 5*64*64 + 64*3), SURVEY.md 8(d)
 MLP_BYTES_PER_SAMPLE = 32.0        # 20 B query + 12 B radiance
 
 
-def global_frame(n_gpus, w, h):
-    """weak scaling: every rank renders w*h pixels (interleaved columns) of a larger frame"""
+def global_frame(n_gpus, w, h, strong=False):
+    """weak scaling: every rank renders w*h pixels (interleaved columns) of a larger frame; strong: w x h IS the global frame"""
+    if strong:
+        return (w, h)
     table = {1: (w, h), 2: (2 * w, h), 4: (2 * w, 2 * h), 8: (4 * w, 2 * h)}
     if n_gpus in table:
         return table[n_gpus]
     return (n_gpus * w, h)
+
+
+def gpu_mc_baseline(api, sc, scene, W, H, frames=20):
+    """the like-for-like GPU figure beside cpu_baseline: McHpmRenderer (mc/render.comp, PATH_LENGTH 32), same scene and camera"""
+    import torch
+    cam = sc.make_camera(aspect=W / H)
+    mc = api.McHpmRenderer(W, H, 32, True, cam, scene)
+    for _ in range(3):
+        mc.Render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        mc.Render()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mc.Destroy()
+    return dict(value=W * H * frames / dt / 1e6, unit="Msamples/s", ms_per_frame=dt / frames * 1e3,
+                kernel="k_mc_render (mc/render.comp, PATH_LENGTH 32)", sample="%d frames of %dx%d" % (frames, W, H))
 
 
 def cpu_baseline(scene, W, H, budget_s=float(os.environ.get("NRC_BENCH_CPU_BUDGET_S", "20"))):
@@ -91,7 +116,13 @@ def main():
     ap.add_argument("--nn-width", type=int, default=64)
     ap.add_argument("--nn-depth", type=int, default=6)
     ap.add_argument("--smoke-volume", action="store_true", help="configs[4]: seeded smoke plume instead of the fBm cloud")
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="BASELINE.json preset (see the module docstring)")
     args = ap.parse_args()
+    strong = False
+    if args.config == "c4":        # configs[3]: one 4K frame, 8 spp, tile shard, global train batch fixed
+        args.width, args.height, args.spp, strong = 3840, 2160, 8, True
+    elif args.config == "c5":      # configs[4]: 512^3 smoke + 8x128
+        args.volume, args.smoke_volume, args.nn_width, args.nn_depth = 512, True, 128, 8
 
     import numpy as np
     import torch
@@ -116,24 +147,36 @@ def main():
     # ---- synthetic inputs: seeded 256^3 fBm cloud, procedural HDR sky, scene preset 4 values
     vol = sc.cached_volume("smoke" if args.smoke_volume else "cloud", args.volume, seed=1337)
     scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky())
-    gw, gh = global_frame(world, W, H)
+    gw, gh = global_frame(world, W, H, strong)
     tile = parallel.column_tile(rank, world, gw, gh)          # (x_offset, x_stride, global_w, global_h), local width
     local_w = parallel.local_width(rank, world, gw)
     cam = sc.make_camera(aspect=gw / gh)
-    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=14, log2_infer_batch_size=21, scene_id=4,
+    # strong scaling keeps the GLOBAL train batch at 16 384 rays (2^14 / world per rank; world must be a power of two <= 512)
+    log2_train = 14
+    if strong:
+        if world & (world - 1) or world > 512:
+            raise SystemExit("--config c4 needs a power-of-two world size")
+        log2_train = 14 - (world.bit_length() - 1)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=log2_train, log2_infer_batch_size=21, scene_id=4,
                         primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337,
                         pos_id=args.pos_id, dir_id=args.dir_id, nn_width=args.nn_width, nn_depth=args.nn_depth)
     north_star = (args.pos_id, args.dir_id, args.nn_width, args.nn_depth) == (3, 0, 64, 6)
     nrc = api.NeuralRadianceCache(cfg)
     ren = api.NrcHpmRenderer(local_w, gh, True, cam, cfg, scene, nrc, tile=tile)
+    exchange = dict(path="none", rccl_rank=None, rccl_ranks=0)
     if use_dist and args.train:
         # RCCL all-reduce of the MLP gradients every training step: issued by the library itself on its training stream; if the
         # library cannot bring up its own communicator the same exchange goes through torch.distributed's RCCL communicator
         try:
             parallel.attach_gradient_allreduce(nrc, world)
+            r_, w_ = nrc.CommInfo()              # what ncclCommUserRank / ncclCommCount say
+            exchange = dict(path="native (nrc_cache_comm_init -> ncclAllReduce on the training stream)", rccl_rank=r_, rccl_ranks=w_)
+            if w_ != world:
+                raise RuntimeError("RCCL communicator reports %d ranks, expected %d" % (w_, world))
         except RuntimeError as e:
             print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
             parallel.attach_gradient_allreduce(nrc, world, native=False)
+            exchange = dict(path="torch.distributed hook (fallback)", rccl_rank=rank, rccl_ranks=world)
     randoms = sc.frame_randoms((args.steps + args.warmup) * spp + 8, seed=1337)
     ri = [0]
 
@@ -164,24 +207,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = nrc.GetLoss() if args.train else None
-    samples = float(local_w) * gh * spp * args.steps * world
+    # every rank's own pixel count (interleaved columns: local widths differ by at most one column)
+    samples = float(sum(parallel.local_width(r, world, gw) for r in range(world))) * gh * spp * args.steps
     value = samples / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
 
-    # ---- integrator traffic model: density fetches counted on the device for one extra (untimed) sub-frame
-    ren.CountFetches(True)
-    ren.SetFrameRandom(randoms[0])
-    ren.Render(None, False)
-    torch.cuda.synchronize()
-    n_fetch = ren.CountFetches(False)
+    # ---- integrator traffic model: density look-ups counted on the device for extra (untimed) sub-frames of the same seed --
+    # n_fetch: the ALGORITHM's look-ups (every camera ray walked, as the reference and the oracle do; empty-space early-out off),
+    # n_fetch_executed: what the timed kernel really issues (early-out on: rays through provably empty space skip their walk)
+    def count(skip):
+        ren.SetEmptySkip(skip)
+        ren.CountFetches(True)
+        ren.SetFrameRandom(randoms[0])
+        ren.Render(None, False)
+        torch.cuda.synchronize()
+        return ren.CountFetches(False)
+
+    n_fetch = count(False)
+    n_fetch_executed = count(True)
     n_px = local_w * gh
 
     out = None
     if rank == 0:
         # ---- per-launch figures.  k_infer: event-timed loop on the launch stream (same buffers the frame uses); k_gen_rays:
-        # the renderer's own HIP events around the launch, averaged over the timed region.  `traffic` = HBM-side bytes per
-        # launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, gfx950
-        # corrections of MI355X_MICROARCH.md) -- only quoted when this run is the profiled workload.
+        # the renderer's own HIP events around the launch, averaged over the timed region.
         n_inf = n_px
         d_out = ren.Buffer("infer_output")
 
@@ -205,53 +254,65 @@ def main():
         rnd[:, :3] += 31.0
         mlp_ms = time_infer(rnd)
         mlp_ms_frame = time_infer(ren.Buffer("infer_input"))
-        mlp_tflops = MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms * 1e-3) / 1e12
+        # FLOP per sample of the configured model: 2 * (E * W + (D - 1) * W^2 + W * 3), E = encoded input dims
+        enc = {0: 32, 1: 3, 2: 36, 3: 72}[args.pos_id] + {0: 8, 1: 2, 2: 8}[args.dir_id]
+        flop = 2.0 * (enc * args.nn_width + (args.nn_depth - 1) * args.nn_width ** 2 + args.nn_width * 3)
+        assert not north_star or flop == MLP_FLOP_PER_SAMPLE
+        mlp_tflops = flop * n_inf / (mlp_ms * 1e-3) / 1e12
         if not (0.0 < mlp_tflops < MFMA_F16_PEAK_TFLOPS):
             raise RuntimeError("MLP timing is not physical (%.1f TFLOP/s): the events did not bracket the kernel's stream" % mlp_tflops)
         gen_ms = stats["gen_rays"]
-        gen_store_bytes = n_px * (16 + 4 + 16 + 16 + 20)                    # primary, info, origin, dir, query
-        gen_bytes = n_fetch * 1.0 + gen_store_bytes
-        traffic = {}
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf) and (W, H, args.volume, world) == (1920, 1080, 256, 1):
-            with open(tf) as f:
-                traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
-        # VALU issue utilisation of k_gen_rays from the committed SQ counter pass (profiles/r01_pmc_sq_counters.txt): busy
-        # quad-cycles x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the bound that actually limits the integrator
-        valu_busy = None
-        sq = os.path.join(ROOT, "profiles", "r01_pmc_sq_counters.txt")
-        if os.path.exists(sq) and (W, H, args.volume, world) == (1920, 1080, 256, 1):
-            vals, on = {}, False
-            for line in open(sq):
-                if not line.startswith(" "):
-                    on = line.startswith("k_gen_rays")
-                elif on and len(line.split()) == 2:
-                    vals[line.split()[0]] = float(line.split()[1])
-            if "SQ_ACTIVE_INST_VALU" in vals and vals.get("GRBM_GUI_ACTIVE"):
-                valu_busy = vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        # algorithmic bytes of the integrator, SURVEY.md 8(d): n_fetch x 1 B (counted on the device for the same seeds) + 16 B
+        # framebuffer write + 32 B NRC query I/O per pixel.  What the kernel stores today on top of that (primary colour, info,
+        # vertex images for the train rays) is reported separately and is not credited.
+        gen_bytes = n_fetch * 1.0 + n_px * (16.0 + 32.0)
+        gen_store_bytes = n_px * (16 + 4 + 20) + ren.VertexImageBytes()
+        # `traffic`: HBM-side bytes per launch from the rocprofv3 PMC passes of the SAME command, committed under profiles/
+        # (FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 corrections of MI355X_MICROARCH.md) -- a constant read from that
+        # file, not measured in this run; quoted only when this run is the profiled workload, and labelled with its source.
+        traffic, traffic_source = {}, None
+        for tf in ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"):
+            if os.path.exists(os.path.join(ROOT, tf)) and (W, H, args.volume, world, args.config) == (1920, 1080, 256, 1, "c2"):
+                with open(os.path.join(ROOT, tf)) as f:
+                    traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
+                traffic_source = tf + " (committed rocprofv3 --pmc passes of this command; not measured in this run)"
+                break
         dominant_is_gen = gen_ms >= mlp_ms
-        roof_mlp = dict(bound="mfma", kernel="k_infer (fused encode + 6x64 MLP)", achieved=mlp_tflops, peak=MFMA_F16_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=traffic.get("k_infer"),
+        mlp_kernel = "k_infer (fused encode + 6x64 MLP)" if north_star else "k_encode + k_infer_gen<%d> (%dx%d MLP)" % (args.nn_width, args.nn_depth, args.nn_width)
+        roof_mlp = dict(bound="mfma", kernel=mlp_kernel, achieved=mlp_tflops, peak=MFMA_F16_PEAK_TFLOPS, flop_per_sample=flop,
+                        unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=traffic.get("k_infer"), traffic_source=traffic_source,
                         algorithmic_bytes=MLP_BYTES_PER_SAMPLE * n_inf, ms_per_launch=mlp_ms, samples_per_launch=n_inf,
                         data="uniform random queries",
                         on_frame_queries=dict(ms_per_launch=mlp_ms_frame,
-                                              achieved=MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms_frame * 1e-3) / 1e12,
-                                              frac=MLP_FLOP_PER_SAMPLE * n_inf / (mlp_ms_frame * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS))
+                                              achieved=flop * n_inf / (mlp_ms_frame * 1e-3) / 1e12,
+                                              frac=flop * n_inf / (mlp_ms_frame * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS))
         roof_gen = dict(bound="hbm", kernel="k_gen_rays (delta/ratio tracking path integrator; ALU/latency-bound, quoted against HBM)",
                         achieved=gen_bytes / (gen_ms * 1e-3) / 1e9 if gen_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(gen_bytes / (gen_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0,
-                        traffic=traffic.get("k_gen_rays"), algorithmic_bytes=gen_bytes,
-                        ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px, valu_issue_busy_pmc=valu_busy)
+                        traffic=traffic.get("k_gen_rays"), traffic_source=traffic_source, algorithmic_bytes=gen_bytes,
+                        bytes_per_pixel="fetches x 1 B + 16 B framebuffer + 32 B query I/O (SURVEY 8d)", stored_bytes=gen_store_bytes,
+                        ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px, fetches_executed_per_pixel=n_fetch_executed / n_px)
+        model = "NRC %dx%d %s+%s" % (args.nn_depth, args.nn_width, {0: "HashGrid(16x2,2^19)", 1: "Identity", 2: "TriangleWave(12)", 3: "Frequency(12)"}[args.pos_id],
+                                     {0: "OneBlob(4)", 1: "Identity", 2: "TriangleWave(4)"}[args.dir_id])
+        volume = "%d^3 seeded %s" % (args.volume, "smoke plume" if args.smoke_volume else "fBm cloud")
+        train_rays = 1 << log2_train
+        if args.config == "c4":
+            workload = ("configs[3]: ONE %dx%d frame sharded into %d interleaved column tiles (%d columns on rank 0), %s, %d spp/step, %s, HDR sky "
+                        "env map, scene preset 4, train=%d (global batch 16384 rays = %d per rank + 1 Adam step per sub-frame)"
+                        % (gw, gh, world, local_w, volume, spp, model, args.train, train_rays))
+        else:
+            workload = ("%s: %dx%d per GPU (global %dx%d, interleaved column tiles), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
+                        "train=%d (%d train rays + 1 Adam step per sub-frame)"
+                        % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", W, H, gw, gh, volume, spp, model, args.train, train_rays))
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "ms_per_frame": ms_per_step / spp, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_frame": ms_per_step / spp, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f16 (fp16 MFMA operands, fp32 accumulate; fp32 integrator)", "data": "synthetic",
-            "config": {"workload": "configs[1]+[2]: %dx%d per GPU (global %dx%d, interleaved column tiles), %d^3 seeded fBm cloud, "
-                                   "%d spp/step, NRC 6x64 Frequency(12)+OneBlob(4), HDR sky env map, scene preset 4, "
-                                   "train=%d (16384 train rays + 1 Adam step per sub-frame)" % (W, H, gw, gh, args.volume, spp, args.train),
+            "config": {"workload": workload, "preset": args.config,
                        "width": W, "height": H, "spp": spp, "volume": args.volume, "train": args.train,
-                       "parallelism": "pixel-column tiles x%d%s" % (world, " + RCCL grad all-reduce" if world > 1 and args.train else "")},
+                       "parallelism": "pixel-column tiles x%d%s" % (world, " + RCCL grad all-reduce" if use_dist and args.train else "")},
+            "exchange": exchange,
             "stage_ms": {k: stats[k] for k in ("gen_rays", "prep_train", "train", "infer", "render", "total")},
             "loss": loss,
             "roofline": roof_gen if dominant_is_gen else roof_mlp,
@@ -259,8 +320,13 @@ def main():
             "roofline_integrator": roof_gen,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # cpu_baseline runs the reference's ground-truth algorithm (mc/render.comp, PATH_LENGTH 32: the reference has no CPU
+        # renderer); `value` is the NRC path (2 vertices + cache query).  gpu_mc_baseline is the same algorithm as the CPU
+        # baseline on the GPU -- the like-for-like ratio is gpu_mc_vs_cpu, gpu_vs_cpu compares the two different estimators.
         out["cpu_baseline"] = cpu_baseline(scene, W, H)
+        out["gpu_mc_baseline"] = gpu_mc_baseline(api, sc, scene, W, H)
         out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        out["gpu_mc_vs_cpu"] = out["gpu_mc_baseline"]["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
     ren.Destroy()

@@ -223,9 +223,20 @@ int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frame
 int nrc_renderer_destroy(nrc_renderer_t* r);
 /* intermediate device buffers of the most recent frame, after synchronising all of the renderer's streams (tests /
  * multi-GPU; the sets rotate, so ask again after every Render): 0 primary colour+throughput [h][w][4], 1 primary info [h][w],
- * 2 nrc ray origin [h][w][4], 3 nrc ray dir [h][w][4], 4 infer input [w*h][5], 5 infer output [w*h][3],
+ * 2 nrc ray origin [h][w][4], 3 nrc ray dir [h][w][4] (train-grid pixels only unless set_full_vertex_images), 4 infer input [w*h][5], 5 infer output [w*h][3],
  * 6 train input [T][5], 7 train target [T][3], 8 train ring {head, tail, RayInfo[ring]} */
 void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes);
+/* Empty-space early-out (on by default): camera rays that provably cannot come within a voxel of non-empty density skip their
+ * delta-tracking walk -- the walk could only reject every tentative collision, leave the volume unscattered and produce env(rd),
+ * and the RNG state behind it is never read, so the frame is bit-identical with and without (tests compare both against the
+ * oracle, which always walks).  The 8x8-pixel tile mask behind it is rebuilt on the render stream whenever the camera changes.
+ * on = 0 traces every ray (what count_fetches needs to report the ALGORITHM's look-ups rather than the executed ones). */
+int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on);
+/* The NRC vertex images (buffers 2 and 3: nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) are read back only at the pixels of
+ * the train grid (prep_train_rays.comp:113-118), so by default gen_rays stores them only there; on != 0 makes it store every
+ * pixel that entered the volume, as the reference's images hold (tests, debugging).  vertex_image_bytes: what one frame stores. */
+int nrc_renderer_set_full_vertex_images(nrc_renderer_t* r, int on);
+size_t nrc_renderer_vertex_image_bytes(nrc_renderer_t* r);
 /* density look-ups executed by gen_rays (measurement: algorithmic bytes of the integrator).
  * Returns the count accumulated so far in *out (may be NULL), then enables/disables + zeroes the device counter. */
 int nrc_renderer_count_fetches(nrc_renderer_t* r, int enable, unsigned long long* out);
@@ -243,6 +254,7 @@ int nrc_mc_renderer_create(uint32_t width, uint32_t height, uint32_t path_length
 int nrc_mc_renderer_render(nrc_mc_renderer_t* r);
 int nrc_mc_renderer_set_camera(nrc_mc_renderer_t* r, const nrc_camera* camera);
 int nrc_mc_renderer_set_blend(nrc_mc_renderer_t* r, int blend);
+int nrc_mc_renderer_set_empty_skip(nrc_mc_renderer_t* r, int on);   /* see nrc_renderer_set_empty_skip */
 int nrc_mc_renderer_is_blending(nrc_mc_renderer_t* r);          /* include/engine/graphics/renderer/McHpmRenderer.hpp */
 int nrc_mc_renderer_set_scene_params(nrc_mc_renderer_t* r, const nrc_scene* scene);   /* see nrc_renderer_set_scene_params */
 int nrc_mc_renderer_set_frame_random(nrc_mc_renderer_t* r, const float random4[4]);

@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "nrc_last_error", "nrc_version", "nrc_config_default",
     "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
     "nrc_cache_get_loss_blocking", "nrc_cache_comm_info", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
+    "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -110,6 +111,8 @@ def load_library():
     L.nrc_renderer_framebuffer_on.restype = C.c_void_p
     L.nrc_renderer_buffer.restype = C.c_void_p
     L.nrc_renderer_frame_time_ms.restype = C.c_float
+    L.nrc_renderer_vertex_image_bytes.restype = C.c_size_t
+    L.nrc_renderer_vertex_image_bytes.argtypes = [C.c_void_p]
     L.nrc_mc_renderer_framebuffer.restype = C.c_void_p
     L.nrc_mc_renderer_frame_time_ms.restype = C.c_float
     for name in ("nrc_cache_get_loss", "nrc_cache_get_loss_blocking", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
@@ -459,6 +462,17 @@ class NrcHpmRenderer:
     def IsBlending(self):
         return bool(self.L.nrc_renderer_is_blending(self.h))
 
+    def SetEmptySkip(self, on=True):
+        """exact empty-space early-out of camera rays (default on); off = every ray is traced"""
+        _check(self.L.nrc_renderer_set_empty_skip(self.h, C.c_int(int(on))))
+
+    def SetFullVertexImages(self, on=True):
+        """store nrcRayOrigin / nrcRayDir for every pixel (the reference's images) instead of the train grid's pixels only"""
+        _check(self.L.nrc_renderer_set_full_vertex_images(self.h, C.c_int(int(on))))
+
+    def VertexImageBytes(self):
+        return int(self.L.nrc_renderer_vertex_image_bytes(self.h))
+
     def Buffer(self, name):
         import torch
         nbytes = C.c_size_t(0)
@@ -520,6 +534,9 @@ class McHpmRenderer:
 
     def IsBlending(self):
         return bool(self.L.nrc_mc_renderer_is_blending(self.h))
+
+    def SetEmptySkip(self, on=True):
+        _check(self.L.nrc_mc_renderer_set_empty_skip(self.h, C.c_int(int(on))))
 
     def SetSceneParams(self, scene):
         sc_ = make_c_scene(scene.scene if hasattr(scene, "scene") else scene)

@@ -293,6 +293,52 @@ struct SceneDev {
     DevScene d{};
     void* d_density = nullptr;
     void* d_env = nullptr;
+    void* d_boxes = nullptr;      // occupancy boxes for the empty-space tile mask (launch_tile_mask)
+    uint32_t n_boxes = 0;
+
+    // Occupancy of the volume in cells of 8^3 voxels: a cell counts as occupied when a non-zero voxel lies in it or within one
+    // voxel of it (the margin that makes the tile mask conservative against every rounding in the ray / sample arithmetic: a
+    // sample position is computed to ~1e-5 of a voxel).  Runs of occupied cells along x become world-space boxes.
+    void build_occupancy(const nrc_scene& s)
+    {
+        const uint32_t nx = s.nx, ny = s.ny, nz = s.nz;
+        const uint32_t gx = (nx + 7) / 8, gy = (ny + 7) / 8, gz = (nz + 7) / 8;
+        std::vector<uint8_t> occ((size_t)gx * gy * gz, 0);
+        for (uint32_t z = 0; z < nz; z++)
+            for (uint32_t y = 0; y < ny; y++) {
+                const uint8_t* row = s.density + ((size_t)z * ny + y) * nx;
+                const uint32_t cz0 = (z ? z - 1 : 0) >> 3, cz1 = std::min(z + 1, nz - 1) >> 3;
+                const uint32_t cy0 = (y ? y - 1 : 0) >> 3, cy1 = std::min(y + 1, ny - 1) >> 3;
+                for (uint32_t x = 0; x < nx; x++) {
+                    if (row[x] == 0) continue;
+                    const uint32_t cx0 = (x ? x - 1 : 0) >> 3, cx1 = std::min(x + 1, nx - 1) >> 3;
+                    for (uint32_t cz = cz0; cz <= cz1; cz++)
+                        for (uint32_t cy = cy0; cy <= cy1; cy++)
+                            for (uint32_t cx = cx0; cx <= cx1; cx++) occ[((size_t)cz * gy + cy) * gx + cx] = 1;
+                }
+            }
+        std::vector<float> boxes;
+        const double vs[3] = {(double)d.size[0] / nx, (double)d.size[1] / ny, (double)d.size[2] / nz};
+        auto world = [&](int axis, uint32_t voxel) { return (float)(-0.5 * (double)d.size[axis] + vs[axis] * (double)voxel); };
+        for (uint32_t cz = 0; cz < gz; cz++)
+            for (uint32_t cy = 0; cy < gy; cy++) {
+                const uint8_t* row = &occ[((size_t)cz * gy + cy) * gx];
+                for (uint32_t cx = 0; cx < gx;) {
+                    if (!row[cx]) { cx++; continue; }
+                    uint32_t e = cx;
+                    while (e + 1 < gx && row[e + 1]) e++;
+                    const float lo[3] = {world(0, 8 * cx), world(1, 8 * cy), world(2, 8 * cz)};
+                    const float hi[3] = {world(0, std::min(8 * (e + 1), nx)), world(1, std::min(8 * (cy + 1), ny)), world(2, std::min(8 * (cz + 1), nz))};
+                    boxes.insert(boxes.end(), {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]});
+                    cx = e + 1;
+                }
+            }
+        n_boxes = (uint32_t)(boxes.size() / 6);
+        if (n_boxes) {
+            NRC_HIP(hipMalloc(&d_boxes, boxes.size() * 4));
+            NRC_HIP(hipMemcpy(d_boxes, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
 
     void upload(const nrc_scene& s)
     {
@@ -322,6 +368,7 @@ struct SceneDev {
         // length(2 * skySize) with the math spec's dot product (a chain of single-rounding FMAs, nrc_math.h) -- what the oracle and
         // the device code compute; a plain (x*x + y*y) + z*z can differ in the last bit and with it every exit point
         d.len2size = sqrtf(fmaf(tz, tz, fmaf(ty, ty, tx * tx)));
+        build_occupancy(s);
         set_params(s);
         d.env = nullptr; d.env_w = d.env_h = 0;
         if (s.env && s.env_w && s.env_h) {
@@ -352,6 +399,7 @@ struct SceneDev {
     {
         if (d_density) (void)hipFree(d_density);
         if (d_env) (void)hipFree(d_env);
+        if (d_boxes) (void)hipFree(d_boxes);
     }
 };
 
@@ -361,6 +409,46 @@ static DevCamera to_dev(const nrc_camera& c)
     std::memcpy(d.m, c.inv_proj_view, sizeof(d.m));
     std::memcpy(d.pos, c.pos, sizeof(d.pos));
     return d;
+}
+
+// The empty-space tile mask projects occupancy boxes with the forward transform of the camera whose inverse the caller hands over.
+// Returns false when the pair (invProjView, pos) is not a perspective camera looking from `pos` (then rays do not consist of the
+// points that project onto their pixel and the mask is not used).
+static bool forward_transform(const nrc_camera& c, DevProjView* out)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; r++)
+        for (int k = 0; k < 4; k++) {
+            a[r][k] = (double)c.inv_proj_view[4 * k + r];      // column-major
+            a[r][4 + k] = r == k ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; col++) {                          // Gauss-Jordan with partial pivoting
+        int piv = col;
+        for (int r = col + 1; r < 4; r++)
+            if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (!(std::fabs(a[piv][col]) > 1e-300)) return false;
+        for (int k = 0; k < 8; k++) std::swap(a[col][k], a[piv][k]);
+        const double inv = 1.0 / a[col][col];
+        for (int k = 0; k < 8; k++) a[col][k] *= inv;
+        for (int r = 0; r < 4; r++) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            for (int k = 0; k < 8; k++) a[r][k] -= f * a[col][k];
+        }
+    }
+    double m[16];
+    for (int r = 0; r < 4; r++)
+        for (int k = 0; k < 4; k++) m[4 * k + r] = a[r][4 + k];
+    // the eye of a perspective transform maps to clip (0, 0, z, 0)
+    double e[4];
+    for (int r = 0; r < 4; r++) e[r] = m[r] * c.pos[0] + m[4 + r] * c.pos[1] + m[8 + r] * c.pos[2] + m[12 + r];
+    const double scale = std::fabs(e[2]) + 1e-30;
+    if (!(std::fabs(e[0]) <= 1e-4 * scale && std::fabs(e[1]) <= 1e-4 * scale && std::fabs(e[3]) <= 1e-4 * scale)) return false;
+    for (int k = 0; k < 16; k++) {
+        if (!std::isfinite(m[k])) return false;
+        out->m[k] = (float)m[k];
+    }
+    return true;
 }
 
 static DevFrame make_frame(uint32_t w, uint32_t h, const nrc_tile* tile)
@@ -448,6 +536,9 @@ public:
         alloc(&d_ring_, 8 + ring_entries_ * 24);
         alloc(&d_scratch_, (2 * T + 4) * 4);
         alloc(&d_fetch_, 8);
+        alloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4);
+        nrc_cam_ = cam;
+        empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
         // train-ray generation + backward overlap inference + compositing on a second stream (NRC_SINGLE_STREAM=1 disables)
         // HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4): a same-priority second stream
         // can land on the queue of the first one (observed under torch.distributed, where RCCL owns several streams) and then
@@ -516,6 +607,7 @@ public:
         // events: 0 frame start, 1 gen_rays done, 2 train rays done (D), 3 inference done, 4 composite done, 5 training done (B)
         hipStream_t A = stream_, B = stream_b_ ? stream_b_ : stream_, Cs = stream_c_ ? stream_c_ : stream_;
         hipStream_t D = stream_d_ ? stream_d_ : B;
+        update_tile_mask(A);
         const int pp = (int)(frame_index_ & 1u);                  // train-ray set, training / inference events
         const int gp = (int)(frame_index_ % (uint64_t)kGenSets);  // gen_rays output set
         d_primary_ = d_primary2_[gp]; d_info_ = d_info2_[gp]; d_origin_ = d_origin2_[gp]; d_dir_ = d_dir2_[gp];
@@ -528,7 +620,7 @@ public:
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
-                        count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, A);
+                        count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, tg_, full_vertex_images_, A);
         NRC_HIP(hipEventRecord(ev_[1], A));
         if (D != A) NRC_HIP(hipStreamWaitEvent(D, ev_[1], 0));
         if (Cs != A) NRC_HIP(hipStreamWaitEvent(Cs, ev_[1], 0));
@@ -575,10 +667,30 @@ public:
         if (stream_d_) NRC_HIP(hipStreamSynchronize(stream_d_));
     }
 
+    // (re)builds the empty-space tile mask for the current camera on stream A, in front of the next gen_rays (stream order)
+    void update_tile_mask(hipStream_t A)
+    {
+        if (!mask_dirty_) return;
+        mask_dirty_ = false;
+        DevProjView pv;
+        frame_.tile_mask = nullptr;
+        if (!empty_skip_ || !forward_transform(nrc_cam_, &pv)) return;
+        launch_tile_mask((const float*)scene_.d_boxes, scene_.n_boxes, pv, frame_, (uint32_t*)d_tile_mask_, A);
+        frame_.tile_mask = (const uint32_t*)d_tile_mask_;
+    }
+    void set_empty_skip(bool on)
+    {
+        sync();       // a frame in flight may be reading the mask
+        empty_skip_ = on;
+        mask_dirty_ = true;
+    }
+
     void set_camera(const nrc_camera& c)       // SetCamera, :561-604: reset blending, clear the accumulation images
     {
         sync();
         cam_ = to_dev(c);
+        nrc_cam_ = c;
+        mask_dirty_ = true;
         blend_index_ = 1;
         const size_t px = (size_t)w_ * h_;
         NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
@@ -701,6 +813,9 @@ public:
         consumer_pending_ = true;
     }
     bool is_blending() const { return blend_; }
+    void set_full_vertex_images(bool on) { full_vertex_images_ = on; }
+    // bytes of NRC vertex data (origin + direction) gen_rays stores per frame
+    size_t vertex_image_bytes() const { return (full_vertex_images_ ? (size_t)w_ * h_ : (size_t)tg_.tw * tg_.th) * 32; }
     const float* framebuffer_unordered() const { return (const float*)d_out_; }
     const TrainGrid& train_grid() const { return tg_; }
     hipStream_t stream() const { return stream_; }
@@ -766,6 +881,10 @@ private:
     bool dense_infer_ = false;
     hipEvent_t ev_consumer_ = nullptr;
     bool consumer_pending_ = false;
+    bool full_vertex_images_ = false;
+    void* d_tile_mask_ = nullptr;
+    nrc_camera nrc_cam_{};
+    bool mask_dirty_ = true, empty_skip_ = true;
 };
 
 // ---------------------------------------------------------------------------------------------------- McRenderer
@@ -782,17 +901,31 @@ public:
         NRC_HIP(hipMalloc(&d_out_, px * 16)); NRC_HIP(hipMemset(d_out_, 0, px * 16));
         NRC_HIP(hipMalloc(&d_info_, px * 4)); NRC_HIP(hipMemset(d_info_, 0, px * 4));
         NRC_HIP(hipMalloc(&d_fetch_, 8)); NRC_HIP(hipMemset(d_fetch_, 0, 8));
+        NRC_HIP(hipMalloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4));
         NRC_HIP(hipEventCreate(&ev_[0])); NRC_HIP(hipEventCreate(&ev_[1]));
+        nrc_cam_ = cam;
+        empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
     }
     ~McRenderer()
     {
         if (d_out_) (void)hipFree(d_out_);
         if (d_info_) (void)hipFree(d_info_);
         if (d_fetch_) (void)hipFree(d_fetch_);
+        if (d_tile_mask_) (void)hipFree(d_tile_mask_);
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     }
+    void set_empty_skip(bool on) { empty_skip_ = on; mask_dirty_ = true; }      // same stream: ordered behind frames in flight
     void render()        // McHpmRenderer::Render, src/McHpmRenderer.cpp:121-151
     {
+        if (mask_dirty_) {      // empty-space tile mask for the current camera (see Renderer::update_tile_mask)
+            mask_dirty_ = false;
+            DevProjView pv;
+            frame_.tile_mask = nullptr;
+            if (empty_skip_ && forward_transform(nrc_cam_, &pv)) {
+                launch_tile_mask((const float*)scene_.d_boxes, scene_.n_boxes, pv, frame_, (uint32_t*)d_tile_mask_, stream_);
+                frame_.tile_mask = (const uint32_t*)d_tile_mask_;
+            }
+        }
         const float blend_factor = 1.0f / (float)blend_index_;
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
@@ -806,6 +939,8 @@ public:
     void set_camera(const nrc_camera& c)
     {
         cam_ = to_dev(c);
+        nrc_cam_ = c;
+        mask_dirty_ = true;
         blend_index_ = 1;
         NRC_HIP(hipMemsetAsync(d_out_, 0, (size_t)w_ * h_ * 16, stream_));
     }
@@ -847,7 +982,9 @@ private:
     hipStream_t stream_;
     std::mt19937 rng_;
     SceneDev scene_;
-    void *d_out_ = nullptr, *d_info_ = nullptr, *d_fetch_ = nullptr;
+    void *d_out_ = nullptr, *d_info_ = nullptr, *d_fetch_ = nullptr, *d_tile_mask_ = nullptr;
+    nrc_camera nrc_cam_{};
+    bool mask_dirty_ = true, empty_skip_ = true;
     hipEvent_t ev_[2] = {nullptr, nullptr};
     bool timed_ = false;
     float pinned_random_[4] = {0, 0, 0, 0};
@@ -1076,6 +1213,23 @@ int nrc_renderer_release_frame(nrc_renderer_t* r, void* consumer_stream)
     NRC_REQUIRE(r);
     return guarded([&] { r->impl.release_frame((hipStream_t)consumer_stream); });
 }
+int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.set_empty_skip(on != 0); });
+}
+int nrc_mc_renderer_set_empty_skip(nrc_mc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.set_empty_skip(on != 0); });
+}
+int nrc_renderer_set_full_vertex_images(nrc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    r->impl.set_full_vertex_images(on != 0);
+    return NRC_OK;
+}
+size_t nrc_renderer_vertex_image_bytes(nrc_renderer_t* r) { return r ? r->impl.vertex_image_bytes() : 0; }
 int nrc_renderer_is_blending(nrc_renderer_t* r) { return r && r->impl.is_blending() ? 1 : 0; }
 int nrc_mc_renderer_is_blending(nrc_mc_renderer_t* r) { return r && r->impl.is_blending() ? 1 : 0; }
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path) { NRC_REQUIRE(r); NRC_REQUIRE(path); return guarded([&] { r->impl.export_exr(path); }); }

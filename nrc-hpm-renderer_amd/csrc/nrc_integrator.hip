@@ -20,6 +20,15 @@
 
 #include "nrc_math.h"
 
+// 1 (product): software-pipelined, predicated tracking loops; 0 (diagnostic A/B build): the plain two-collision loops
+#ifndef NRC_TRACK_PIPELINE
+#define NRC_TRACK_PIPELINE 1
+#endif
+// waves per SIMD the camera kernels are register-allocated for
+#ifndef NRC_CAMERA_WAVES_PER_SIMD
+#define NRC_CAMERA_WAVES_PER_SIMD 5
+#endif
+
 namespace nrc {
 namespace {
 
@@ -224,10 +233,19 @@ __device__ __forceinline__ float get_density(Ctx& c, V3 p)
     return inb ? d : 0.0f;
 }
 
-// get_density at start + dir*t1 and start + dir*t2 (second fetch masked unless `second`); returns densities
-__device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, float t2, bool second)
+// Two density look-ups, at start + dir*t1 and start + dir*t2, split into address, load and use so that the tracking loops can
+// locate the NEXT pair of collisions while the gathers of the current pair are in flight (software pipelining: the free-flight
+// chain does not depend on the fetched densities).  fetch2_addr computes both voxel indices (slots that are masked off or
+// outside the volume get offset 2^31: the raw buffer returns the sampler's black border without a memory access), fetch2_load
+// issues the two 1-byte gathers, fetch2_density turns the bytes into getDensity()'s value, volume.glsl:31-39.
+struct Addr2 {
+    uint32_t i0, i1;
+};
+struct Fetch2 {
+    uint32_t b0, b1;
+};
+__device__ __forceinline__ Addr2 fetch2_addr(const DevScene& s, V3 dir, V3 start, float t1, float t2, bool first, bool second)
 {
-    const DevScene& s = c.sc;
     const f2 t = f2{t1, t2};
     const f2 px = fma2(splat(dir.x), t, splat(start.x));
     const f2 py = fma2(splat(dir.y), t, splat(start.y));
@@ -237,15 +255,22 @@ __device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, f
     const f2 w = fma2(pz, splat(s.inv_size[2]), splat(0.5f));
     const f2 fx = u * splat(s.fnx), fy = v * splat(s.fny), fz = w * splat(s.fnz);
     // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
-    const bool in0 = max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u;
+    const bool in0 = (max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u) & first;
     const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
-    uint32_t idx0 = mad24(mad24((uint32_t)fz.x, s.ny, (uint32_t)fy.x), s.nx, (uint32_t)fx.x);
-    uint32_t idx1 = mad24(mad24((uint32_t)fz.y, s.ny, (uint32_t)fy.y), s.nx, (uint32_t)fx.y);
-    idx0 = in0 ? idx0 : 0x80000000u;
-    idx1 = in1 ? idx1 : 0x80000000u;
-    const uint8_t b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx0, 0, 0);
-    const uint8_t b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx1, 0, 0);
-    return splat(s.density_factor) * (f2{(float)b0, (float)b1} * splat(1.0f / 255.0f));
+    const uint32_t idx0 = mad24(mad24((uint32_t)fz.x, s.ny, (uint32_t)fy.x), s.nx, (uint32_t)fx.x);
+    const uint32_t idx1 = mad24(mad24((uint32_t)fz.y, s.ny, (uint32_t)fy.y), s.nx, (uint32_t)fx.y);
+    return Addr2{in0 ? idx0 : 0x80000000u, in1 ? idx1 : 0x80000000u};
+}
+__device__ __forceinline__ Fetch2 fetch2_load(Ctx& c, const Addr2& a)
+{
+    Fetch2 f;
+    f.b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)a.i0, 0, 0);
+    f.b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)a.i1, 0, 0);
+    return f;
+}
+__device__ __forceinline__ f2 fetch2_density(const DevScene& s, const Fetch2& f)
+{
+    return splat(s.density_factor) * (f2{(float)f.b0, (float)f.b1} * splat(1.0f / 255.0f));
 }
 
 // ---- include/dir_gen.glsl
@@ -300,9 +325,92 @@ __device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_samplin
 }
 
 // ---- include/path_trace.glsl
-// RatioTrack, path_trace.glsl:24-43, two collisions per trip: nothing in a step depends on the previous fetch, so both
-// free-flight logs share packed math and both fetches are in flight together; a lane that ends on the first collision
-// keeps the RNG state of that draw, exactly as the one-step loop would
+// RatioTrack, path_trace.glsl:24-43.  Two collisions per trip: nothing in a step depends on the previous fetch, so both free-
+// flight logs share packed math.  The loop is software-pipelined: a trip's two gathers are issued at the top of the loop body,
+// the NEXT trip is located (hash chain, logs, positions, voxel indices -- about 80 instructions that do not depend on any
+// density) while they are in flight, and only then are the densities used.  A lane that ends on a collision keeps the RNG state
+// of that draw, exactly as the one-step loop would; the trip located ahead of it is dropped.
+struct RatioTrip {
+    float s1, s2, t1, t2;
+    bool live1, second;       // collision 1 / collision 2 lie inside the segment
+};
+__device__ __forceinline__ RatioTrip ratio_trip(float rng, float t, float t_max, float inv)
+{
+    RatioTrip r;
+    r.s1 = random1(rng);
+    r.s2 = random1(r.s1);
+    const f2 l = logf2(f2{1.0f - r.s1, 1.0f - r.s2});
+    r.t1 = nrc_fmaf_(-l.x, inv, t);
+    r.t2 = nrc_fmaf_(-l.y, inv, r.t1);
+    r.live1 = !(r.t1 >= t_max);
+    r.second = !(r.t2 >= t_max);
+    return r;
+}
+#if NRC_TRACK_PIPELINE
+// The loop is wave-uniform (it runs while any lane still walks) and its body is predicated with selects instead of per-lane
+// branches: with `break`s the compiler sinks the look-ahead into the continue path, i.e. behind the wait for the gathers, and
+// the overlap is gone.  Lanes that have finished keep their results and issue no gathers (offset 2^31).
+__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
+{
+    V3 d = sub(end, start);
+    const V3 dir = normalize(d);
+    const float t_max = length(d);
+    const float inv = c.sc.inv_max_density;
+    float tr = 1.0f;
+    float rng = c.rng;
+    bool alive = true;
+    RatioTrip a = ratio_trip(rng, 0.0f, t_max, inv);
+    Addr2 ia = fetch2_addr(c.sc, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
+    for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
+        rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
+        alive &= a.live1;
+        if (__ballot(alive) == 0ull) break;
+        if (alive) NRC_PROF(c, 3);
+        const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
+        __builtin_amdgcn_sched_barrier(0);
+        const bool last = i + 2 >= 128;
+        const bool more = alive & a.second & !last;
+        const RatioTrip b = ratio_trip(a.s2, a.t2, t_max, inv);      // ... fly while the next trip is located
+        const Addr2 ib = fetch2_addr(c.sc, dir, start, b.t1, b.t2, more & b.live1, more & b.live1 & b.second);
+        __builtin_amdgcn_sched_barrier(0);
+        const f2 dens = fetch2_density(c.sc, fa);
+        const bool two = alive & a.second;
+        c.fetches += alive ? (a.second ? 2u : 1u) : 0u;
+        tr = alive ? tr * nrc_fmaf_(-dens.x, inv, 1.0f) : tr;
+        tr = two ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
+        rng = (alive & (!a.second | last)) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
+        alive = more;
+        a = b;
+        ia = ib;
+    }
+    c.rng = rng;
+    return tr;
+}
+#else
+// reference form of the loop (diagnostic build -DNRC_TRACK_PIPELINE=0): two collisions per trip, gathers awaited in the trip
+// get_density at start + dir*t1 and start + dir*t2 (second fetch masked unless `second`); returns densities
+__device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, float t2, bool second)
+{
+    const DevScene& s = c.sc;
+    const f2 t = f2{t1, t2};
+    const f2 px = fma2(splat(dir.x), t, splat(start.x));
+    const f2 py = fma2(splat(dir.y), t, splat(start.y));
+    const f2 pz = fma2(splat(dir.z), t, splat(start.z));
+    const f2 u = fma2(px, splat(s.inv_size[0]), splat(0.5f));
+    const f2 v = fma2(py, splat(s.inv_size[1]), splat(0.5f));
+    const f2 w = fma2(pz, splat(s.inv_size[2]), splat(0.5f));
+    const f2 fx = u * splat(s.fnx), fy = v * splat(s.fny), fz = w * splat(s.fnz);
+    // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
+    const bool in0 = max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u;
+    const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
+    uint32_t idx0 = mad24(mad24((uint32_t)fz.x, s.ny, (uint32_t)fy.x), s.nx, (uint32_t)fx.x);
+    uint32_t idx1 = mad24(mad24((uint32_t)fz.y, s.ny, (uint32_t)fy.y), s.nx, (uint32_t)fx.y);
+    idx0 = in0 ? idx0 : 0x80000000u;
+    idx1 = in1 ? idx1 : 0x80000000u;
+    const uint8_t b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx0, 0, 0);
+    const uint8_t b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx1, 0, 0);
+    return splat(s.density_factor) * (f2{(float)b0, (float)b1} * splat(1.0f / 255.0f));
+}
 __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
 {
     V3 d = sub(end, start);
@@ -331,6 +439,7 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
     c.rng = rng;
     return tr;
 }
+#endif
 
 __device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir)
 {
@@ -411,9 +520,80 @@ __device__ __forceinline__ V3 trace_scene(Ctx& c, V3 pos, V3 dir)
     return add(add(a, b), e);
 }
 
-// DeltaTrack, path_trace.glsl:150-174, two collisions per trip: the second collision's free flight and fetch are issued
-// speculatively beside the first's (the RNG chain does not depend on the density); whichever event comes first in
-// sequence order -- exit, accept 1, exit, accept 2 -- ends the walk with the RNG state the one-step loop would have
+// DeltaTrack, path_trace.glsl:150-174, two collisions per trip, software-pipelined like ratio_track: the second collision's free
+// flight and fetch are issued beside the first's and the NEXT trip's two collisions are located while the gathers are in flight
+// (the RNG chain does not depend on the density); whichever event comes first in sequence order -- exit, accept 1, exit,
+// accept 2 -- ends the walk with the RNG state the one-step loop would have, and the trip located ahead is dropped
+struct DeltaTrip {
+    float s1, a1, s2, a2, t1, t2;
+    bool live1, second;
+};
+__device__ __forceinline__ DeltaTrip delta_trip(float rng, float t, float t_max, float inv)
+{
+    DeltaTrip r;
+    r.s1 = random1(rng);
+    r.a1 = random1(r.s1);
+    r.s2 = random1(r.a1);
+    r.a2 = random1(r.s2);
+    const f2 l = logf2(f2{1.0f - r.s1, 1.0f - r.s2});
+    r.t1 = nrc_fmaf_(-l.x, inv, t);
+    r.t2 = nrc_fmaf_(-l.y, inv, r.t1);
+    r.live1 = !(r.t1 >= t_max);
+    r.second = !(r.t2 >= t_max);
+    return r;
+}
+#if NRC_TRACK_PIPELINE
+__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)
+{
+    V3 en, ex;
+    find_entry_exit(c, ro, rd, &en, &ex);
+    const float t_max = length(sub(ex, ro));
+    const float inv = c.sc.inv_max_density;
+    float rng = c.rng;
+    bool alive = true, hit = false, vexit = false;
+    float t_hit = 0.0f;
+    DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
+    Addr2 ia = fetch2_addr(c.sc, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
+    for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:161); predicated like ratio_track
+        const bool out1 = alive & !a.live1;                          // collision 1 beyond the exit point
+        rng = out1 ? a.s1 : rng;
+        vexit |= out1;
+        alive &= a.live1;
+        if (__ballot(alive) == 0ull) break;
+        if (alive) NRC_PROF(c, 2);
+        const Fetch2 fa = fetch2_load(c, ia);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool last = i + 2 >= 128;
+        const DeltaTrip b = delta_trip(a.a2, a.t2, t_max, inv);      // located ahead; used only if this trip accepts nothing
+        const bool maybe = alive & a.second & !last;
+        const Addr2 ib = fetch2_addr(c.sc, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
+        __builtin_amdgcn_sched_barrier(0);
+        const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
+        c.fetches += alive ? 1u : 0u;
+        const bool acc1 = alive & (dens.x > a.a1);
+        const bool alive2 = alive & !acc1;
+        const bool out2 = alive2 & !a.second;                        // collision 2 beyond the exit point
+        const bool alive3 = alive2 & a.second;
+        c.fetches += alive3 ? 1u : 0u;
+        const bool acc2 = alive3 & (dens.y > a.a2);
+        hit |= acc1 | acc2;
+        t_hit = acc1 ? a.t1 : (acc2 ? a.t2 : t_hit);
+        vexit |= out2;
+        // RNG state of the event that ended the walk: accept 1 -> a1, exit 2 -> s2, accept 2 or the 128-collision cap -> a2
+        rng = acc1 ? a.a1 : rng;
+        rng = out2 ? a.s2 : rng;
+        rng = (alive3 & (acc2 | last)) ? a.a2 : rng;
+        alive = alive3 & !acc2 & !last;
+        a = b;
+        ia.i0 = alive ? ib.i0 : 0x80000000u;                         // a lane that has just finished fetches nothing next trip
+        ia.i1 = alive ? ib.i1 : 0x80000000u;
+    }
+    c.rng = rng;
+    *volume_exit = vexit;
+    if (hit) return madd(rd, t_hit, ro);
+    return madd(rd, c.rand(t_max), ro);
+}
+#else
 __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)
 {
     *volume_exit = false;
@@ -449,6 +629,7 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
     if (hit) return madd(rd, t_hit, ro);
     return madd(rd, c.rand(t_max), ro);
 }
+#endif
 
 // camera ray: mc/render.comp:42-60, nrc/gen_rays.comp:53-72 (no half-pixel offset, no y flip)
 __device__ __forceinline__ void camera_ray(const DevCamera& cam, float u, float v, V3* ro, V3* rd)
@@ -504,6 +685,21 @@ __device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t*
     return *lx < fr.w && *y < fr.h;
 }
 
+// Empty-space early-out, exact: the tile mask (k_tile_mask) clears the bit of an 8x8 tile only when no camera ray of the tile can
+// come within a voxel of non-empty density.  Every density such a ray's delta tracking fetches is 0, so every tentative collision
+// is rejected, the walk leaves the volume without scattering and the pixel is env(rd) with didScatter = 0 and an all-zero query
+// -- whatever the random numbers are, and the RNG state after the walk is never used.  The tile's waves skip the walk (a third
+// of the kernel's work on the bench view sits in such tiles) and write exactly what the walk would have produced.
+__device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, uint32_t y)
+{
+    if (fr.tile_mask == nullptr) return false;
+    const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
+    const uint32_t id = __builtin_amdgcn_readfirstlane((y >> 3) * tiles_x + (lx >> 3));      // wave-uniform: one tile per wave
+    const uint32_t n_words = (tiles_x * tiles_y + 31u) >> 5;
+    const uint32_t word = fr.tile_mask[id >> 5], ignore = fr.tile_mask[n_words];
+    return ignore == 0u && ((word >> (id & 31u)) & 1u) == 0u;
+}
+
 __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint32_t n)
 {
     if (counter == nullptr) return;
@@ -514,11 +710,11 @@ __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint3
 }
 
 // ------------------------------------------------------------------------------------------------ nrc/gen_rays.comp + prep_infer_rays.comp
-__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
+__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_SIMD) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
                                                  float primary_ray_prob, float4* __restrict__ primary,
                                                  float* __restrict__ info, float4* __restrict__ origin,
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
-                                                 unsigned long long* fetch_counter)
+                                                 unsigned long long* fetch_counter, TrainGrid tg, int full_vertex_images)
 {
     uint32_t lx, y;
     const bool inside = pixel_of_wave_tile(fr, &lx, &y);
@@ -540,20 +736,23 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_gen_rays(DevSce
         V3 ro, rd;
         camera_ray(cam, u, v, &ro, &rd);
         init_random(c, u, v, fr.random);
-        V3 entry, ex;
-#ifdef NRC_LOOP_PROFILE
-        c.fee_kind = 0;
-#endif
-        find_entry_exit(c, ro, rd, &entry, &ex);
-#ifdef NRC_LOOP_PROFILE
-        c.fee_kind = 1;
-#endif
         const size_t pix = (size_t)y * fr.w + lx;
         V3 col;
         float thr = 1.0f;
         bool did_scatter = false;
         float q[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if (sky_sdf(sc, entry) > 100000.0f) {
+        V3 entry = ro, ex;
+        const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform
+        if (!empty) {
+#ifdef NRC_LOOP_PROFILE
+            c.fee_kind = 0;
+#endif
+            find_entry_exit(c, ro, rd, &entry, &ex);
+#ifdef NRC_LOOP_PROFILE
+            c.fee_kind = 1;
+#endif
+        }
+        if (empty || sky_sdf(sc, entry) > 100000.0f) {
             col = sample_env_dir(sc, rd);
         } else {
             V3 light = v3(0, 0, 0);
@@ -571,8 +770,18 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_gen_rays(DevSce
                     if (c.rand(1.0f) >= primary_ray_prob || i == 128) break;
                 }
             }
-            origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
-            dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            // the NRC vertex images (nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) have one reader besides the query packing
+            // fused in here: prep_train_rays, at the pixels (tx * xDist, ty * yDist) of the train grid.  Only those are stored
+            // (32 B for 16 384 of 2 073 600 pixels instead of 66 MB per frame) unless the caller asks for the whole images.
+            bool on_grid = full_vertex_images != 0;
+            if (!on_grid) {
+                const uint32_t qx = tg.x_dist ? lx / tg.x_dist : 0u, qy = tg.y_dist ? y / tg.y_dist : 0u;
+                on_grid = (qx * tg.x_dist == lx) & (qy * tg.y_dist == y) & (qx < tg.tw) & (qy < tg.th);
+            }
+            if (on_grid) {
+                origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
+                dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            }
             col = light;
             thr = factor;
             if (!did_scatter) {
@@ -600,7 +809,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_gen_rays(DevSce
 }
 
 // ------------------------------------------------------------------------------------------------ mc/render.comp
-__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_mc_render(DevScene sc, DevCamera cam, DevFrame fr, uint32_t path_length,
+__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_SIMD) void k_mc_render(DevScene sc, DevCamera cam, DevFrame fr, uint32_t path_length,
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
 {
@@ -613,11 +822,12 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_mc_render(DevSc
         V3 ro, rd;
         camera_ray(cam, u, v, &ro, &rd);
         init_random(c, u, v, fr.random);
-        V3 entry, ex;
-        find_entry_exit(c, ro, rd, &entry, &ex);
+        V3 entry = ro, ex;
+        const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform, see tile_is_empty
+        if (!empty) find_entry_exit(c, ro, rd, &entry, &ex);
         V3 col;
         bool did_scatter = false;
-        if (sky_sdf(sc, entry) > 100000.0f) {
+        if (empty || sky_sdf(sc, entry) > 100000.0f) {
             col = sample_env_dir(sc, rd);
         } else {
             V3 light = v3(0, 0, 0);
@@ -644,6 +854,54 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK) void k_mc_render(DevSc
         if (info) info[pix] = a;
     }
     count_fetches(fetch_counter, c.fetches);
+}
+
+// ------------------------------------------------------------------------------------------------ empty-space tile mask
+// One thread per occupancy box (world-space AABB around a run of non-empty 8^3-voxel cells, grown by one voxel): its eight
+// corners are projected with the camera's forward transform; the screen rectangle around them, grown by a pixel, covers every
+// pixel whose camera ray can pass through the box (a pixel's ray consists of the points that project onto the pixel).  The 8x8
+// tiles the rectangle touches are marked.  A box with a corner at or behind the eye plane switches the mask off for this camera.
+__global__ __launch_bounds__(256) void k_tile_mask(const float* __restrict__ boxes, uint32_t n_boxes, DevProjView pv, DevFrame fr,
+                                                  uint32_t* __restrict__ mask)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_boxes) return;
+    const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
+    const uint32_t n_words = (tiles_x * tiles_y + 31u) >> 5;
+    const float* b = boxes + 6u * (size_t)i;
+    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+    bool behind = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x = b[(k & 1) ? 3 : 0], y = b[(k & 2) ? 4 : 1], z = b[(k & 4) ? 5 : 2];
+        const float cx = pv.m[0] * x + pv.m[4] * y + pv.m[8] * z + pv.m[12];
+        const float cy = pv.m[1] * x + pv.m[5] * y + pv.m[9] * z + pv.m[13];
+        const float cw = pv.m[3] * x + pv.m[7] * y + pv.m[11] * z + pv.m[15];
+        if (!(cw > 1.0e-3f)) { behind = true; continue; }
+        const float nx = cx / cw, ny = cy / cw;
+        xmin = fminf(xmin, nx); xmax = fmaxf(xmax, nx);
+        ymin = fminf(ymin, ny); ymax = fmaxf(ymax, ny);
+    }
+    if (behind || !(xmin <= xmax) || !(ymin <= ymax)) {      // NaN-safe
+        atomicOr(&mask[n_words], 1u);
+        return;
+    }
+    // pixel (gx, y) looks along ndc = (2 gx / gw - 1, 2 y / gh - 1): gx = (ndc.x + 1) / 2 * gw
+    const float gw = 1.0f / fr.inv_gw, gh = 1.0f / fr.inv_gh;
+    float gx0 = floorf((xmin + 1.0f) * 0.5f * gw) - 1.0f, gx1 = ceilf((xmax + 1.0f) * 0.5f * gw) + 1.0f;
+    float gy0 = floorf((ymin + 1.0f) * 0.5f * gh) - 1.0f, gy1 = ceilf((ymax + 1.0f) * 0.5f * gh) + 1.0f;
+    // local columns: gx = x_offset + lx * x_stride
+    float lx0 = floorf((gx0 - (float)fr.x_offset) / (float)fr.x_stride), lx1 = ceilf((gx1 - (float)fr.x_offset) / (float)fr.x_stride);
+    lx0 = fmaxf(lx0, 0.0f); gy0 = fmaxf(gy0, 0.0f);
+    lx1 = fminf(lx1, (float)(fr.w - 1u)); gy1 = fminf(gy1, (float)(fr.h - 1u));
+    if (!(lx0 <= lx1) || !(gy0 <= gy1)) return;             // off screen
+    const uint32_t tx0 = (uint32_t)lx0 >> 3, tx1 = (uint32_t)lx1 >> 3, ty0 = (uint32_t)gy0 >> 3, ty1 = (uint32_t)gy1 >> 3;
+    for (uint32_t ty = ty0; ty <= ty1; ty++)
+        for (uint32_t tx = tx0; tx <= tx1; tx++) {
+            const uint32_t id = ty * tiles_x + tx;
+            const uint32_t bit = 1u << (id & 31u);
+            if ((mask[id >> 5] & bit) == 0u) atomicOr(&mask[id >> 5], bit);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ nrc/clear.comp + ring ordering
@@ -941,11 +1199,21 @@ static dim3 wave_tile_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(ceil_d
 
 void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
-                     unsigned long long* fetch_counter, hipStream_t s)
+                     unsigned long long* fetch_counter, const TrainGrid& tg, bool full_vertex_images, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gen_rays, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
-                       fetch_counter);
+                       fetch_counter, tg, full_vertex_images ? 1 : 0);
+    NRC_HIP(hipGetLastError());
+}
+
+uint32_t tile_mask_words(uint32_t w, uint32_t h) { return (ceil_div(w, 8) * ceil_div(h, 8) + 31u) / 32u + 1u; }
+
+void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s)
+{
+    NRC_HIP(hipMemsetAsync(mask, 0, (size_t)tile_mask_words(fr.w, fr.h) * 4, s));
+    if (n_boxes == 0) return;
+    hipLaunchKernelGGL(k_tile_mask, dim3(ceil_div(n_boxes, 256)), dim3(256), 0, s, boxes, n_boxes, pv, fr, mask);
     NRC_HIP(hipGetLastError());
 }
 

@@ -32,15 +32,29 @@ struct DevFrame {
     uint32_t w, h;                // local image: w columns x h rows
     uint32_t x_offset, x_stride;  // global x = x_offset + lx * x_stride
     float inv_gw, inv_gh;         // 1/global width, 1/global height (ONE_OVER_RENDER_WIDTH/HEIGHT)
+    // one bit per 8x8 pixel tile (index ty * ceil(w/8) + tx), set when a camera ray of the tile can meet a non-empty voxel; the
+    // word behind the last tile word is non-zero when the mask must be ignored.  nullptr: no mask (every tile is traced).
+    const uint32_t* tile_mask;
+};
+
+// forward camera transform for the tile mask: clip = m * (x, y, z, 1), column-major like DevCamera::m
+struct DevProjView {
+    float m[16];
 };
 
 struct TrainGrid {
     uint32_t tw, th, x_dist, y_dist, spp, ray_length, ring_size;
 };
 
+// origin / dir (the NRC vertex images) are written at the train grid's pixels only unless full_vertex_images
 void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
-                     unsigned long long* fetch_counter, hipStream_t s);
+                     unsigned long long* fetch_counter, const TrainGrid& tg, bool full_vertex_images, hipStream_t s);
+
+// marks the 8x8-pixel tiles whose camera rays can meet a non-empty voxel: `boxes` = n axis-aligned world-space boxes
+// {lo.xyz, hi.xyz} that together cover every non-empty voxel with a margin of one voxel.  mask: ceil(tiles/32) + 1 words, zeroed.
+void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s);
+uint32_t tile_mask_words(uint32_t w, uint32_t h);
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);

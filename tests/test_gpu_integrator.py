@@ -140,6 +140,51 @@ def test_unusual_scenes_and_cameras_match_oracle_bitwise(api, orc, sc, cloud16, 
     nrc.Destroy()
 
 
+@pytest.mark.parametrize("view", ["default", "oblique", "inside", "tile-3-of-8"])
+def test_empty_space_early_out_is_exact(api, orc, sc, cloud16, torch_gpu, view):
+    """the tile mask that lets camera rays skip a walk through provably empty space: frames with and without it are bit-identical
+    (NRC primary pass, query buffer, MC image), the oracle -- which walks every ray -- agrees with both, and the mask really
+    removes work (fewer density look-ups executed) wherever part of the view is empty"""
+    from nrc_hpm_renderer_amd import parallel
+    W, H = 256, 144
+    cam_kw = {"default": {}, "oblique": dict(pos=(40.0, 35.0, -50.0), view_dir=(-0.6, -0.5, 0.7)),
+              "inside": dict(pos=(5.0, 2.0, -3.0), view_dir=(-0.7, 0.1, 0.7)), "tile-3-of-8": {}}[view]
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H, **cam_kw)
+    tile, lw = None, W
+    if view == "tile-3-of-8":
+        tile, lw = parallel.column_tile(3, 8, W, H), parallel.local_width(3, 8, W)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=14)
+    out = {}
+    for skip in (True, False):
+        nrc = api.NeuralRadianceCache(cfg)
+        ren = api.NrcHpmRenderer(lw, H, False, cam, cfg, scene, nrc, tile=tile)
+        ren.SetEmptySkip(skip)
+        ren.CountFetches(True)
+        ren.SetFrameRandom(FRAME_RANDOM)
+        ren.Render(None, False)
+        n_fetch = ren.CountFetches(False)
+        mc = api.McHpmRenderer(lw, H, 8, False, cam, scene, tile=tile)
+        mc.SetEmptySkip(skip)
+        mc.SetFrameRandom(FRAME_RANDOM)
+        mc.Render()
+        out[skip] = (ren.Buffer("primary").cpu().numpy().copy(), ren.Buffer("info").cpu().numpy().copy(),
+                     ren.Buffer("infer_input").cpu().numpy().copy(), mc.GetImage().cpu().numpy().copy(), n_fetch)
+        mc.Destroy()
+        ren.Destroy()
+        nrc.Destroy()
+    for k in range(4):
+        assert same_bits(out[True][k], out[False][k])
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
+    sel = slice(3, None, 8) if tile else slice(None)
+    assert same_bits(out[True][0].reshape(H, lw, 4), o["primary"][:, sel]) and same_bits(out[True][1].reshape(H, lw), o["info"][:, sel])
+    if tile is None:
+        assert out[False][4] == o["n_fetch"]                      # without the mask the device executes the algorithm's look-ups
+    assert out[True][4] <= out[False][4]
+    if view in ("default", "tile-3-of-8", "oblique"):
+        assert out[True][4] < 0.8 * out[False][4]                  # a good part of these views is empty space
+
+
 def test_renderer_argument_errors(api, sc, sphere_scene, torch_gpu):
     """Log::Error semantics at the boundary: a message starting with "SkyRenderer ERROR", no crash, nothing left half-built"""
     cam = sc.make_camera(aspect=1.0)
@@ -195,9 +240,29 @@ def test_gen_rays_and_query_packing_match_oracle(api, orc, sc, cloud16, torch_gp
     frames whose width / height are not multiples of the 8x8 wave tile (partial tiles, odd tile-row counts)"""
     scene = sc.make_scene(cloud16, scene_id=4)
     cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
+    # default: the NRC vertex images are stored at the train grid's pixels only (their one reader, prep_train_rays)
     ren.SetFrameRandom(FRAME_RANDOM)
     ren.Render(None, False)
-    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
+    tg = ren.TrainGrid()
+    assert ren.VertexImageBytes() == tg["tw"] * tg["th"] * 32
+    gy, gx = np.meshgrid(np.arange(tg["th"]) * tg["y_dist"], np.arange(tg["tw"]) * tg["x_dist"], indexing="ij")
+    ok = (gy < H) & (gx < W)
+    gy, gx = gy[ok], gx[ok]
+    on = o["info"][gy, gx] == 1
+    org_s = ren.Buffer("origin").cpu().numpy().reshape(H, W, 4)
+    dir_s = ren.Buffer("dir").cpu().numpy().reshape(H, W, 4)
+    assert same_bits(org_s[gy[on], gx[on]], o["origin"][gy[on], gx[on]]) and same_bits(dir_s[gy[on], gx[on]], o["dir"][gy[on], gx[on]])
+    off_grid = np.ones((H, W), bool)
+    off_grid[gy, gx] = False
+    assert (org_s[off_grid] == 0).all() and (dir_s[off_grid] == 0).all()      # nothing stored elsewhere (zero-initialised images)
+    ren.Destroy()
+    nrc.Destroy()
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+    ren.SetFullVertexImages(True)                   # the reference's whole images
+    assert ren.VertexImageBytes() == W * H * 32
+    ren.SetFrameRandom(FRAME_RANDOM)
+    ren.Render(None, False)
     prim = ren.Buffer("primary").cpu().numpy().reshape(H, W, 4)
     info = ren.Buffer("info").cpu().numpy().reshape(H, W)
     big = W * H >= 4096
