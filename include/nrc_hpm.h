@@ -33,13 +33,13 @@ const char* nrc_version(void);
  * en::AppConfig (include/engine/AppConfig.hpp:9-66; 17 positional CLI args src/AppConfig.cpp:154-182,
  * defaults src/main.cu:429-440).  Scene preset values (src/AppConfig.cpp:93-150) are carried explicitly. */
 typedef struct nrc_config {
-    char loss_fn[32];              /* "RelativeL2Luminance" | "L2" | "RelativeL2" */
+    char loss_fn[32];              /* "RelativeL2Luminance" | "L2" | "RelativeL2" | "L1" | "Mape" | "Smape" | "LogL1" (tiny-cuda-nn names) */
     char optimizer[32];            /* "Adam" (default) | "SGD": nested in the EMA wrapper, src/NeuralRadianceCache.cu:20-28 */
     float learning_rate;
     float ema_decay;
     uint32_t pos_id;               /* 0 HashGrid(16x2, 2^19) | 1 Identity | 2 TriangleWave-12 | 3 Frequency-12 */
     uint32_t dir_id;               /* 0 OneBlob-4 | 1 Identity | 2 TriangleWave-4 */
-    uint32_t nn_width;             /* 64 (32, 64, 128) */
+    uint32_t nn_width;             /* 64 (16, 32, 64, 128: tiny-cuda-nn's FullyFusedMLP widths) */
     uint32_t nn_depth;             /* n_hidden_layers, 6 */
     uint32_t log2_infer_batch_size;
     uint32_t log2_train_batch_size;

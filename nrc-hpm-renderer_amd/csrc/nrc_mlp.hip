@@ -387,6 +387,41 @@ __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------------ training: fwd + loss + dgrad
+// tiny-cuda-nn's element-wise losses (the reference passes the name through, src/NeuralRadianceCache.cu:17-19):
+// per element value / n_total and dL/dy * loss_scale / n_total, n_total = 3 * (global) batch.
+//   0 RelativeL2Luminance (p-t)^2 / (lum(p)^2 + .01)      1 L2 (p-t)^2             2 RelativeL2 (p-t)^2 / (p^2 + .01)
+//   3 L1 |p-t|        4 Mape |p-t| / (|t| + .01)        5 Smape |p-t| / ((|p|+|t|)/2 + .01)        6 LogL1 log(1 + |p-t|)
+// (the relative losses treat their denominator as a constant in the gradient, as tiny-cuda-nn does)
+__device__ __forceinline__ void loss_terms(uint32_t loss_id, const float (&y)[3], const float* __restrict__ t, float inv_n_total,
+                                           float& loss_v, float (&dy)[3])
+{
+    float lum2 = 0.0f;
+    if (loss_id == 0u) {
+        const float lum = (0.299f * y[0] + 0.587f * y[1]) + 0.114f * y[2];
+        lum2 = lum * lum + 0.01f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float d = y[c] - t[c];
+        float value, grad;
+        if (loss_id <= 2u) {
+            const float den = loss_id == 0u ? lum2 : (loss_id == 1u ? 1.0f : y[c] * y[c] + 0.01f);
+            value = d * d / den;
+            grad = 2.0f * d / den;
+        } else if (loss_id == 6u) {
+            const float div = fabsf(d) + 1.0f;
+            value = logf(div);
+            grad = copysignf(1.0f / div, d);
+        } else {
+            const float scale = loss_id == 3u ? 1.0f : 1.0f / ((loss_id == 4u ? fabsf(t[c]) : 0.5f * (fabsf(y[c]) + fabsf(t[c]))) + 0.01f);
+            value = fabsf(d) * scale;
+            grad = copysignf(scale, d);
+        }
+        loss_v += value * inv_n_total;
+        dy[c] = Mlp::kLossScale * (grad * inv_n_total);
+    }
+}
+
 struct TrainArgs {
     const float* in;
     const float* target;
@@ -456,23 +491,12 @@ __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const ui
         for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
         if (h == 0) {
             const float* t = a.target + (size_t)sidx * 3u;
-            float yv[3] = {y[0], y[1], y[2]};
-            float den[3];
-            if (a.loss_id == 0u) {
-                float lum = (0.299f * yv[0] + 0.587f * yv[1]) + 0.114f * yv[2];
-                den[0] = den[1] = den[2] = lum * lum + 0.01f;
-            } else if (a.loss_id == 1u) {
-                den[0] = den[1] = den[2] = 1.0f;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; c++) den[c] = yv[c] * yv[c] + 0.01f;
-            }
+            const float yv[3] = {y[0], y[1], y[2]};
+            float dy[3];
+            loss_terms(a.loss_id, yv, t, a.inv_n_total, loss_v, dy);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                float d = yv[c] - t[c];
-                loss_v += d * d / den[c] * a.inv_n_total;
-                float dy = Mlp::kLossScale * (2.0f * d / den[c] * a.inv_n_total);
-                bo[c] = (half_t)dy;
+                bo[c] = (half_t)dy[c];
                 pd[(DEPTH * WIDTH + c) * 8] = bo[c];
             }
         }
@@ -1029,23 +1053,12 @@ __global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* 
         for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
         if (h == 0) {
             const float* t = a.target + (size_t)sidx * 3u;
-            float yv[3] = {y[0], y[1], y[2]};
-            float den[3];
-            if (a.loss_id == 0u) {
-                float lum = (0.299f * yv[0] + 0.587f * yv[1]) + 0.114f * yv[2];
-                den[0] = den[1] = den[2] = lum * lum + 0.01f;
-            } else if (a.loss_id == 1u) {
-                den[0] = den[1] = den[2] = 1.0f;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; c++) den[c] = yv[c] * yv[c] + 0.01f;
-            }
+            const float yv[3] = {y[0], y[1], y[2]};
+            float dy[3];
+            loss_terms(a.loss_id, yv, t, a.inv_n_total, loss_v, dy);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                float d = yv[c] - t[c];
-                loss_v += d * d / den[c] * a.inv_n_total;
-                float dy = Mlp::kLossScale * (2.0f * d / den[c] * a.inv_n_total);
-                bo[c] = (half_t)dy;
+                bo[c] = (half_t)dy[c];
                 pd[(size_t)((uint32_t)depth * WIDTH + c) * 8] = bo[c];
             }
         }
@@ -1238,7 +1251,12 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     width_ = cfg.nn_width;
     depth_ = cfg.nn_depth;
     if (pos_enc_dims(cfg.pos_id) == 0 || dir_enc_dims(cfg.dir_id) == ~0u) fail("NNEncodingConfig posID/dirID is invalid");
-    if (width_ != 32 && width_ != 64 && width_ != 128) fail("nnWidth must be 32, 64 or 128 (got " + std::to_string(width_) + ")");
+    if (width_ != 16 && width_ != 32 && width_ != 64 && width_ != 128)
+        fail("nnWidth must be 16, 32, 64 or 128 -- tiny-cuda-nn's FullyFusedMLP widths (got " + std::to_string(width_) + ")");
+    // a 16-wide network runs on the 32-row MFMA tiles of the 32-wide kernels: neurons 16..31 of every hidden layer have all-zero
+    // fragment entries, so they stay exactly 0 through ReLU and contribute exactly 0 downstream; the parameter vector, gradients
+    // and optimizer see the true 16-wide shapes (half of the MFMA work is padding: the model is 10x cheaper than 6x64 anyway)
+    kw_ = width_ < 32 ? 32 : width_;
     if (depth_ < 1 || depth_ > 16) fail("nnDepth must be in 1..16 (got " + std::to_string(depth_) + ")");
     if (std::strcmp(cfg.optimizer, "Adam") == 0) sgd_ = false;
     else if (std::strcmp(cfg.optimizer, "SGD") == 0) sgd_ = true;
@@ -1246,7 +1264,14 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     if (std::strcmp(cfg.loss_fn, "RelativeL2Luminance") == 0) loss_id_ = 0;
     else if (std::strcmp(cfg.loss_fn, "L2") == 0) loss_id_ = 1;
     else if (std::strcmp(cfg.loss_fn, "RelativeL2") == 0) loss_id_ = 2;
-    else fail(std::string("unsupported loss ") + cfg.loss_fn);
+    else if (std::strcmp(cfg.loss_fn, "L1") == 0) loss_id_ = 3;
+    else if (std::strcmp(cfg.loss_fn, "Mape") == 0) loss_id_ = 4;
+    else if (std::strcmp(cfg.loss_fn, "Smape") == 0) loss_id_ = 5;
+    else if (std::strcmp(cfg.loss_fn, "LogL1") == 0) loss_id_ = 6;
+    else
+        fail(std::string("unsupported loss ") + cfg.loss_fn +
+             " (built: RelativeL2Luminance, L2, RelativeL2, L1, Mape, Smape, LogL1; tiny-cuda-nn's CrossEntropy and Variance need a "
+             "sample pdf the NRC path does not have)");
     // encoded width, padded to a multiple of 16 with 1.0 (tiny-cuda-nn); the fused kernels cover the north-star model
     enc_dims_ = (pos_enc_dims(cfg.pos_id) + dir_enc_dims(cfg.dir_id) + 15u) / 16u * 16u;
     fused_ = cfg.pos_id == 3 && cfg.dir_id == 0 && width_ == 64 && depth_ == 6;
@@ -1307,7 +1332,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 
     // fragment-image gather tables: [frag][lane][8]; layer 0 [mt][s], hidden layer l [mt][s], output [s];
     // backward image: hidden layer l (W^T) [mt over inputs][s over outputs], output layer [mt] (one k-step, 3 live rows)
-    const int D = (int)depth_, mt_n = (int)width_ / 32, ksh = (int)width_ / 16, ks0 = (int)enc_dims_ / 16, W = (int)width_;
+    const int D = (int)depth_, mt_n = (int)kw_ / 32, ksh = (int)kw_ / 16, ks0 = (int)enc_dims_ / 16, W = (int)width_;
     const int E = (int)enc_dims_;
     const int hid_base = mt_n * ks0, out_base = hid_base + (D - 1) * mt_n * ksh;
     n_frag_fwd_ = (uint32_t)(out_base + ksh);
@@ -1319,21 +1344,24 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         const int r = lane & 31, h = lane >> 5;
         for (int j = 0; j < 8; j++) {
             for (int mt = 0; mt < mt_n; mt++) {
+                const bool row_ok = 32 * mt + r < W;          // rows / columns beyond the true width stay -1 = zero (width 16)
                 for (int s = 0; s < ks0; s++) {
                     const int k = fused_ ? fmap80(s, h, j) : 16 * s + 8 * h + j;
-                    sf[slot(mt * ks0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + r) * E + k);
+                    if (row_ok) sf[slot(mt * ks0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + r) * E + k);
                 }
                 for (int l = 1; l < D; l++)
                     for (int s = 0; s < ksh; s++) {
+                        if (!row_ok || kperm(s, h, j) >= W) continue;
                         sf[slot(hid_base + (l - 1) * mt_n * ksh + mt * ksh + s, lane, j)] =
                             (int32_t)(layers_[l].off + (32 * mt + r) * W + kperm(s, h, j));
                         sb[slot((l - 1) * mt_n * ksh + mt * ksh + s, lane, j)] =
                             (int32_t)(layers_[l].off + kperm(s, h, j) * W + (32 * mt + r));
                     }
                 const int k = 8 * h + j;
-                if (k < 3) sb[slot((D - 1) * mt_n * ksh + mt, lane, j)] = (int32_t)(layers_[D].off + k * W + (32 * mt + r));
+                if (k < 3 && row_ok) sb[slot((D - 1) * mt_n * ksh + mt, lane, j)] = (int32_t)(layers_[D].off + k * W + (32 * mt + r));
             }
             for (int s = 0; s < ksh; s++) {
+                if (kperm(s, h, j) >= W) continue;
                 if (r < 3) sf[slot(out_base + s, lane, j)] = (int32_t)(layers_[D].off + r * W + kperm(s, h, j));
                 if (hash_) sb[slot(din_base + s, lane, j)] = (int32_t)(layers_[0].off + kperm(s, h, j) * E + r);
             }
@@ -1461,7 +1489,7 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     if (!fused_) {
         launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
         const float* skip_in = skip_zero_queries ? d_in : nullptr;
-        if (width_ == 32) {
+        if (kw_ == 32) {
             uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
             const uint32_t cap = (uint32_t)num_cus() * 4u;
             if (blocks > cap) blocks = cap;
@@ -1471,7 +1499,7 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             else
                 hipLaunchKernelGGL((k_infer_gen<32, 256, false>), dim3(blocks), dim3(256), 2 * 5 * 1024, s, (const half_t*)d_feat_[0],
                                    d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
-        } else if (width_ == 64) {           // 4 waves x 2 tiles = 256 samples per workgroup pass, 20 KB of LDS
+        } else if (kw_ == 64) {           // 4 waves x 2 tiles = 256 samples per workgroup pass, 20 KB of LDS
             uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
             const uint32_t cap = (uint32_t)num_cus() * 4u;
             if (blocks > cap) blocks = cap;
@@ -1593,7 +1621,7 @@ void Mlp::ensure_train_workspace(uint32_t n)
     if (d_loss_part_) (void)hipFree(d_loss_part_);
     d_acts_ = d_deltas_ = nullptr;
     d_slabs_ = d_loss_part_ = nullptr;
-    const size_t rows_a = enc_dims_ + (size_t)depth_ * width_, rows_d = (size_t)depth_ * width_ + 8;
+    const size_t rows_a = enc_dims_ + (size_t)depth_ * kw_, rows_d = (size_t)depth_ * kw_ + 8;
     NRC_HIP(hipMalloc(&d_acts_, rows_a * n * 2));
     NRC_HIP(hipMalloc(&d_deltas_, rows_d * n * 2));
     NRC_HIP(hipMemset(d_deltas_, 0, rows_d * n * 2));
@@ -1610,8 +1638,8 @@ void Mlp::ensure_train_workspace(uint32_t n)
         const uint32_t D = depth_;
         for (uint32_t l = 0; l <= D; l++) {
             const MlpLayer& L = layers_[l];
-            const uint32_t a_rows = l == D ? D * width_ : l * width_;                 // delta_l rows
-            const uint32_t b_rows = l == 0 ? 0 : enc_dims_ + (l - 1) * width_;        // a_{l-1} rows (enc for l = 0)
+            const uint32_t a_rows = l == D ? D * kw_ : l * kw_;                       // delta_l rows (kernel width: 32 for width 16)
+            const uint32_t b_rows = l == 0 ? 0 : enc_dims_ + (l - 1) * kw_;           // a_{l-1} rows (enc for l = 0)
             for (uint32_t mt = 0; mt * 32 < L.out; mt++)
                 for (uint32_t nt = 0; nt * 32 < L.in; nt++) {
                     WgradTile T;
@@ -1673,9 +1701,9 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
         const uint32_t cap = (uint32_t)num_cus() * 4u;
         if (blocks > cap) blocks = cap;
-        if (width_ == 32)
+        if (kw_ == 32)
             hipLaunchKernelGGL(k_train_gen<32>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
-        else if (width_ == 64)
+        else if (kw_ == 64)
             hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
         else
             hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
@@ -1691,7 +1719,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
     NRC_HIP(hipGetLastError());
     const uint32_t n_chunks = ceil_div(n, WGRAD_CHUNK);
     hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_, (const half_t*)d_acts_, n,
-                       depth_ * width_ + 8, enc_dims_ + depth_ * width_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
+                       depth_ * kw_ + 8, enc_dims_ + depth_ * kw_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
                        n_mlp_);
     NRC_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_mlp_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_mlp_,

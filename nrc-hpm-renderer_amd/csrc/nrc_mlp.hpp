@@ -52,6 +52,7 @@ private:
 
     nrc_config cfg_;
     uint32_t width_, depth_, enc_dims_, n_params_;
+    uint32_t kw_ = 0;            // width the kernels run at: max(width_, 32)
     uint32_t loss_id_;
     bool sgd_ = false;           // nested optimizer: Adam (default) or SGD
     bool fused_ = false;         // north-star model (Frequency+OneBlob, 6x64): fully fused kernels; otherwise the generic path

@@ -868,27 +868,27 @@ float orc_nn_backward(void* p, const float* in, const float* target, uint32_t n,
         forward_one(*nn, wq, enc.data(), 1, &acts, y);
         const float* t = target + 3 * (size_t)i;
         float dy[3];
+        /* tiny-cuda-nn element-wise losses (PARITY UNPINNED: the submodule is absent, formulas from its published
+         * loss headers): value / n_total and dL/dy * loss_scale / n_total; relative losses keep their denominator constant */
+        float lum2 = 0.0f;
         if (nn->cfg.loss_id == 0) {             /* RelativeL2Luminance */
             float lum = (0.299f * y[0] + 0.587f * y[1]) + 0.114f * y[2];
-            float den = lum * lum + 0.01f;
-            for (int c = 0; c < 3; c++) {
-                float d = y[c] - t[c];
-                loss_sum += (double)(d * d / den / n_total);
-                dy[c] = loss_scale * (2.0f * d / den / n_total);
+            lum2 = lum * lum + 0.01f;
+        }
+        for (int c = 0; c < 3; c++) {
+            const float d = y[c] - t[c];
+            float value, grad;
+            switch (nn->cfg.loss_id) {
+            case 0: value = d * d / lum2; grad = 2.0f * d / lum2; break;
+            case 1: value = d * d; grad = 2.0f * d; break;                                      /* L2 */
+            case 2: { float den = y[c] * y[c] + 0.01f; value = d * d / den; grad = 2.0f * d / den; break; }   /* RelativeL2 */
+            case 3: value = fabsf(d); grad = copysignf(1.0f, d); break;                         /* L1 */
+            case 4: { float sc = 1.0f / (fabsf(t[c]) + 0.01f); value = fabsf(d) * sc; grad = copysignf(sc, d); break; }   /* Mape */
+            case 5: { float sc = 1.0f / (0.5f * (fabsf(y[c]) + fabsf(t[c])) + 0.01f); value = fabsf(d) * sc; grad = copysignf(sc, d); break; }   /* Smape */
+            default: { float dv = fabsf(d) + 1.0f; value = logf(dv); grad = copysignf(1.0f / dv, d); break; }      /* LogL1 */
             }
-        } else if (nn->cfg.loss_id == 1) {      /* L2 */
-            for (int c = 0; c < 3; c++) {
-                float d = y[c] - t[c];
-                loss_sum += (double)(d * d / n_total);
-                dy[c] = loss_scale * (2.0f * d / n_total);
-            }
-        } else {                                /* RelativeL2 */
-            for (int c = 0; c < 3; c++) {
-                float d = y[c] - t[c];
-                float den = y[c] * y[c] + 0.01f;
-                loss_sum += (double)(d * d / den / n_total);
-                dy[c] = loss_scale * (2.0f * d / den / n_total);
-            }
+            loss_sum += (double)(value / n_total);
+            dy[c] = loss_scale * (grad / n_total);
         }
         delta.assign(3, 0.0f);
         for (int c = 0; c < 3; c++) delta[c] = orc_round_f16(dy[c]);
