@@ -110,7 +110,8 @@ def test_infer_and_train_batch_slicing_and_filter(api, orc, torch_gpu):
     c.Destroy()
 
 
-@pytest.mark.parametrize("loss_fn,loss_id", [("RelativeL2Luminance", 0), ("L2", 1), ("RelativeL2", 2)])
+@pytest.mark.parametrize("loss_fn,loss_id", [("RelativeL2Luminance", 0), ("L2", 1), ("RelativeL2", 2), ("L1", 3), ("Mape", 4), ("Smape", 5),
+                                             ("LogL1", 6)])
 def test_backward_matches_oracle(api, orc, torch_gpu, loss_fn, loss_id):
     c = api.NeuralRadianceCache(api.AppConfig(loss_fn=loss_fn))
     onn = orc.nn_create(loss_id=loss_id)
@@ -249,8 +250,8 @@ def test_sgd_optimizer_matches_oracle(api, orc, torch_gpu, model):
 
 
 def test_unsupported_configurations_fail_loudly(api, torch_gpu):
-    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_width=16), dict(nn_depth=0), dict(optimizer="Shampoo"),
-               dict(loss_fn="Huber")):
+    for kw in (dict(pos_id=4), dict(dir_id=3), dict(pos_id=0, hashgrid_log2_size=30), dict(nn_width=96), dict(nn_width=8), dict(nn_depth=0), dict(optimizer="Shampoo"),
+               dict(loss_fn="CrossEntropy"), dict(loss_fn="Variance"), dict(log2_infer_batch_size=0), dict(train_ring_buf_size=-1.0)):
         with pytest.raises(RuntimeError, match="SkyRenderer ERROR"):
             api.NeuralRadianceCache(api.AppConfig(**kw))
 
@@ -272,6 +273,7 @@ def test_full_size_inference_properties(cache, orc, torch_gpu):
 GENERIC = [  # (posID, dirID, width, depth): everything except the fused 3/0/64/6 model runs the generic kernels
     (1, 0, 64, 6), (2, 2, 64, 4), (3, 1, 64, 2), (3, 0, 64, 5), (3, 0, 128, 8), (1, 1, 128, 3), (2, 0, 128, 1),
     (3, 0, 32, 4), (2, 1, 32, 2),
+    (3, 0, 16, 3), (1, 1, 16, 2), (0, 0, 16, 2),      # nnWidth 16: tiny-cuda-nn's smallest FullyFusedMLP width, on the 32-row MFMA tiles
 ]
 
 
@@ -279,15 +281,16 @@ GENERIC = [  # (posID, dirID, width, depth): everything except the fused 3/0/64/
 def test_generic_models_match_oracle(api, orc, torch_gpu, pos_id, dir_id, width, depth):
     """other encodings (src/AppConfig.cpp:11-87: Identity / TriangleWave / Frequency x OneBlob / Identity / TriangleWave),
     widths 64/128 (BASELINE configs[4]: 8x128) and depths: inference, gradients and one optimizer step vs the oracle"""
-    c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth))
-    onn = orc.nn_create(pos_id=pos_id, dir_id=dir_id, width=width, depth=depth)
+    hg = 11 if pos_id == 0 else 0
+    c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth, hashgrid_log2_size=hg))
+    onn = orc.nn_create(pos_id=pos_id, dir_id=dir_id, width=width, depth=depth, hashgrid_log2_size=hg)
     assert c.ParamCount() == onn.n_params
     assert np.array_equal(c.GetParams(0), onn.buffer(0))
     randomize(c, onn, seed=3, scale=1.0)
     n = 1024 + 37
     x = queries(n, seed=pos_id * 7 + dir_id, nan_frac=0.1 if dir_id == 0 else 0.0)   # only OneBlob absorbs the NaN phi of quirk Q5
-    if pos_id == 1:
-        x[:, :3] -= 31.0                                     # keep Identity positions O(1)
+    if pos_id in (0, 1):
+        x[:, :3] -= 31.0                                     # keep Identity / HashGrid positions in [0, 1)
     d_out = torch_gpu.empty((n, 3), device="cuda")
     c.Infer(torch_gpu.from_numpy(x).cuda(), d_out, useEma=True)
     got, ref = d_out.cpu().numpy(), onn.forward(x, True, 1)

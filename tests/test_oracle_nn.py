@@ -54,11 +54,11 @@ def test_oneblob_encoding(orc):
     assert abs(e[0, 0] - e[0, 3]) < 1e-3 and e[0, 1] < 1e-3
 
 
-def torch_mlp(nn, enc, use_ema, quant):
+def torch_mlp(nn, enc, use_ema, quant, width=64, depth=6):
     w = torch.from_numpy(np.array(nn.buffer(1 if use_ema else 0)))
     if quant:
         w = w.half().float()
-    dims = [(64, 80)] + [(64, 64)] * 5 + [(3, 64)]
+    dims = [(width, 80)] + [(width, width)] * (depth - 1) + [(3, width)]
     mats, off = [], 0
     for o, i in dims:
         mats.append(w[off:off + o * i].view(o, i).clone().requires_grad_(True))
@@ -84,15 +84,16 @@ def test_forward_matches_torch(orc):
     assert np.linalg.norm(y16 - y32) / np.linalg.norm(y32) < 1e-2      # fp16 storage stays close to fp32
 
 
-@pytest.mark.parametrize("loss_id", [0, 1, 2])
-def test_backward_matches_autograd(orc, loss_id):
-    nn = orc.nn_create(loss_id=loss_id)
+@pytest.mark.parametrize("loss_id,width", [(0, 64), (1, 64), (2, 64), (3, 64), (4, 64), (5, 64), (6, 64), (0, 16)],
+                         ids=["RelativeL2Luminance", "L2", "RelativeL2", "L1", "Mape", "Smape", "LogL1", "width16"])
+def test_backward_matches_autograd(orc, loss_id, width):
+    nn = orc.nn_create(loss_id=loss_id, width=width)
     n = 256
     x = queries(n, seed=1)
     rng = np.random.default_rng(2)
     t = rng.random((n, 3), dtype=np.float32) * 2.0
     loss = nn.backward(x, t)
-    y, mats = torch_mlp(nn, nn.encode(x), False, True)
+    y, mats = torch_mlp(nn, nn.encode(x), False, True, width=width)
     tt = torch.from_numpy(t)
     N = 3 * n
     if loss_id == 0:
@@ -100,9 +101,18 @@ def test_backward_matches_autograd(orc, loss_id):
         den = (lum * lum + 0.01).detach()[:, None]       # tiny-cuda-nn treats the normaliser as a constant
     elif loss_id == 1:
         den = torch.ones_like(y)
-    else:
+    elif loss_id == 2:
         den = (y * y + 0.01).detach()
-    lt = ((y - tt) ** 2 / den / N).sum()
+    if loss_id <= 2:
+        lt = ((y - tt) ** 2 / den / N).sum()
+    elif loss_id == 3:                                    # L1
+        lt = ((y - tt).abs() / N).sum()
+    elif loss_id == 4:                                    # Mape
+        lt = ((y - tt).abs() / (tt.abs() + 0.01) / N).sum()
+    elif loss_id == 5:                                    # Smape: the scale is a constant in tiny-cuda-nn's gradient
+        lt = ((y - tt).abs() / (0.5 * (y.abs() + tt.abs()) + 0.01).detach() / N).sum()
+    else:                                                 # LogL1
+        lt = (torch.log(1.0 + (y - tt).abs()) / N).sum()
     lt.backward()
     g_ref = torch.cat([m.grad.reshape(-1) for m in mats]).numpy()
     g = np.array(nn.buffer(4))
