@@ -86,8 +86,8 @@ int nrc_cache_infer_and_train(nrc_cache_t* c, const uint32_t* infer_filter, int 
 int nrc_cache_destroy(nrc_cache_t* c);
 /* GetLoss / Get{Infer,Train}Batch{Count,Size} (src/NeuralRadianceCache.cu:109-132).
  * The reference reads the loss back synchronously inside every training step (trainer->loss, :154) and GetLoss() returns that
- * value; its main loop polls it every frame (src/main.cu:303,376).  Here every training step copies its loss to pinned host
- * memory behind an event on the training stream:
+ * value; its main loop polls it every frame (src/main.cu:303,376).  Here a one-thread kernel behind every training step stores
+ * {loss, step number} into host-mapped pinned memory on the training stream:
  *   nrc_cache_get_loss           the loss of the most recent training step that has COMPLETED; never blocks and never drains
  *                                the renderer's frame pipeline (it lags the enqueued work by at most the pipeline depth, three
  *                                frames).  NaN/Inf polling as in src/main.cu:380-384 works unchanged.

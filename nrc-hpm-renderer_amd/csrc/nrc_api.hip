@@ -63,6 +63,19 @@ struct Rccl {
     }
 };
 
+// one thread: the training step's loss and its sequence number as ONE 8-byte store into host-mapped pinned memory
+struct LossCell {
+    float loss;
+    uint32_t seq;
+};
+__global__ void k_publish_loss(const float* __restrict__ d_loss, uint32_t seq, unsigned long long* __restrict__ host_cell)
+{
+    LossCell c{d_loss[0], seq};
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &c, 8);
+    __hip_atomic_store(host_cell, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------------------- Cache
 class Cache {
     // validated before any size is derived from it: 2 << (log2 - 1) with log2 = 0 would shift by 0xFFFFFFFF
@@ -85,9 +98,10 @@ public:
           train_batch_count_(cfg.train_batch_count),
           mlp_(new Mlp(cfg))
     {
-        for (auto& e : ev_loss_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        NRC_HIP(hipHostMalloc((void**)&h_loss_, sizeof(float) * kLossSlots, hipHostMallocDefault));
-        for (int k = 0; k < kLossSlots; k++) h_loss_[k] = 0.0f;
+        NRC_HIP(hipEventCreateWithFlags(&ev_loss_, hipEventDisableTiming));
+        NRC_HIP(hipHostMalloc((void**)&h_loss_, sizeof(unsigned long long), hipHostMallocMapped));
+        *h_loss_ = 0ull;
+        NRC_HIP(hipHostGetDevicePointer((void**)&d_loss_cell_, h_loss_, 0));
         NRC_HIP(hipEventCreateWithFlags(&ev_owner_infer_, hipEventDisableTiming));
         NRC_HIP(hipEventCreateWithFlags(&ev_owner_train_, hipEventDisableTiming));
     }
@@ -190,40 +204,27 @@ public:
     }
 
     // m_Loss = trainer->loss(*ctx) after every training step (src/NeuralRadianceCache.cu:154) is a device->host sync in the
-    // reference.  Here every step's loss cell is copied to a pinned host slot on the training stream, followed by an event:
-    //   get_loss(false)  the loss of the most recent step that has COMPLETED -- never blocks, never drains the frame pipeline
-    //                    (what a per-frame GetLoss() poll needs: src/main.cu:303,376; it lags the enqueued work by the
-    //                    pipeline depth, at most three frames);
+    // reference.  Here a one-thread kernel behind every step stores {loss, step number} with one 8-byte store into host-mapped
+    // pinned memory (no event polling: the runtime reports a recorded event complete only with the batch it was submitted in):
+    //   get_loss(false)  the loss of the most recent step that has COMPLETED -- a plain read of that cell; never blocks, never
+    //                    drains the frame pipeline (what a per-frame GetLoss() poll needs: src/main.cu:303,376; it lags the
+    //                    enqueued work by the pipeline depth, at most three frames);
     //   get_loss(true)   waits for the last step that was enqueued (only for that step, not for the device).
     void push_loss(hipStream_t st)
     {
-        const int slot = (int)(loss_pushed_ % kLossSlots);
-        NRC_HIP(hipMemcpyAsync(&h_loss_[slot], mlp_->loss_ptr(), sizeof(float), hipMemcpyDeviceToHost, st));
-        NRC_HIP(hipEventRecord(ev_loss_[slot], st));
         loss_pushed_++;
+        hipLaunchKernelGGL(k_publish_loss, dim3(1), dim3(1), 0, st, (const float*)mlp_->loss_ptr(), loss_pushed_, d_loss_cell_);
+        NRC_HIP(hipGetLastError());
+        NRC_HIP(hipEventRecord(ev_loss_, st));
     }
     float get_loss(bool wait)
     {
-        if (loss_pushed_ == 0) return loss_;
-        const uint64_t newest = loss_pushed_ - 1;
-        if (wait) {
-            NRC_HIP(hipEventSynchronize(ev_loss_[newest % kLossSlots]));
-            loss_ = h_loss_[newest % kLossSlots];
-            loss_seen_ = newest + 1;
-            return loss_;
-        }
-        // newest first; a slot older than the ring has been re-armed by a younger step and is covered by that one
-        const uint64_t oldest = newest + 1 > (uint64_t)kLossSlots ? newest + 1 - kLossSlots : 0;
-        for (uint64_t k = newest + 1; k-- > std::max(oldest, loss_seen_);) {
-            const hipError_t q = hipEventQuery(ev_loss_[k % kLossSlots]);
-            if (q == hipSuccess) {
-                loss_ = h_loss_[k % kLossSlots];
-                loss_seen_ = k + 1;
-                break;
-            }
-            if (q != hipErrorNotReady) NRC_HIP(q);
-        }
-        return loss_;
+        if (loss_pushed_ == 0) return 0.0f;
+        if (wait) NRC_HIP(hipEventSynchronize(ev_loss_));
+        LossCell c;
+        const unsigned long long bits = __atomic_load_n(h_loss_, __ATOMIC_ACQUIRE);
+        std::memcpy(&c, &bits, 8);
+        return c.loss;       // c.seq = the step it belongs to (0: none has completed yet)
     }
 
     Mlp& mlp() { return *mlp_; }
@@ -256,7 +257,7 @@ public:
     ~Cache()
     {
         if (comm_) (void)Rccl::get().comm_destroy(comm_);
-        for (auto& e : ev_loss_) if (e) (void)hipEventDestroy(e);
+        if (ev_loss_) (void)hipEventDestroy(ev_loss_);
         if (ev_owner_infer_) (void)hipEventDestroy(ev_owner_infer_);
         if (ev_owner_train_) (void)hipEventDestroy(ev_owner_train_);
         if (h_loss_) (void)hipHostFree(h_loss_);
@@ -278,11 +279,10 @@ private:
     void* hook_user_ = nullptr;
     ncclComm_t comm_ = nullptr;
     uint32_t loss_norm_factor_ = 1;
-    static constexpr int kLossSlots = 8;
-    float loss_ = 0.0f;
-    float* h_loss_ = nullptr;                 // pinned
-    hipEvent_t ev_loss_[kLossSlots] = {};
-    uint64_t loss_pushed_ = 0, loss_seen_ = 0;
+    unsigned long long* h_loss_ = nullptr;    // pinned, host-mapped: LossCell written by k_publish_loss
+    unsigned long long* d_loss_cell_ = nullptr;
+    hipEvent_t ev_loss_ = nullptr;            // behind the newest publish (blocking GetLoss)
+    uint32_t loss_pushed_ = 0;
     const void* owner_ = nullptr;
     hipStream_t owner_infer_stream_ = nullptr, owner_train_stream_ = nullptr;
     hipEvent_t ev_owner_infer_ = nullptr, ev_owner_train_ = nullptr;
