@@ -837,12 +837,12 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 // barrier per layer, no staging registers, 0.5-1 KB of L2 traffic per sample.  Same accumulator-as-
 // operand chain and numerics as k_infer.  skip_in (renderer inference): tiles whose 32 queries are all zero are not computed,
 // a workgroup whose 256 queries are all zero does not even stream the weights.
-template <int WIDTH, int THREADS, bool FEAT_LM>
+template <int WIDTH, int THREADS, bool FEAT_LM, int NT = 2>
 __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                       const uint4* __restrict__ img, int depth, int ks0,
                                                       const float* __restrict__ skip_in)
 {
-    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, NT = 2, WAVES = THREADS / 64;
+    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = THREADS / 64;
     constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);        // largest stage (layer 0 has ks0 <= 5 k-steps)
     constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;      // uint4 per thread per stage
     extern __shared__ uint4 lds_w[];                              // [2][STAGE_FRAGS * 64]
@@ -889,7 +889,9 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
             mine[t] = used;                           // this lane's own query is live
             run[t] = __ballot(used) != 0ull;          // wave-uniform
         }
-        const bool wave_runs = run[0] || run[1];
+        bool wave_runs = false;
+#pragma unroll
+        for (int t = 0; t < NT; t++) wave_runs |= run[t];
         if (__syncthreads_or(wave_runs ? 1 : 0) == 0) continue;       // nothing to do for this group: stage 0 stays staged
 
         f32x16 acc[NT][MTG];
@@ -1509,23 +1511,27 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             else
                 hipLaunchKernelGGL((k_infer_gen<64, 256, false>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0],
                                    d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
-        } else {                             // 8 waves x 2 tiles = 512 samples per pass, 64 KB of LDS, one workgroup per CU
-            uint32_t blocks = ceil_div(ceil_div(n, 32), 16);
-            const uint32_t cap = (uint32_t)num_cus();
+        } else {
+            // 8 waves x 1 tile = 256 samples per staged layer (32 KB), 64 KB of LDS.  One tile per wave keeps the four 32-row
+            // accumulators of a 128-wide layer (64 VGPRs) and the operands in registers: with two tiles per wave the kernel
+            // spilled 27 VGPRs to scratch.  The staged layers come out of the L2 (the 250 KB image is resident there): 1 KB per
+            // sample instead of 0.5 KB, still far below what the per-tile fragment fetches cost (7.8 KB).
+            uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
+            const uint32_t cap = (uint32_t)num_cus() * 2u;
             if (blocks > cap) blocks = cap;
             const size_t lds = 2 * 32 * 1024;
             if (!attr_infer_set_) {      // per instance = per device: the attribute belongs to the device's code object
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false>),
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, true>),
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, true, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_infer_set_ = true;
             }
             if (hash_)
-                hipLaunchKernelGGL((k_infer_gen<128, 512, true>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
+                hipLaunchKernelGGL((k_infer_gen<128, 512, true, 1>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
                                    img, (int)depth_, (int)enc_dims_ / 16, skip_in);
             else
-                hipLaunchKernelGGL((k_infer_gen<128, 512, false>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
+                hipLaunchKernelGGL((k_infer_gen<128, 512, false, 1>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
                                    img, (int)depth_, (int)enc_dims_ / 16, skip_in);
         }
         NRC_HIP(hipGetLastError());

@@ -63,6 +63,8 @@ def test_per_frame_loss_poll_does_not_drain_the_pipeline(api, sc, torch_gpu):
         for f in range(20):
             ren.SetFrameRandom(frs[f])
             ren.Render(None, True)
+            if mode == "block":
+                seen.append(nrc.GetLoss(wait=True))
         torch_gpu.cuda.synchronize()
         t0 = time.perf_counter()
         for f in range(frames):
@@ -84,7 +86,8 @@ def test_per_frame_loss_poll_does_not_drain_the_pipeline(api, sc, torch_gpu):
     t_block, blocked, _ = loop("block")
     assert final[0] == final[1]                                      # drained: both polls agree
     assert np.isfinite(polled).all() and len(set(polled)) > frames // 4   # the poll keeps up with training
-    assert set(polled[8:]) <= set(blocked) | {final[1]}              # same deterministic loss sequence, only delayed
+    assert set(polled) <= set(blocked)                               # the same deterministic loss sequence, only delayed (the host
+    #                                                                  enqueues frames faster than the GPU retires them)
     assert t_poll <= 1.10 * t_none, (t_poll, t_none, t_block)
     assert t_none < 0.6e-3                                           # the loop itself runs at the bench frame rate
 
