@@ -168,6 +168,58 @@ __device__ __forceinline__ void encode80(const float (&x)[5], int h, half8 (&b)[
     }
 }
 
+// the same encoding, one layer-0 k-step at a time (s is a compile-time constant after unrolling): lets the inference chain build
+// each B fragment right before the MFMAs that consume it instead of holding all five per tile (40 VGPRs for two tiles)
+template <int S>
+__device__ __forceinline__ half8 encode80_frag(const float (&x)[5], int h)
+{
+    half8 b;
+    if constexpr (S < 4) {
+        const int g0 = 2 * S, g1 = 2 * S + 1;
+        const float xv = h ? x[g1 / 3] : x[g0 / 3];
+        const float sc = h ? (float)(1 << (4 * (g1 % 3))) * 0.5f : (float)(1 << (4 * (g0 % 3))) * 0.5f;
+        const float rev = __builtin_amdgcn_fractf(xv * sc);
+        float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        b[0] = (half_t)sn;
+        b[1] = (half_t)cs;
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            const float t2 = sn + sn;
+            const float s2 = t2 * cs;
+            cs = __builtin_fmaf(-t2, sn, 1.0f);
+            sn = s2;
+            b[2 * i] = (half_t)sn;
+            b[2 * i + 1] = (half_t)cs;
+        }
+    } else {
+        const float rev = __builtin_amdgcn_fractf(x[2] * (h ? 512.0f : 128.0f));      // f = 10,11 | 8,9
+        const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        b[0] = (half_t)sn;
+        b[1] = (half_t)cs;
+        const float t2 = sn + sn;
+        b[2] = (half_t)(t2 * cs);
+        b[3] = (half_t)__builtin_fmaf(-t2, sn, 1.0f);
+        const float xd = h ? x[4] : x[3];
+        float cdf[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float bx = (float)k * 0.25f - xd;
+            const float kk = __builtin_rintf(bx);
+            const float w = bx - kk;
+            const float sat = __builtin_amdgcn_fmed3f(kk + 1.0f, 0.0f, 3.0f);
+            cdf[k] = sat + (__builtin_fabsf(kk) <= 1.0f ? quartic_cdf4(w) : 0.0f);
+        }
+        const bool bad = !(xd == xd);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
+            const float v = right - cdf[k];
+            b[4 + k] = (half_t)(bad ? (k == 3 ? 1.0f : 0.0f) : v);
+        }
+    }
+    return b;
+}
+
 // fragment bases inside the forward image
 constexpr int FRAG_L0 = 0;                       // [mt][s]      MT*KS0
 constexpr int FRAG_HID = MT * KS0;               // [l-1][mt][s] (depth-1)*MT*KSH
@@ -248,26 +300,54 @@ __device__ __forceinline__ void relu_pack_abl(const f32x16& acc, half8& lo, half
 
 // forward chain for NT independent 32-sample tiles of one wave: every weight fragment read from LDS feeds NT MFMAs, and
 // the ReLU/convert VALU work of one tile can overlap the MFMAs of the other inside the wave (in-order issue needs the ILP).
+template <int DEPTH, int NT, int ABL, int S>
+__device__ __forceinline__ void layer0_steps(const uint4* lw, int lane, int h, const float (&x)[NT][5], f32x16 (&acc0)[NT], f32x16 (&acc1)[NT])
+{
+    if constexpr (S < KS0) {
+        const half8 a0 = ld_frag(lw, FRAG_L0 + S, lane);
+        const half8 a1 = ld_frag(lw, FRAG_L0 + KS0 + S, lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            half8 bs;
+            if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) bs[j] = (half_t)x[t][(S + j) % 5];
+            } else {
+                bs = encode80_frag<S>(x[t], h);
+            }
+            acc0[t] = mfma(a0, bs, acc0[t]);
+            acc1[t] = mfma(a1, bs, acc1[t]);
+        }
+        layer0_steps<DEPTH, NT, ABL, S + 1>(lw, lane, h, x, acc0, acc1);
+    }
+}
+
 template <int DEPTH, int NT, int ABL = 0>
-__device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, half8 (&enc)[NT][KS0], f32x16 (&y)[NT])
+__device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, int h, const float (&x)[NT][5], f32x16 (&y)[NT])
 {
     f32x16 acc0[NT], acc1[NT];
     half8 b[NT][KSH];
 #pragma unroll
-    for (int l = 0; l < DEPTH; l++) {
-        const int ks = l == 0 ? KS0 : KSH;
-        const int base = l == 0 ? FRAG_L0 : FRAG_HID + (l - 1) * MT * KSH;
+    for (int t = 0; t < NT; t++) { acc0[t] = zero16(); acc1[t] = zero16(); }
+    layer0_steps<DEPTH, NT, ABL, 0>(lw, lane, h, x, acc0, acc1);      // the encoding is built fragment by fragment beside the MFMAs
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        relu_pack_abl<ABL>(acc0[t], b[t][0], b[t][1]);
+        relu_pack_abl<ABL>(acc1[t], b[t][2], b[t][3]);
+    }
+#pragma unroll
+    for (int l = 1; l < DEPTH; l++) {
+        const int base = FRAG_HID + (l - 1) * MT * KSH;
 #pragma unroll
         for (int t = 0; t < NT; t++) { acc0[t] = zero16(); acc1[t] = zero16(); }
 #pragma unroll
-        for (int s = 0; s < ks; s++) {
+        for (int s = 0; s < KSH; s++) {
             const half8 a0 = ld_frag(lw, base + s, lane);
-            const half8 a1 = ld_frag(lw, base + ks + s, lane);
+            const half8 a1 = ld_frag(lw, base + KSH + s, lane);
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const half8 bs = l == 0 ? enc[t][s] : b[t][s];
-                acc0[t] = mfma(a0, bs, acc0[t]);
-                acc1[t] = mfma(a1, bs, acc1[t]);
+                acc0[t] = mfma(a0, b[t][s], acc0[t]);
+                acc1[t] = mfma(a1, b[t][s], acc1[t]);
             }
         }
 #pragma unroll
@@ -289,7 +369,7 @@ __device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, half8 (
 // persistent workgroups; NT 32-sample tiles per wave per iteration; the next iteration's queries are loaded (20 B per
 // sample, straight from HBM/L2 into registers) before the current tiles are computed, so their latency is hidden.
 template <int DEPTH, int THREADS, int NT, int ABL = 0>
-__global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
+__global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
                                                   int skip_zero = 0)
 {
@@ -342,19 +422,7 @@ __global__ __launch_bounds__(THREADS) void k_infer(const float* __restrict__ in,
             live = __ballot(nz) != 0ull;
         }
         if (live) {
-            half8 enc[NT][KS0];
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                if constexpr ((ABL & 1) != 0) {
-#pragma unroll
-                    for (int s2 = 0; s2 < KS0; s2++)
-#pragma unroll
-                        for (int j = 0; j < 8; j++) enc[t][s2][j] = (half_t)x[t][(s2 + j) % 5];
-                } else {
-                    encode80(x[t], h, enc[t]);
-                }
-            }
-            forward_tiles<DEPTH, NT, ABL>(lw, lane, enc, y);
+            forward_tiles<DEPTH, NT, ABL>(lw, lane, h, x, y);
         } else {
 #pragma unroll
             for (int t = 0; t < NT; t++) y[t] = zero16();
