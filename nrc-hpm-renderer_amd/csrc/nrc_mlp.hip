@@ -1073,7 +1073,8 @@ __global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* 
     const uint32_t rows_a = e16 + (uint32_t)depth * WIDTH, rows_d = (uint32_t)depth * WIDTH + 8u;
     const uint32_t n_tiles = a.n >> 5;
     const int hid_base = MTG * ks0;
-    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+    const uint32_t wpb = blockDim.x >> 6;       // 1 or 4 waves per workgroup (the host picks: small batches spread over every CU)
+    for (uint32_t tile = blockIdx.x * wpb + wave; tile < n_tiles; tile += gridDim.x * wpb) {
         const uint32_t sidx = tile * 32u + r;
         const half_t* fp = a.feat + (size_t)sidx * e16 + 8 * h;
         half_t* const pa = a.acts + ((size_t)(sidx >> 3) * rows_a) * 8 + (sidx & 7u);
@@ -1773,14 +1774,18 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.depth = (int)depth_;
         a.ks0 = (int)enc_dims_ / 16;
         a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
+        // a training batch is a few hundred 32-sample tiles (16 384 rays = 512): one-wave workgroups put a tile on every CU
+        // (two per CU) instead of filling half of the chip with four-wave workgroups; large batches keep four waves
         const uint32_t cap = (uint32_t)num_cus() * 4u;
+        uint32_t threads = THREADS;
+        if (n_tiles <= cap) { threads = 64; blocks = n_tiles; }
         if (blocks > cap) blocks = cap;
         if (kw_ == 32)
-            hipLaunchKernelGGL(k_train_gen<32>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+            hipLaunchKernelGGL(k_train_gen<32>, dim3(blocks), dim3(threads), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
         else if (kw_ == 64)
-            hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+            hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(threads), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
         else
-            hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(THREADS), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+            hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(threads), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
         if (hash_) {
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
