@@ -232,6 +232,12 @@ void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes);
  * oracle, which always walks).  The 8x8-pixel tile mask behind it is rebuilt on the render stream whenever the camera changes.
  * on = 0 traces every ray (what count_fetches needs to report the ALGORITHM's look-ups rather than the executed ones). */
 int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on);
+/* Costliest-first launch order of gen_rays' 8x8-pixel tiles (on by default): every 16th frame records what each tile's wave cost,
+ * a counting sort turns that into the order the following frames start their tiles in (the long walks through the cloud first,
+ * the cheap rim in the tail of the launch).  The order is a permutation of the tiles and nothing else: frames are bit-identical
+ * with and without.  tile_order copies the permutation in use (n = nrc_renderer_tile_order(r, NULL, 0) entries) to the host. */
+int nrc_renderer_set_cost_order(nrc_renderer_t* r, int on);
+size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t capacity);
 /* The NRC vertex images (buffers 2 and 3: nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) are read back only at the pixels of
  * the train grid (prep_train_rays.comp:113-118), so by default gen_rays stores them only there; on != 0 makes it store every
  * pixel that entered the volume, as the reference's images hold (tests, debugging).  vertex_image_bytes: what one frame stores. */

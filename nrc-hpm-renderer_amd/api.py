@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
     "nrc_cache_get_loss_blocking", "nrc_cache_comm_info", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
+    "nrc_renderer_set_cost_order", "nrc_renderer_tile_order",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -113,6 +114,8 @@ def load_library():
     L.nrc_renderer_frame_time_ms.restype = C.c_float
     L.nrc_renderer_vertex_image_bytes.restype = C.c_size_t
     L.nrc_renderer_vertex_image_bytes.argtypes = [C.c_void_p]
+    L.nrc_renderer_tile_order.restype = C.c_size_t
+    L.nrc_renderer_tile_order.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.nrc_mc_renderer_framebuffer.restype = C.c_void_p
     L.nrc_mc_renderer_frame_time_ms.restype = C.c_float
     for name in ("nrc_cache_get_loss", "nrc_cache_get_loss_blocking", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
@@ -465,6 +468,20 @@ class NrcHpmRenderer:
     def SetEmptySkip(self, on=True):
         """exact empty-space early-out of camera rays (default on); off = every ray is traced"""
         _check(self.L.nrc_renderer_set_empty_skip(self.h, C.c_int(int(on))))
+
+    def SetCostOrder(self, on=True):
+        """costliest-first launch order of gen_rays' tiles from earlier frames' per-tile times (default on); frames do not change"""
+        _check(self.L.nrc_renderer_set_cost_order(self.h, C.c_int(int(on))))
+
+    def TileOrder(self):
+        """the tile permutation the next frame launches in (numpy uint32)"""
+        import numpy as np
+        n = self.L.nrc_renderer_tile_order(self.h, None, C.c_size_t(0))
+        out = np.zeros(n, np.uint32)
+        got = self.L.nrc_renderer_tile_order(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        if got != n:
+            raise RuntimeError(self.L.nrc_last_error().decode() or "nrc_renderer_tile_order failed")
+        return out
 
     def SetFullVertexImages(self, on=True):
         """store nrcRayOrigin / nrcRayDir for every pixel (the reference's images) instead of the train grid's pixels only"""

@@ -567,6 +567,18 @@ public:
         alloc(&d_scratch_, (2 * T + 4) * 4);
         alloc(&d_fetch_, 8);
         alloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4);
+        // costliest-first launch order of gen_rays' tiles: costs of frame N order frame N + 2 (sorted on stream D beside frame N + 1)
+        n_slots_ = camera_slots(w, h);
+        alloc(&d_tile_cost_, (size_t)n_slots_ * 4);
+        for (auto& o : d_tile_order_) alloc(&o, (size_t)n_slots_ * 4);
+        {
+            std::vector<uint32_t> ident(n_slots_);
+            for (uint32_t i = 0; i < n_slots_; i++) ident[i] = i;
+            for (auto& o : d_tile_order_) NRC_HIP(hipMemcpy(o, ident.data(), (size_t)n_slots_ * 4, hipMemcpyHostToDevice));
+        }
+        NRC_HIP(hipEventCreateWithFlags(&ev_order_done_, hipEventDisableTiming));
+        cost_order_ = getenv("NRC_NO_COST_ORDER") == nullptr;
+        if (const char* e = getenv("NRC_COST_ORDER_EVERY")) order_every_ = (uint64_t)std::max(2, atoi(e));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
         // train-ray generation + backward overlap inference + compositing on a second stream (NRC_SINGLE_STREAM=1 disables)
@@ -606,6 +618,7 @@ public:
         for (auto& e : ev_train_done_) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_comp_done_) if (e) (void)hipEventDestroy(e);
         if (ev_consumer_) (void)hipEventDestroy(ev_consumer_);
+        if (ev_order_done_) (void)hipEventDestroy(ev_order_done_);
         cache_.forget(this);
     }
 
@@ -647,6 +660,19 @@ public:
             if (D != A) NRC_HIP(hipStreamWaitEvent(A, ev_prep_done_[gp], 0));
         }
         if (frame_index_ >= 2 && D != B) NRC_HIP(hipStreamWaitEvent(D, ev_train_done_[pp], 0));   // train-ray set pp: frame N-2
+        // launch order: costliest tiles first, from the tile costs of an earlier frame.  Every order_every_ frames gen_rays
+        // records its per-tile times and a sort at the end of stream D's work for the frame (behind the train rays, so training
+        // does not wait for it) turns them into the other order buffer; the frames from two later on launch in that order (A
+        // waits for the sort's event, long complete by then).  A fifth stream for the sort is not an option: HIP multiplexes
+        // streams onto four hardware queues, and with five in use inference stopped overlapping gen_rays (frame 0.31 -> 0.40 ms).
+        if (cost_order_ && order_pending_ && frame_index_ >= order_pending_frame_ + 2) {
+            if (D != A) NRC_HIP(hipStreamWaitEvent(A, ev_order_done_, 0));
+            order_cur_ ^= 1;
+            order_pending_ = false;
+        }
+        const bool sample_cost = cost_order_ && !order_pending_ && frame_index_ % order_every_ == 0;
+        frame_.tile_order = cost_order_ ? (const uint32_t*)d_tile_order_[order_cur_] : nullptr;
+        frame_.tile_cost = sample_cost ? (uint32_t*)d_tile_cost_ : nullptr;
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
@@ -660,6 +686,12 @@ public:
         NRC_HIP(hipEventRecord(ev_[2], D));
         NRC_HIP(hipEventRecord(ev_prep_done_[gp], D));
         if (B != D) NRC_HIP(hipStreamWaitEvent(B, ev_prep_done_[gp], 0));
+        if (sample_cost) {      // order buffer cur^1: its last reader is a gen_rays before this one on A
+            launch_tile_order((const uint32_t*)d_tile_cost_, n_slots_, (uint32_t*)d_tile_order_[order_cur_ ^ 1], D);
+            NRC_HIP(hipEventRecord(ev_order_done_, D));
+            order_pending_ = true;
+            order_pending_frame_ = frame_index_;
+        }
         if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
         // same NRC from another camera, src/Reference.cpp:71-107)
@@ -713,6 +745,22 @@ public:
         sync();       // a frame in flight may be reading the mask
         empty_skip_ = on;
         mask_dirty_ = true;
+    }
+
+    void set_cost_order(bool on)
+    {
+        sync();
+        cost_order_ = on;
+    }
+    // the permutation the next frame launches its tiles in (after the pending sort, if one is due)
+    size_t tile_order(uint32_t* host_out, size_t capacity)
+    {
+        sync();
+        if (host_out == nullptr) return n_slots_;
+        if (capacity < n_slots_) throw std::invalid_argument("tile_order: capacity below the number of tile slots");
+        const int cur = (order_pending_ && frame_index_ >= order_pending_frame_ + 2) ? order_cur_ ^ 1 : order_cur_;
+        NRC_HIP(hipMemcpy(host_out, d_tile_order_[cur], (size_t)n_slots_ * 4, hipMemcpyDeviceToHost));
+        return n_slots_;
     }
 
     void set_camera(const nrc_camera& c)       // SetCamera, :561-604: reset blending, clear the accumulation images
@@ -891,7 +939,10 @@ private:
     TrainGrid tg_{};
     size_t ring_entries_ = 0;
     void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
-    static constexpr int kGenSets = 3;
+#ifndef NRC_GEN_SETS
+#define NRC_GEN_SETS 3
+#endif
+    static constexpr int kGenSets = NRC_GEN_SETS;
     void *d_info2_[kGenSets] = {}, *d_origin2_[kGenSets] = {}, *d_dir2_[kGenSets] = {};
     void *d_primary2_[kGenSets] = {}, *d_infer_in2_[kGenSets] = {};
     hipEvent_t ev_train_done_[2] = {nullptr, nullptr}, ev_comp_done_[kGenSets] = {};
@@ -913,6 +964,13 @@ private:
     bool consumer_pending_ = false;
     bool full_vertex_images_ = false;
     void* d_tile_mask_ = nullptr;
+    void* d_tile_cost_ = nullptr;
+    void* d_tile_order_[2] = {nullptr, nullptr};
+    uint32_t n_slots_ = 0;
+    hipEvent_t ev_order_done_ = nullptr;
+    bool cost_order_ = true, order_pending_ = false;
+    int order_cur_ = 0;
+    uint64_t order_every_ = 16, order_pending_frame_ = 0;
     nrc_camera nrc_cam_{};
     bool mask_dirty_ = true, empty_skip_ = true;
 };
@@ -1247,6 +1305,18 @@ int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on)
 {
     NRC_REQUIRE(r);
     return guarded([&] { r->impl.set_empty_skip(on != 0); });
+}
+int nrc_renderer_set_cost_order(nrc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.set_cost_order(on != 0); });
+}
+size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t capacity)
+{
+    if (!r) return 0;
+    size_t n = 0;
+    if (guarded([&] { n = r->impl.tile_order(host_out, capacity); }) != NRC_OK) return 0;
+    return n;
 }
 int nrc_mc_renderer_set_empty_skip(nrc_mc_renderer_t* r, int on)
 {

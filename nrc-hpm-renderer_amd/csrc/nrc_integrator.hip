@@ -696,18 +696,36 @@ __device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx
 
 // Camera kernels: each wave renders one 8x8 pixel tile (coherent paths inside a wave), four tiles of a row per workgroup.
 // Tile rows are issued centre-out, so the expensive middle of the image starts first and the cheap rim fills the tail of the
-// launch.  (Measured and rejected, tools/loop_profile.py: one-wave workgroups and a costliest-first order from per-tile clock
-// counts of earlier frames -- the launch already sits at its residency plateau; both only starve the concurrent streams.)
+// launch.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD (b + c) mod 8, MI355X_MICROARCH.md) and an
+// XCD never helps another out, so the MAPPING must spread the expensive tiles evenly: with 60 workgroups per tile row (1920
+// pixels) the XCD of a column alternates between only two values from row to row, every XCD ends up with its own comb of
+// columns, and the per-XCD work differed by 1.9x between the lightest and the heaviest (tools/loop_profile.py) -- the launch
+// ended with three of eight XCDs busy.  Rows are therefore padded to an ODD number of workgroups (the padding workgroup exits):
+// the XCD of a column then walks through all eight values over eight consecutive rows.
+// On top of that mapping the tiles are launched costliest first (DevFrame::tile_order, k_tile_order below): slot d of the grid
+// renders tile order[d].  (Measured and rejected, tools/loop_profile.py: one-wave workgroups.)
 constexpr uint32_t CAMERA_WAVES_PER_BLOCK = 4;
-__device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y)
+__host__ __device__ inline uint32_t camera_row_blocks(uint32_t w)
+{
+    const uint32_t blocks_x = (((w + 7u) >> 3) + CAMERA_WAVES_PER_BLOCK - 1u) / CAMERA_WAVES_PER_BLOCK;
+    return blocks_x | 1u;
+}
+// *slot: the wave's default slot (index into DevFrame::tile_cost)
+__device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
-    const uint32_t slot = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (slot >= tiles_x * tiles_y) return false;
-    const uint32_t k = slot / tiles_x, mid = tiles_y >> 1;
+    const uint32_t row_blocks = camera_row_blocks(fr.w);
+    uint32_t d = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (fr.tile_order != nullptr) d = __builtin_amdgcn_readfirstlane(fr.tile_order[d]);      // costliest tiles first
+    if (slot) *slot = d;
+    const uint32_t bd = d / CAMERA_WAVES_PER_BLOCK;
+    const uint32_t k = bd / row_blocks, jb = bd - k * row_blocks;
+    const uint32_t tx = jb * CAMERA_WAVES_PER_BLOCK + (d - bd * CAMERA_WAVES_PER_BLOCK);
+    if (k >= tiles_y || tx >= tiles_x) return false;
+    const uint32_t mid = tiles_y >> 1;
     const uint32_t ty = (k & 1u) ? mid - ((k + 1u) >> 1) : mid + (k >> 1);      // mid, mid-1, mid+1, ...: a bijection
-    *lx = (slot - k * tiles_x) * 8u + (lane & 7u);
+    *lx = tx * 8u + (lane & 7u);
     *y = ty * 8u + (lane >> 3);
     return *lx < fr.w && *y < fr.h;
 }
@@ -743,10 +761,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
                                                  unsigned long long* fetch_counter, TrainGrid tg, int full_vertex_images)
 {
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
-    uint32_t lx, y;
-    const bool inside = pixel_of_wave_tile(fr, &lx, &y);
+    uint32_t lx, y, slot;
+    const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
@@ -830,6 +849,9 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
         for (int k = 0; k < 5; k++) qo[k] = q[k];
     }
     count_fetches(fetch_counter, c.fetches);
+    // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order)
+    if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)
+        fr.tile_cost[slot] = (uint32_t)min(__builtin_amdgcn_s_memtime() - t_start, 0xffffffffull);
 #if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
     for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
 #endif
@@ -887,6 +909,40 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
         if (info) info[pix] = a;
     }
     count_fetches(fetch_counter, c.fetches);
+}
+
+// ------------------------------------------------------------------------------------------------ costliest-first launch order
+// A tile costs between 2 us (provably empty) and 160 us (cloud interior), a launch holds ~4 200 of its 32 400 waves at a time, and
+// the hardware starts workgroups in index order: in the default centre-out order the last expensive tiles start at 60 % of the
+// launch and a third of its duration is a thinning tail (tools/loop_profile.py).  Tile costs repeat from frame to frame
+// (correlation 0.95), so the waves are launched in order of decreasing cost of an earlier frame: a counting sort over 1024
+// cost classes of 512 cycles, one workgroup, order within a class arbitrary -- any permutation gives the same frame.
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[1024];
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0u;
+    __syncthreads();
+    auto key_of = [](uint32_t c) { return 1023u - min(c >> 9, 1023u); };      // descending cost
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[key_of(cost[i])], 1u);
+    __syncthreads();
+    // exclusive prefix sum over the 1024 classes (wave scans + wave totals)
+    const uint32_t v = hist[tid];
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if ((int)(tid & 63u) >= off) incl += t;
+    }
+    __shared__ uint32_t wsum[16];
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) woff += wsum[w];
+    __syncthreads();
+    hist[tid] = woff + incl - v;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024u) order[atomicAdd(&hist[key_of(cost[i])], 1u)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------ empty-space tile mask
@@ -1231,7 +1287,7 @@ __global__ void k_test_rng(float u, float v, float r0, float r1, float r2, float
 // ================================================================================================ launchers
 static dim3 pixel_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(w, 16), ceil_div(h, 16)); }
 // k_gen_rays / k_mc_render: one 8x8 pixel tile per wave, see pixel_of_wave_tile
-static dim3 wave_tile_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(ceil_div(w, 8) * ceil_div(h, 8), CAMERA_WAVES_PER_BLOCK)); }
+static dim3 wave_tile_grid(uint32_t w, uint32_t h) { return dim3(camera_row_blocks(w) * ceil_div(h, 8)); }
 
 void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
@@ -1240,6 +1296,14 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     hipLaunchKernelGGL(k_gen_rays, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
                        fetch_counter, tg, full_vertex_images ? 1 : 0);
+    NRC_HIP(hipGetLastError());
+}
+
+uint32_t camera_slots(uint32_t w, uint32_t h) { return camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK * ceil_div(h, 8); }
+
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order);
     NRC_HIP(hipGetLastError());
 }
 

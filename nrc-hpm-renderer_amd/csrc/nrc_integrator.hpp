@@ -41,6 +41,11 @@ struct DevFrame {
     // one bit per 8x8 pixel tile (index ty * ceil(w/8) + tx), set when a camera ray of the tile can meet a non-empty voxel; the
     // word behind the last tile word is non-zero when the mask must be ignored.  nullptr: no mask (every tile is traced).
     const uint32_t* tile_mask;
+    // launch order of the camera kernels' 8x8 tiles: launch slot (workgroup * 4 + wave) -> default slot (the centre-out order of
+    // pixel_of_wave_tile), costliest first (k_tile_order); nullptr: default order.  tile_cost: cycles each default slot's wave
+    // took in this launch (written by k_gen_rays when non-null)
+    const uint32_t* tile_order;
+    uint32_t* tile_cost;
 };
 
 // forward camera transform for the tile mask: clip = m * (x, y, z, 1), column-major like DevCamera::m
@@ -61,6 +66,9 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 // {lo.xyz, hi.xyz} that together cover every non-empty voxel with a margin of one voxel.  mask: ceil(tiles/32) + 1 words, zeroed.
 void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s);
 uint32_t tile_mask_words(uint32_t w, uint32_t h);
+// launch slots of the camera kernels (rows padded to an odd number of workgroups) and the costliest-first order over them
+uint32_t camera_slots(uint32_t w, uint32_t h);
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, hipStream_t s);
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);

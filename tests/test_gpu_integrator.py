@@ -666,3 +666,55 @@ def test_cli_main_loop_and_benchmark_log(torch_gpu, tmp_path):
     assert img.shape == (80, 128, 4) and np.isfinite(img).all()
     with pytest.raises(SystemExit):
         cli.main(argv[:5])
+
+
+def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc, cloud16, torch_gpu):
+    """the costliest-first launch order of gen_rays' tiles: after the first sort the order is no longer the identity, it is a
+    permutation of all tile slots with the provably empty tiles behind the cloud's, and every frame -- primary pass, queries,
+    train rays, loss, composited image -- is bit-identical to the renderer that launches in the fixed centre-out order"""
+    W, H = 328, 200                       # ragged: 41 x 25 tiles, an odd row of 11 + 1 padding workgroups
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=14)
+    frs = sc.frame_randoms(20, seed=5)
+    out = {}
+    for on in (True, False):
+        nrc = api.NeuralRadianceCache(cfg)
+        ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
+        ren.SetCostOrder(on)
+        ren.SetBlend(True)
+        frames = []
+        for f in range(20):               # sorts after frames 0 and 16, in use from frames 2 and 18
+            ren.SetFrameRandom(frs[f])
+            ren.Render(None, True)
+            if f in (0, 1, 2, 17, 19):
+                frames.append([ren.Buffer(k).cpu().numpy().copy() for k in ("primary", "info", "infer_input", "train_input", "train_target")])
+        order = ren.TileOrder()
+        out[on] = (frames, ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), order, ren.Buffer("info").cpu().numpy().reshape(H, W))
+        ren.Destroy()
+        nrc.Destroy()
+    for fa, fb in zip(out[True][0], out[False][0]):
+        for a, b in zip(fa, fb):
+            assert same_bits(a, b)
+    assert same_bits(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    n = len(out[False][3])
+    assert np.array_equal(out[False][3], np.arange(n, dtype=np.uint32))       # off: never sorted
+    order = out[True][3]
+    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32)) and not np.array_equal(order, np.arange(n, dtype=np.uint32))
+    # slot -> tile (centre-out rows of 4-tile workgroups, rows padded to an odd count); scattering tiles come before empty ones
+    tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+    row_blocks = ((tiles_x + 3) // 4) | 1
+    assert n == row_blocks * 4 * tiles_y
+    info = out[True][4]
+    scat = np.zeros(n, bool)
+    for d in range(n):
+        k, j = divmod(d // 4, row_blocks)
+        tx = j * 4 + d % 4
+        mid = tiles_y // 2
+        ty = mid - (k + 1) // 2 if k & 1 else mid + k // 2
+        if tx < tiles_x:
+            scat[d] = info[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8].mean() > 0.5
+    assert scat.sum() > 20
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    assert rank[scat].mean() < 0.5 * rank[~scat].mean()

@@ -1,0 +1,14 @@
+#!/bin/bash
+# bench frame under a list of environment settings: tools/ab_env.sh <tag> "VAR=1 VAR2=x" "..."   ("-" = no extra environment)
+TAG=$1; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+i=0
+for E in "$@"; do
+  i=$((i+1))
+  [ "$E" = "-" ] && E=""
+  env $E timeout -k 10 200 python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline > $OUT/env_$i.json 2> $OUT/env_$i.err || { tail -5 $OUT/env_$i.err; exit 1; }
+  python3 -c "
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print('%-40s %7.1f Msamples/s frame %.4f' % (sys.argv[2] or '(default)', d['value'], d['ms_per_frame']), {k: round(v,3) for k,v in d['stage_ms'].items()})" $OUT/env_$i.json "$E"
+done
