@@ -366,6 +366,13 @@ __device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, int h, 
     }
 }
 
+// (Measured, tools/infer_micro.hip + profiles/r02_micro_infer_structure.txt: running the two tiles of a wave half a layer apart,
+// so that the ReLU/convert of one tile fills the MFMA gaps of the other -- 4 VALU per 32-cycle MFMA, fragments re-read per
+// tile, sched_barrier after every gap.  The bare layer stream then keeps the MFMA pipes 96 % busy instead of 84 %, but only
+// trivial operands let the chip run it at 2.4 GHz: on random activations it holds 1.63-1.89 GHz, so even that stream tops
+// out at 68 % of the nominal peak (58 % with the encoding's VALU share, against 50 % for this order).  In k_infer itself,
+// where the encoding sits in front of layer 0 instead of being spread over the gaps, the skewed order ran within 1 % of
+// this one at every batch size, so the simpler order stayed.)
 // persistent workgroups; NT 32-sample tiles per wave per iteration; the next iteration's queries are loaded (20 B per
 // sample, straight from HBM/L2 into registers) before the current tiles are computed, so their latency is hidden.
 template <int DEPTH, int THREADS, int NT, int ABL = 0>
@@ -397,6 +404,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
         for (int i = 0; i < 5; i++) x[t][i] = __builtin_nontemporal_load(p + i);
     }
     __syncthreads();
+    unsigned long long r_staged = 0;
+    if constexpr ((ABL & 4) != 0) r_staged = __builtin_amdgcn_s_memrealtime();
     for (; tile < n_tiles; tile += stride) {
         // the weight image in LDS is loop invariant: keep hipcc from hoisting all 54 fragments (216 VGPRs) out of
         // the tile loop -- fragments are meant to be re-read from LDS, one ds_read_b128 per NT MFMAs
@@ -447,9 +456,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
             stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
             stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
             stamps[4 * blockIdx.x + 2] = r0;
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            stamps[4 * blockIdx.x + 3] = xcc;
+            stamps[4 * blockIdx.x + 3] = r_staged - r0;
         }
     }
 }
@@ -1655,7 +1662,7 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
         if (!d_st) NRC_HIP(hipMalloc(&d_st, (size_t)SLOTS * 4 * 2048 * sizeof(unsigned long long)));
         static int count = 0;
         const int slot = count % SLOTS;
-        hipLaunchKernelGGL((k_infer<6, 512, 1, 4>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
+        hipLaunchKernelGGL((k_infer<6, 512, 2, 4>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
         if (++count % 64 == 0) {
             std::vector<unsigned long long> h((size_t)SLOTS * 4 * 2048);
             NRC_HIP(hipStreamSynchronize(s));
@@ -1679,6 +1686,22 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
                 fprintf(stderr, " (%.1f, %.1f)", (double)(span[k].second - span[k].first) / 100.0,
                         (double)(span[k + 1].first - span[k].second) / 100.0);
             fprintf(stderr, "\n");
+            // one launch in detail: when workgroups start, how long the LDS staging takes, when they end (us from the first start)
+            {
+                std::vector<double> st, sg, en;
+                const unsigned long long* base = &h[0];
+                unsigned long long first = ~0ull;
+                for (uint32_t b = 0; b < blocks; b++) first = std::min(first, base[4 * b + 2]);
+                for (uint32_t b = 0; b < blocks; b++) {
+                    st.push_back((double)(base[4 * b + 2] - first) / 100.0);
+                    sg.push_back((double)base[4 * b + 3] / 100.0);
+                    en.push_back((double)(base[4 * b + 2] + base[4 * b + 1] - first) / 100.0);
+                }
+                std::sort(st.begin(), st.end()); std::sort(sg.begin(), sg.end()); std::sort(en.begin(), en.end());
+                auto q = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (double)(v.size() - 1))]; };
+                fprintf(stderr, "[nrc diag] workgroup start us: med %.1f p90 %.1f max %.1f | staging us: min %.1f med %.1f max %.1f | end us: min %.1f p10 %.1f med %.1f p90 %.1f max %.1f\n",
+                        q(st, .5), q(st, .9), q(st, 1), q(sg, 0), q(sg, .5), q(sg, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
+            }
         }
     } else if (abl == 1) hipLaunchKernelGGL((k_infer<6, 512, 1, 1>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);
     else if (abl == 2) hipLaunchKernelGGL((k_infer<6, 512, 1, 2>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img);

@@ -1,0 +1,184 @@
+// Microbenchmark of k_infer's inner structure (nrc_mlp.hip, forward_tiles / forward_tiles_skewed) without the memory side:
+// a persistent wave runs LAYERS hidden 64x64 layers on two 32-sample tiles per iteration, weight fragments from a 54 KB LDS
+// image, ReLU + fp16 convert between the layers, optionally FILL extra VALU instructions per MFMA (the encoding's share).
+//   MODE 0: both tiles in the same layer (16 MFMAs, then 64 ReLU/convert instructions)      -- forward_tiles
+//   MODE 1: tiles half a layer apart, ReLU of one tile in the MFMA gaps of the other           -- forward_tiles_skewed
+//   RELU 0: accumulators are re-used without conversion work (v_mov only where the compiler needs them)
+// Reports the MFMA pipe utilisation at the clock the kernel held (s_memtime / s_memrealtime).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/infer_micro.hip -o tools/_build/infer_micro
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using half8 = _Float16 __attribute__((ext_vector_type(8)));
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using float2v = float __attribute__((ext_vector_type(2)));
+using half2v = _Float16 __attribute__((ext_vector_type(2)));
+using short2v = short __attribute__((ext_vector_type(2)));
+using uint4v = uint32_t __attribute__((ext_vector_type(4)));
+
+constexpr int NFRAG = 54, LAYERS = 6;
+
+__device__ __forceinline__ half8 ld_frag(const uint4* lw, int frag, int lane)
+{
+    uint4 v = lw[frag * 64 + lane];
+    return __builtin_bit_cast(half8, v);
+}
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+template <int RELU>
+__device__ __forceinline__ uint32_t relu_pk(float a, float b)
+{
+    if constexpr (RELU == 0) {
+        return __builtin_bit_cast(uint32_t, a) ^ (__builtin_bit_cast(uint32_t, b) & 0u);
+    } else {
+        float2v f = {a, b};
+        half2v h = __builtin_convertvector(f, half2v);
+        short2v s = __builtin_bit_cast(short2v, h);
+        short2v z = {0, 0};
+        s = __builtin_elementwise_max(s, z);
+        return __builtin_bit_cast(uint32_t, s);
+    }
+}
+template <int RELU>
+__device__ __forceinline__ void relu_pair(const f32x16 (&acc)[2], uint4v (&b)[4], int q)
+{
+    const int m = q >> 3, e = q & 7;
+    b[q >> 2][q & 3] = relu_pk<RELU>(acc[m][2 * e], acc[m][2 * e + 1]);
+}
+template <int FILL>
+__device__ __forceinline__ void filler(float (&f)[4])
+{
+#pragma unroll
+    for (int i = 0; i < FILL; i++) f[i & 3] = __builtin_fmaf(f[i & 3], 1.0001f, 0.25f);
+}
+
+template <int MODE, int RELU, int FILL, int WPS>
+__global__ __launch_bounds__(512, WPS) void k(float* out, int iters, unsigned long long* clk, int trivial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* lw = (uint4*)smem;
+    // TRIVIAL 0: He-initialised random weights (uniform +-0.3: variance 2/64, activations keep their scale through ReLU layers);
+    // TRIVIAL 1: a few fixed bit patterns, activations die out -- the operands the chip holds its full clock on
+    for (int i = threadIdx.x; i < NFRAG * 64; i += blockDim.x) {
+        if (trivial) { lw[i] = make_uint4(0x2c002c00u + (i & 0xff), 0xa8002c00u, 0x2c00a800u + 7 * (i & 0xff), 0x24002c00u); continue; }
+        uint32_t w[4];
+        for (int c = 0; c < 4; c++) {
+            uint32_t hsh = (uint32_t)(i * 4 + c) * 2654435761u;
+            hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+            const float lo = ((float)(hsh & 0xffffu) / 65535.0f - 0.5f) * 0.6f, hi = ((float)(hsh >> 16) / 65535.0f - 0.5f) * 0.6f;
+            half2v pk = {(_Float16)lo, (_Float16)hi};
+            w[c] = __builtin_bit_cast(uint32_t, pk);
+        }
+        lw[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[2][2];
+    uint4v b[2][4];
+    float f[4] = {0.1f * lane, 0.2f, 0.3f, 0.4f};
+    for (int t = 0; t < 2; t++)
+        for (int s = 0; s < 4; s++) b[t][s] = uint4v{0x3c003c00u + lane, 0x38003c00u, 0x3c003800u, 0x34003c00u + t};
+    for (int t = 0; t < 2; t++) for (int m = 0; m < 2; m++) acc[t][m] = zero16();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+        asm volatile("" ::: "memory");
+        if (!trivial) {       // fresh inputs every iteration (k_infer encodes new queries here): |x| <= 0.3 from the weight image
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) { const uint4 v = lw[((it + 4 * t + s) % NFRAG) * 64 + lane]; b[t][s] = uint4v{v.x & 0x7fff7fffu, v.y, v.z & 0x7fff7fffu, v.w}; }
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int l = 0; l < LAYERS; l++) {
+                const int base = 8 * l;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const half8 a0 = ld_frag(lw, base + s, lane), a1 = ld_frag(lw, base + 4 + s, lane);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        acc[t][0] = mfma(a0, __builtin_bit_cast(half8, b[t][s]), s == 0 ? zero16() : acc[t][0]);
+                        acc[t][1] = mfma(a1, __builtin_bit_cast(half8, b[t][s]), s == 0 ? zero16() : acc[t][1]);
+                        filler<2 * FILL>(f);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) relu_pair<RELU>(acc[t], b[t], q);
+            }
+        } else {
+            half8 fa[3];
+            fa[0] = ld_frag(lw, 0, lane);
+            fa[1] = ld_frag(lw, 4, lane);
+#pragma unroll
+            for (int l = 0; l < LAYERS; l++) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = (l * 2 + t) * 8 + k, s = k >> 1, m = k & 1;
+                        const int j = i + 2, lj = (j / 16) % LAYERS, kj = j % 8;
+                        fa[j % 3] = ld_frag(lw, 8 * lj + (kj & 1) * 4 + (kj >> 1), lane);
+                        acc[t][m] = mfma(fa[i % 3], __builtin_bit_cast(half8, b[t][s]), s == 0 ? zero16() : acc[t][m]);
+                        relu_pair<RELU>(acc[t ^ 1], b[t ^ 1], 2 * k);
+                        relu_pair<RELU>(acc[t ^ 1], b[t ^ 1], 2 * k + 1);
+                        filler<FILL>(f);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = f[0] + f[1] + f[2] + f[3];
+    for (int t = 0; t < 2; t++) for (int m = 0; m < 2; m++) for (int e = 0; e < 16; e++) s += acc[t][m][e];
+    for (int t = 0; t < 2; t++) for (int q = 0; q < 4; q++) s += (float)(b[t][q][0] & 0xffu);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int MODE, int RELU, int FILL, int WPS>
+void run(const char* name, int blocks_per_cu, int iters, int trivial)
+{
+    const int threads = 512, blocks = 256 * blocks_per_cu;
+    float* out; unsigned long long* clk;
+    hipMalloc(&out, (size_t)blocks * threads * 4); hipMalloc(&clk, blocks * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto kern = k<MODE, RELU, FILL, WPS>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG * 1024);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), NFRAG * 1024, 0, out, iters, clk, trivial);
+    hipEventRecord(e0);
+    for (int w = 0; w < 5; w++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), NFRAG * 1024, 0, out, iters, clk, trivial);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    std::vector<unsigned long long> h(2 * blocks); hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost);
+    const double mhz = (double)h[0] / (double)h[1] * 100.0;
+    const double n_mfma = (double)blocks * (threads / 64) * iters * LAYERS * 16.0;
+    const double flop = n_mfma * 32768.0;
+    const double util = n_mfma * 32.0 / (1024.0 * ms * 1e-3 * mhz * 1e6);
+    printf("%-8s %-44s waves/SIMD %d: %.3f ms  %6.0f TFLOP/s  clock %4.0f MHz  MFMA pipe %.1f%% busy  (%.1f%% of 2.5 PF)\n", trivial ? "trivial" : "random", name,
+           2 * blocks_per_cu, ms, flop / ms / 1e9, mhz, util * 100.0, flop / ms / 1e9 / 25.0);
+    hipFree(out); hipFree(clk);
+}
+
+int main()
+{
+    const int it = 3000;
+    for (int trivial = 1; trivial >= 0; trivial--) {
+        run<0, 1, 0, 1>("same-layer tiles, relu", 1, it, trivial);
+        run<1, 1, 0, 1>("skewed tiles, relu", 1, it, trivial);
+        run<1, 1, 0, 4>("skewed tiles, relu", 2, it, trivial);
+        run<0, 1, 3, 1>("same-layer tiles, relu, 3 VALU fill/MFMA", 1, it, trivial);
+        run<1, 1, 3, 1>("skewed tiles, relu, 3 VALU fill/MFMA", 1, it, trivial);
+        run<1, 1, 3, 4>("skewed tiles, relu, 3 VALU fill/MFMA", 2, it, trivial);
+    }
+    return 0;
+}
