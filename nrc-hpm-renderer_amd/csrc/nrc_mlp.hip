@@ -220,6 +220,18 @@ __device__ __forceinline__ half8 encode80_frag(const float (&x)[5], int h)
     return b;
 }
 
+// the same, s a constant after unrolling
+__device__ __forceinline__ half8 encode80_step(const float (&x)[5], int h, int s)
+{
+    switch (s) {
+    case 0: return encode80_frag<0>(x, h);
+    case 1: return encode80_frag<1>(x, h);
+    case 2: return encode80_frag<2>(x, h);
+    case 3: return encode80_frag<3>(x, h);
+    default: return encode80_frag<4>(x, h);
+    }
+}
+
 // fragment bases inside the forward image
 constexpr int FRAG_L0 = 0;                       // [mt][s]      MT*KS0
 constexpr int FRAG_HID = MT * KS0;               // [l-1][mt][s] (depth-1)*MT*KSH
@@ -461,6 +473,31 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ k-group stores
+// Activations and deltas go to HBM as [sample/8][row][8 samples] fp16 ("k-groups": the 16 bytes one lane of the weight-gradient
+// MFMA loads).  A lane of the forward chain holds the transposed piece -- ONE sample, 8 rows in a half8 -- and used to write it
+// with eight 2-byte stores (1 600 scattered short stores and loads per tile of an 8x128 net: the memory pipeline, not the MFMAs,
+// set the kernels' time).  Now the wave turns each 16-row x 32-sample block through 1.25 KB of its own LDS (8 ds_write_b16, one
+// ds_read_b128 per lane; rows padded to 40 halves so that the two lane halves hit different banks) and stores 16 bytes per lane.
+// PERM: the half8's rows are 8(j>>2) + 4h + (j&3) (an accumulator pair re-used as operand, kperm), else 8h + j (natural order).
+constexpr int KG_ROW = 40;                          // halves per scratch row
+constexpr int KG_SCRATCH = 16 * KG_ROW * 2;         // bytes per wave
+template <bool PERM>
+__device__ __forceinline__ void store_kgroups(half_t* scratch, const half8& v, int lane, half_t* dst_row0, uint32_t rows)
+{
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int rho = PERM ? 8 * (j >> 2) + 4 * h + (j & 3) : 8 * h + j;
+        scratch[rho * KG_ROW + r] = v[j];
+    }
+    __builtin_amdgcn_wave_barrier();                 // same wave, LDS executes in order: only the compiler must not reorder
+    const half8 t = *reinterpret_cast<const half8*>(scratch + (lane >> 2) * KG_ROW + 8 * (lane & 3));
+    __builtin_amdgcn_wave_barrier();
+    // lane -> row lane >> 2 of the block, sample group lane & 3 of the tile
+    *reinterpret_cast<half8*>(dst_row0 + ((size_t)(lane & 3) * rows + (size_t)(lane >> 2)) * 8) = t;
+}
+
 // ------------------------------------------------------------------------------------------------ training: fwd + loss + dgrad
 // tiny-cuda-nn's element-wise losses (the reference passes the name through, src/NeuralRadianceCache.cu:17-19):
 // per element value / n_total and dL/dy * loss_scale / n_total, n_total = 3 * (global) batch.
@@ -536,7 +573,9 @@ __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const ui
         f32x16 y = forward_tile<DEPTH, true>(lw, lane, st);
 
         // ---- activations -> HBM in [sample/8][row][8] order: the 16-byte k-groups the weight-gradient GEMM reads;
-        //      row offsets are compile-time immediates on two per-lane bases (+8h / +4h rows)
+        //      row offsets are compile-time immediates on two per-lane bases (+8h / +4h rows).  (The generic kernel's LDS
+        //      transposition, store_kgroups, makes this kernel faster alone -- 24 instead of 31 us -- but 1-3 % slower inside
+        //      the frame, where its wait chains stretch beside gen_rays; these fire-and-forget 2-byte stores stayed.)
         constexpr int ROWS_A = ENC + DEPTH * WIDTH;
         constexpr int ROWS_D = DEPTH * WIDTH + 8;
         half_t* const pa = a.acts + ((size_t)(sidx >> 3) * ROWS_A) * 8 + (sidx & 7u);
@@ -912,10 +951,15 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 // barrier per layer, no staging registers, 0.5-1 KB of L2 traffic per sample.  Same accumulator-as-
 // operand chain and numerics as k_infer.  skip_in (renderer inference): tiles whose 32 queries are all zero are not computed,
 // a workgroup whose 256 queries are all zero does not even stream the weights.
-template <int WIDTH, int THREADS, bool FEAT_LM, int NT = 2>
-__global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
+#ifndef NRC_GEN128_WPS
+#define NRC_GEN128_WPS 1
+#endif
+// ENC80: the input is the raw 5-float query and the Frequency(12) + OneBlob(4) encoding is computed here, k-step by k-step, as
+// k_infer does (no k_encode pass, no 160 B/sample feature buffer); feat is unused, raw_in required, the image is in fmap80 order.
+template <int WIDTH, int THREADS, bool FEAT_LM, int NT = 2, bool ENC80 = false>
+__global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                       const uint4* __restrict__ img, int depth, int ks0,
-                                                      const float* __restrict__ skip_in)
+                                                      const float* __restrict__ skip_in, const float* __restrict__ raw_in = nullptr)
 {
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = THREADS / 64;
     constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);        // largest stage (layer 0 has ks0 <= 5 k-steps)
@@ -930,23 +974,66 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
     // stage st: layer-0 fragments | hidden layer st | output fragments; first fragment and size (in uint4) in the image
 #define NRC_STAGE_FIRST(st) ((st) == 0 ? 0 : hid_base + ((st) - 1) * MTG * KSG)
 #define NRC_STAGE_COUNT(st) (((st) == 0 ? MTG * ks0 : ((st) == depth ? KSG : MTG * KSG)) * 64)
-    // async global -> LDS copy of one stage (global_load_lds_dwordx4: a wave writes 64 x 16 B contiguously = one fragment, which
-    // is exactly the image layout); completion is awaited by the __syncthreads() that ends the current stage
-#define NRC_STAGE_IN(st, buf)                                                                \
+    // Stage prefetch through registers: the global loads of stage st+1 are issued at the top of stage st (PF x 16 B per thread),
+    // their data is written to the other LDS buffer at the bottom, in front of the barrier.  (The direct global->LDS loads used
+    // before -- global_load_lds_dwordx4, no staging registers -- did not overlap anything: the compiler cannot tell which LDS
+    // buffer an LDS-DMA writes and put s_waitcnt vmcnt(0) in front of the first ds_read of the CURRENT stage, so every layer paid
+    // the L2 latency of the next one: 4 700 cycles per layer instead of the 2 048 its MFMAs need.)
+    uint4v pf[PF];
+#define NRC_STAGE_FETCH(st)                                                                  \
     do {                                                                                     \
         const uint4* src_ = img + (size_t)NRC_STAGE_FIRST(st) * 64;                          \
+        const int cnt_ = NRC_STAGE_COUNT(st);                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < PF; k_++) {                                  \
+            const int i_ = k_ * THREADS + (int)threadIdx.x;                                  \
+            if (i_ < cnt_) pf[k_] = reinterpret_cast<const uint4v*>(src_)[i_];                  \
+        }                                                                                    \
+    } while (0)
+#define NRC_STAGE_COMMIT(st, buf)                                                            \
+    do {                                                                                     \
         uint4* dst_ = lds_w + (buf) * (STAGE_FRAGS * 64);                                    \
         const int cnt_ = NRC_STAGE_COUNT(st);                                                \
         _Pragma("unroll") for (int k_ = 0; k_ < PF; k_++) {                                  \
             const int i_ = k_ * THREADS + (int)threadIdx.x;                                  \
-            if (i_ < cnt_)                                                                   \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + i_),       \
-                                                 (__attribute__((address_space(3))) void*)(dst_ + i_), 16, 0, 0); \
+            if (i_ < cnt_) reinterpret_cast<uint4v*>(dst_)[i_] = pf[k_];                        \
         }                                                                                    \
     } while (0)
 
+    // layer-0 operands (the encoded features of this wave's samples, ks0 <= 5 k-steps): all loaded at the top of the group --
+    // fetched inside the k-loop, each of the five load -> MFMA rounds exposed a full memory latency, a quarter of a group's time
+    half8 f0[NT][5];
+    auto load_features = [&](uint32_t g) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint32_t sx = ((g * WAVES + (uint32_t)wave) * NT + (uint32_t)t) * 32u + (uint32_t)r;
+            const size_t si = sx < n ? sx : n - 1u;
+            if constexpr (ENC80) {
+                const float* qv = raw_in + si * 5u;
+                const float x[5] = {qv[0], qv[1], qv[2], qv[3], qv[4]};
+#pragma unroll
+                for (int k = 0; k < 5; k++) f0[t][k] = encode80_step(x, h, k);
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int kc = k < ks0 ? k : ks0 - 1;      // k-steps beyond ks0: load the last one again, use zeros -- no branches
+                if (FEAT_LM) {           // [slot][n] half2 (k_encode_hash_lm): features 16k+8h+2i, +1 = slot 8k+4h+i
+                    const uint32_t* fl = reinterpret_cast<const uint32_t*>(feat) + (size_t)(8 * kc + 4 * h) * n + si;
+                    uint4v v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = fl[(size_t)i * n];
+                    f0[t][k] = __builtin_bit_cast(half8, v);
+                } else {
+                    f0[t][k] = *reinterpret_cast<const half8*>(feat + si * e16 + 8 * h + 16 * kc);
+                }
+                if (k >= ks0) f0[t][k] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+
     int q = 0;                       // stage counter: stage data lives in buffer q & 1
-    NRC_STAGE_IN(0, 0);
+    NRC_STAGE_FETCH(0);
+    NRC_STAGE_COMMIT(0, 0);
     __syncthreads();
     for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
         uint32_t sidx[NT];
@@ -968,56 +1055,78 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
 #pragma unroll
         for (int t = 0; t < NT; t++) wave_runs |= run[t];
         if (__syncthreads_or(wave_runs ? 1 : 0) == 0) continue;       // nothing to do for this group: stage 0 stays staged
+        if (wave_runs) load_features(group);
 
-        f32x16 acc[NT][MTG];
-        half8 b[NT][KSG];
+        half8 b[NT][KSG];                 // the only state carried from stage to stage
 #pragma unroll 1
         for (int st = 0; st <= depth; st++) {
             const uint4* lw = lds_w + (q & 1) * (STAGE_FRAGS * 64);
             const bool last = st == depth;
             const bool more = !last || group + gridDim.x < n_groups;       // next stage to stream (stage 0 of the next group)
             const int next = last ? 0 : st + 1;
-            if (more) NRC_STAGE_IN(next, (q + 1) & 1);
+            if (more) NRC_STAGE_FETCH(next);
             if (wave_runs) {
                 if (st == 0) {
+                    f32x16 acc[NT][MTG];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {      // always five k-steps: beyond ks0 the operand is zero (and the fragment a repeat)
+#pragma unroll
+                        for (int m = 0; m < MTG; m++) {
+                            const half8 a = ld_frag(lw, m * ks0 + (k < ks0 ? k : ks0 - 1), lane);
+#pragma unroll
+                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, f0[t][k], k == 0 ? zero16() : acc[t][m]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // one k-step's fragments in flight, not all five
+                    }
 #pragma unroll
                     for (int t = 0; t < NT; t++)
 #pragma unroll
-                        for (int m = 0; m < MTG; m++) acc[t][m] = zero16();
-#pragma unroll 1
-                    for (int k = 0; k < ks0; k++) {
-                        half8 b0[NT];
+                        for (int m = 0; m < MTG; m++) relu_pack(acc[t][m], b[t][2 * m], b[t][2 * m + 1]);
+                } else if (!last) {
+                    if constexpr (WIDTH == 128) {
+                        // one 32-row block at a time, converted as soon as the next block's MFMAs are issued: two accumulators
+                        // live instead of four (the four-block form needed 167 VGPRs and spilled under a 128-register cap, so a
+                        // workgroup only fitted on a CU that gen_rays had all but left)
+                        half8 bn[NT][KSG];
+                        f32x16 acc[NT][2];
 #pragma unroll
-                        for (int t = 0; t < NT; t++) {
-                            const size_t si = valid[t] ? sidx[t] : n - 1u;
-                            if (FEAT_LM) {       // [slot][n] half2 (k_encode_hash_lm): features 16k+8h+2i, +1 = slot 8k+4h+i
-                                const uint32_t* fl = reinterpret_cast<const uint32_t*>(feat) + (size_t)(8 * k + 4 * h) * n + si;
-                                uint4v v;
+                        for (int m = 0; m <= MTG; m++) {
+                            if (m < MTG) {
 #pragma unroll
-                                for (int i = 0; i < 4; i++) v[i] = fl[(size_t)i * n];
-                                b0[t] = __builtin_bit_cast(half8, v);
-                            } else {
-                                b0[t] = *reinterpret_cast<const half8*>(feat + si * e16 + 8 * h + 16 * k);
+                                for (int k = 0; k < KSG; k++) {
+                                    const half8 a = ld_frag(lw, m * KSG + k, lane);
+#pragma unroll
+                                    for (int t = 0; t < NT; t++) acc[t][m & 1] = mfma(a, b[t][k], k == 0 ? zero16() : acc[t][m & 1]);
+                                    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most four fragments in flight
+                                }
+                            }
+                            if (m > 0) {
+#pragma unroll
+                                for (int t = 0; t < NT; t++) relu_pack(acc[t][(m - 1) & 1], bn[t][2 * (m - 1)], bn[t][2 * (m - 1) + 1]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+#pragma unroll
+                            for (int k = 0; k < KSG; k++) b[t][k] = bn[t][k];
+                    } else {
+                        f32x16 acc[NT][MTG];
+#pragma unroll
+                        for (int m = 0; m < MTG; m++) {
+#pragma unroll
+                            for (int t = 0; t < NT; t++) acc[t][m] = zero16();
+#pragma unroll
+                            for (int k = 0; k < KSG; k++) {
+                                const half8 a = ld_frag(lw, m * KSG + k, lane);
+#pragma unroll
+                                for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, b[t][k], acc[t][m]);
                             }
                         }
 #pragma unroll
-                        for (int m = 0; m < MTG; m++) {
-                            const half8 a = ld_frag(lw, m * ks0 + k, lane);
+                        for (int t = 0; t < NT; t++)
 #pragma unroll
-                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, b0[t], acc[t][m]);
-                        }
-                    }
-                } else if (!last) {
-#pragma unroll
-                    for (int m = 0; m < MTG; m++) {
-#pragma unroll
-                        for (int t = 0; t < NT; t++) acc[t][m] = zero16();
-#pragma unroll
-                        for (int k = 0; k < KSG; k++) {
-                            const half8 a = ld_frag(lw, m * KSG + k, lane);
-#pragma unroll
-                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, b[t][k], acc[t][m]);
-                        }
+                            for (int m = 0; m < MTG; m++) relu_pack(acc[t][m], b[t][2 * m], b[t][2 * m + 1]);
                     }
                 } else {
                     f32x16 y[NT];
@@ -1039,20 +1148,16 @@ __global__ __launch_bounds__(THREADS) void k_infer_gen(const half_t* __restrict_
                         }
                     }
                 }
-                if (!last) {
-#pragma unroll
-                    for (int t = 0; t < NT; t++)
-#pragma unroll
-                        for (int m = 0; m < MTG; m++) relu_pack(acc[t][m], b[t][2 * m], b[t][2 * m + 1]);
-                }
             }
+            if (more) NRC_STAGE_COMMIT(next, (q + 1) & 1);
             __syncthreads();
             q++;
         }
     }
 #undef NRC_STAGE_FIRST
 #undef NRC_STAGE_COUNT
-#undef NRC_STAGE_IN
+#undef NRC_STAGE_FETCH
+#undef NRC_STAGE_COMMIT
 }
 
 struct TrainArgsGen {
@@ -1068,118 +1173,210 @@ struct TrainArgsGen {
     half_t* d_enc;        // [n][32] dL/d(first 32 encoded dims) for a trainable encoding (HashGrid), or nullptr
 };
 
-template <int WIDTH>
-__global__ __launch_bounds__(256) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
-                                                  const uint4* __restrict__ img_bwd)
+// Generic training forward + loss + dgrad (any encoding, width 32 / 64 / 128, any depth).  Like k_infer_gen the workgroup streams the
+// weight images through LDS one layer at a time -- the forward image front to back, then the transposed (W^T) image back to
+// front -- with the next stage arriving by direct global->LDS loads while the current one feeds the MFMAs: every fragment is
+// fetched from L2 once per workgroup (WAVES tiles) instead of once per tile (a wave used to pull all 500 KB of an 8x128 net's
+// two images through its own dependent loads: 284 us for a 16 384-ray batch beside gen_rays).  One tile per wave; activations and
+// deltas leave for HBM in the k-group layout the weight-gradient GEMM reads, as before.
+//   stages: 0 layer 0 | 1..depth-1 hidden layers | depth output layer | depth+1 output layer^T | depth+1+j hidden layer^T
+//   l = depth-j (j = 1..depth-1) | 2*depth+1 layer 0^T rows of a trainable encoding
+template <int WIDTH, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
+                                                         const uint4* __restrict__ img_bwd)
 {
-    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16;
+    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, THREADS = WAVES * 64;
+    constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);
+    constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;
+    extern __shared__ uint4 lds_w[];                              // [2][STAGE_FRAGS * 64] | k-group scratch per wave | ReLU masks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int depth = a.depth, ks0 = a.ks0;
     const uint32_t e16 = (uint32_t)ks0 * 16u;
     const uint32_t rows_a = e16 + (uint32_t)depth * WIDTH, rows_d = (uint32_t)depth * WIDTH + 8u;
     const uint32_t n_tiles = a.n >> 5;
+    const uint32_t n_groups = (n_tiles + WAVES - 1u) / WAVES;
+    half_t* const kg = reinterpret_cast<half_t*>(lds_w + 2 * STAGE_FRAGS * 64) + wave * (KG_SCRATCH / 2);
+    // ReLU masks of every layer's output (1 bit per value, KSG * 8 values per lane and layer), kept for the dgrad chain
+    uint2* const masks = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds_w + 2 * STAGE_FRAGS * 64) + WAVES * KG_SCRATCH) +
+                         (size_t)wave * depth * 64 + lane;
+    constexpr int MASK_BITS = KSG * 4 >= 16 ? 16 : KSG * 4;       // operand dwords folded into one mask word (two values each)
     const int hid_base = MTG * ks0;
-    const uint32_t wpb = blockDim.x >> 6;       // 1 or 4 waves per workgroup (the host picks: small batches spread over every CU)
-    for (uint32_t tile = blockIdx.x * wpb + wave; tile < n_tiles; tile += gridDim.x * wpb) {
-        const uint32_t sidx = tile * 32u + r;
-        const half_t* fp = a.feat + (size_t)sidx * e16 + 8 * h;
-        half_t* const pa = a.acts + ((size_t)(sidx >> 3) * rows_a) * 8 + (sidx & 7u);
+    const int n_stages = 2 * depth + 1 + (a.d_enc != nullptr ? 1 : 0);
+    // stage st of the images: source and size in uint4; prefetched through registers (see k_infer_gen): loaded at the top of the
+    // stage before, written to the other LDS buffer at its bottom
+    uint4v pf[PF];
+    auto stage_src = [&](int st, const uint4*& src, int& cnt) {
+        if (st <= depth) {
+            src = img_fwd + (size_t)(st == 0 ? 0 : hid_base + (st - 1) * MTG * KSG) * 64;
+            cnt = (st == 0 ? MTG * ks0 : (st == depth ? KSG : MTG * KSG)) * 64;
+        } else {
+            const int j = st - depth - 1;
+            if (j == 0) { src = img_bwd + (size_t)((depth - 1) * MTG * KSG) * 64; cnt = MTG * 64; }
+            else if (j < depth) { src = img_bwd + (size_t)((depth - j - 1) * MTG * KSG) * 64; cnt = MTG * KSG * 64; }
+            else { src = img_bwd + (size_t)((depth - 1) * MTG * KSG + MTG) * 64; cnt = KSG * 64; }
+        }
+    };
+    auto stage_fetch = [&](int st) {
+        const uint4* src;
+        int cnt;
+        stage_src(st, src, cnt);
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int i = k * THREADS + (int)threadIdx.x;
+            if (i < cnt) pf[k] = reinterpret_cast<const uint4v*>(src)[i];
+        }
+    };
+    auto stage_commit = [&](int st, int buf) {
+        const uint4* src;
+        int cnt;
+        stage_src(st, src, cnt);
+        uint4* dst = lds_w + buf * (STAGE_FRAGS * 64);
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int i = k * THREADS + (int)threadIdx.x;
+            if (i < cnt) reinterpret_cast<uint4v*>(dst)[i] = pf[k];
+        }
+    };
+
+    // layer-0 operands (encoded features, ks0 <= 5 k-steps) of this wave's tile, all loaded at the top of the group (see k_infer_gen)
+    half8 f0[5];
+    auto load_features = [&](uint32_t g) {
+        const uint32_t tl = g * WAVES + (uint32_t)wave;
+        const half_t* fq = a.feat + (size_t)((tl < n_tiles ? tl : 0u) * 32u + (uint32_t)r) * e16 + 8 * h;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {      // k-steps beyond ks0: load the last one again, use zeros -- no branches
+            f0[k] = *reinterpret_cast<const half8*>(fq + 16 * (k < ks0 ? k : ks0 - 1));
+            if (k >= ks0) f0[k] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+
+    int q = 0;
+    stage_fetch(0);
+    stage_commit(0, 0);
+    __syncthreads();
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        const uint32_t tile = group * WAVES + (uint32_t)wave;
+        const bool active = tile < n_tiles;                         // wave-uniform; idle waves still stage and meet the barriers
+        if (active) load_features(group);
+        const uint32_t sidx = (active ? tile : 0u) * 32u + (uint32_t)r;
+        half_t* const ta = a.acts + (size_t)(active ? tile : 0u) * 4u * rows_a * 8;        // this tile's four sample groups, row 0
+        half_t* const td = a.deltas + (size_t)(active ? tile : 0u) * 4u * rows_d * 8;
         half_t* const pd = a.deltas + ((size_t)(sidx >> 3) * rows_d) * 8 + (sidx & 7u);
-        half_t* const pa4 = pa + 32 * h;       // rows + 4h
-        half_t* const pd4 = pd + 32 * h;
-        // ---- forward; every layer's input goes to HBM in the k-group layout the weight-gradient GEMM reads
-        f32x16 acc[MTG];
-#pragma unroll
-        for (int m = 0; m < MTG; m++) acc[m] = zero16();
-        for (int s = 0; s < ks0; s++) {
-            const half8 b0 = *reinterpret_cast<const half8*>(fp + 16 * s);
-#pragma unroll
-            for (int j = 0; j < 8; j++) pa[(size_t)(16 * s + 8 * h + j) * 8] = b0[j];
-#pragma unroll
-            for (int m = 0; m < MTG; m++) acc[m] = mfma(ld_frag_g(img_fwd, m * ks0 + s, lane), b0, acc[m]);
-        }
-        half8 b[KSG];
-#pragma unroll
-        for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
-        for (int l = 0;; l++) {
-            half_t* const pl = pa4 + (size_t)(e16 + (uint32_t)l * WIDTH) * 8;
-#pragma unroll
-            for (int s = 0; s < KSG; s++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) pl[kperm(s, 0, j) * 8] = b[s][j];
-            if (l + 1 >= depth) break;
-            const int base = hid_base + l * MTG * KSG;
-#pragma unroll
-            for (int m = 0; m < MTG; m++) {
-                acc[m] = zero16();
-#pragma unroll
-                for (int s = 0; s < KSG; s++) acc[m] = mfma(ld_frag_g(img_fwd, base + m * KSG + s, lane), b[s], acc[m]);
-            }
-#pragma unroll
-            for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
-        }
-        f32x16 y = zero16();
-        const int obase = hid_base + (depth - 1) * MTG * KSG;
-#pragma unroll
-        for (int s = 0; s < KSG; s++) y = mfma(ld_frag_g(img_fwd, obase + s, lane), b[s], y);
-
-        // ---- loss + dL/dy
-        float loss_v = 0.0f;
+        f32x16 acc[MTG];                       // forward accumulators, then the dgrad accumulators
+        half8 b[KSG];                          // forward operands, then the deltas
         half8 bo;
+#pragma unroll 1
+        for (int st = 0; st < n_stages; st++) {
+            const uint4* lw = lds_w + (q & 1) * (STAGE_FRAGS * 64);
+            const bool last = st == n_stages - 1;
+            const bool more = !last || group + gridDim.x < n_groups;
+            const int next = last ? 0 : st + 1;
+            if (more) stage_fetch(next);
+            if (active) {
+                if (st < depth) {
+                    // ---- forward layer st; every layer's input goes to HBM in the k-group layout the weight-gradient GEMM reads
 #pragma unroll
-        for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
-        if (h == 0) {
-            const float* t = a.target + (size_t)sidx * 3u;
-            const float yv[3] = {y[0], y[1], y[2]};
-            float dy[3];
-            loss_terms(a.loss_id, yv, t, a.inv_n_total, loss_v, dy);
+                    for (int m = 0; m < MTG; m++) acc[m] = zero16();
+                    if (st == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                bo[c] = (half_t)dy[c];
-                pd[(size_t)((uint32_t)depth * WIDTH + c) * 8] = bo[c];
-            }
-        }
+                        for (int s = 0; s < 5; s++) {      // always five k-steps: beyond ks0 the operand is zero
+                            if (s < ks0) store_kgroups<false>(kg, f0[s], lane, ta + (size_t)(16 * s) * 8, rows_a);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
-        if (lane == 0) a.loss_part[tile] = loss_v;
-
-        // ---- dgrad chain; the ReLU mask is re-read from this lane's own activation stores
-        const int bout = (depth - 1) * MTG * KSG;
-        f32x16 d[MTG];
+                            for (int m = 0; m < MTG; m++) acc[m] = mfma(ld_frag(lw, m * ks0 + (s < ks0 ? s : ks0 - 1), lane), f0[s], acc[m]);
+                            __builtin_amdgcn_sched_barrier(0);      // one k-step's fragments in flight, not all five
+                        }
+                    } else {
 #pragma unroll
-        for (int m = 0; m < MTG; m++) d[m] = mfma(ld_frag_g(img_bwd, bout + m, lane), bo, zero16());
-        for (int l = depth - 1; l >= 0; l--) {
-            const half_t* const pl = pa4 + (size_t)(e16 + (uint32_t)l * WIDTH) * 8;
-            half_t* const pdl = pd4 + (size_t)((uint32_t)l * WIDTH) * 8;
-            half8 dl[KSG];
+                        for (int m = 0; m < MTG; m++)
 #pragma unroll
-            for (int s = 0; s < KSG; s++)
+                            for (int s = 0; s < KSG; s++) acc[m] = mfma(ld_frag(lw, m * KSG + s, lane), b[s], acc[m]);
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const half_t act = pl[kperm(s, 0, j) * 8];
-                    const half_t v = (act > (half_t)0.0f) ? (half_t)d[s >> 1][8 * (s & 1) + j] : (half_t)0.0f;
-                    dl[s][j] = v;
-                    pdl[kperm(s, 0, j) * 8] = v;
+                    for (int m = 0; m < MTG; m++) relu_pack(acc[m], b[2 * m], b[2 * m + 1]);
+                    half_t* const tl = ta + (size_t)(e16 + (uint32_t)st * WIDTH) * 8;
+                    uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+                    for (int s = 0; s < KSG; s++) {
+                        store_kgroups<true>(kg, b[s], lane, tl + (size_t)(16 * s) * 8, rows_a);
+                        const uint4v w = __builtin_bit_cast(uint4v, b[s]);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {      // ReLU output > 0 <=> its fp16 bits are non-zero
+                            // (plain integer tests: hipcc 7.2 folded a packed min(bits, 1) over the four dwords into ONE dword's result)
+                            const uint32_t wi = w[i];
+                            const uint32_t nz = ((wi & 0x0000ffffu) != 0u ? 1u : 0u) | ((wi & 0xffff0000u) != 0u ? 0x10000u : 0u);
+                            const int k = 4 * s + i;
+                            mk[k >> 4] = (mk[k >> 4] << 1) | nz;
+                        }
+                    }
+                    masks[(size_t)st * 64] = make_uint2(mk[0], mk[1]);
+                } else if (st == depth) {
+                    // ---- output layer, loss, dL/dy
+                    f32x16 y = zero16();
+#pragma unroll
+                    for (int s = 0; s < KSG; s++) y = mfma(ld_frag(lw, s, lane), b[s], y);
+                    float loss_v = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
+                    if (h == 0) {
+                        const float* t = a.target + (size_t)sidx * 3u;
+                        const float yv[3] = {y[0], y[1], y[2]};
+                        float dy[3];
+                        loss_terms(a.loss_id, yv, t, a.inv_n_total, loss_v, dy);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            bo[c] = (half_t)dy[c];
+                            pd[(size_t)((uint32_t)depth * WIDTH + c) * 8] = bo[c];
+                        }
+                    }
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
+                    if (lane == 0) a.loss_part[tile] = loss_v;
+                } else if (st <= 2 * depth) {
+                    // ---- dgrad: W_{l+1}^T delta_{l+1} (the output layer's W^T first), then delta_l = relu'(a_l) * that; the ReLU
+                    //      mask is re-read from this lane's own activation stores
+                    const int l = 2 * depth - st;      // the layer whose delta this stage produces: depth-1 ... 0
+                    if (st == depth + 1) {
+#pragma unroll
+                        for (int m = 0; m < MTG; m++) acc[m] = mfma(ld_frag(lw, m, lane), bo, zero16());
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MTG; m++) {
+                            acc[m] = zero16();
+#pragma unroll
+                            for (int s = 0; s < KSG; s++) acc[m] = mfma(ld_frag(lw, m * KSG + s, lane), b[s], acc[m]);
+                        }
+                    }
+                    const uint2 mw = masks[(size_t)l * 64];
+                    half_t* const tdl = td + (size_t)((uint32_t)l * WIDTH) * 8;
+#pragma unroll
+                    for (int s = 0; s < KSG; s++) {
+                        uint4v w;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int k = 4 * s + i;
+                            const uint32_t bits = ((k >> 4) ? mw.y : mw.x) >> (MASK_BITS - 1 - (k & 15));
+                            const short2v keep = -__builtin_bit_cast(short2v, bits & 0x00010001u);      // 0xffff where the ReLU passed
+                            const float2v dv = {acc[s >> 1][8 * (s & 1) + 2 * i], acc[s >> 1][8 * (s & 1) + 2 * i + 1]};
+                            const half2v dh = __builtin_convertvector(dv, half2v);
+                            w[i] = __builtin_bit_cast(uint32_t, dh) & __builtin_bit_cast(uint32_t, keep);
+                        }
+                        b[s] = __builtin_bit_cast(half8, w);
+                        store_kgroups<true>(kg, b[s], lane, tdl + (size_t)(16 * s) * 8, rows_d);
+                    }
+                } else {
+                    // ---- dL/d(encoded input rows 0..31) = W0^T delta_0 for a trainable encoding
+                    f32x16 de = zero16();
+#pragma unroll
+                    for (int s = 0; s < KSG; s++) de = mfma(ld_frag(lw, s, lane), b[s], de);
+                    half_t* const po = a.d_enc + (size_t)sidx * 32u + 4 * h;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) po[(reg & 3) + 8 * (reg >> 2)] = (half_t)de[reg];
                 }
-            if (l > 0) {
-                const int base = (l - 1) * MTG * KSG;
-#pragma unroll
-                for (int m = 0; m < MTG; m++) {
-                    d[m] = zero16();
-#pragma unroll
-                    for (int s = 0; s < KSG; s++) d[m] = mfma(ld_frag_g(img_bwd, base + m * KSG + s, lane), dl[s], d[m]);
-                }
-            } else if (a.d_enc != nullptr) {
-                // dL/d(encoded input rows 0..31) = W0^T delta_0: fragments appended behind the output layer's in the W^T image
-                const int base = (depth - 1) * MTG * KSG + MTG;
-                f32x16 de = zero16();
-#pragma unroll
-                for (int s = 0; s < KSG; s++) de = mfma(ld_frag_g(img_bwd, base + s, lane), dl[s], de);
-                half_t* const po = a.d_enc + (size_t)sidx * 32u + 4 * h;
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) po[(reg & 3) + 8 * (reg >> 2)] = (half_t)de[reg];
             }
+            if (more) stage_commit(next, (q + 1) & 1);
+            __syncthreads();
+            q++;
         }
     }
 }
@@ -1303,13 +1500,13 @@ __global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const 
 
 // fragment images from the canonical fp32 vectors
 __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ ema, const int32_t* __restrict__ src_fwd,
-                       uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd, half_t* __restrict__ pk_infer,
-                       half_t* __restrict__ pk_fwd, half_t* __restrict__ pk_bwd)
+                       const int32_t* __restrict__ src_inf, uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd,
+                       half_t* __restrict__ pk_infer, half_t* __restrict__ pk_fwd, half_t* __restrict__ pk_bwd)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_fwd) {
-        const int32_t s = src_fwd[i];
-        pk_infer[i] = s < 0 ? (half_t)0.0f : (half_t)ema[s];
+        const int32_t s = src_fwd[i], si = src_inf[i];      // the EMA (inference) image may order layer 0's inputs differently
+        pk_infer[i] = si < 0 ? (half_t)0.0f : (half_t)ema[si];
         pk_fwd[i] = s < 0 ? (half_t)0.0f : (half_t)w[s];
     }
     if (i < n_bwd) {
@@ -1448,6 +1645,21 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     NRC_HIP(hipMalloc(&d_src_fwd_, sf.size() * 4));
     NRC_HIP(hipMalloc(&d_src_bwd_, sb.size() * 4));
     NRC_HIP(hipMemcpy(d_src_fwd_, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
+    // Generic models with the Frequency(12) + OneBlob(4) input (configs[4]'s 8x128): EMA inference encodes inside k_infer_gen as
+    // k_infer does, so its image takes layer 0's inputs in that encoder's order (fmap80); training keeps k_encode's natural order
+    enc80_generic_ = !fused_ && !hash_ && cfg.pos_id == 3 && cfg.dir_id == 0;
+    d_src_inf_ = d_src_fwd_;
+    if (enc80_generic_) {
+        std::vector<int32_t> si = sf;
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 8; j++)
+                for (int mt = 0; mt < mt_n; mt++)
+                    for (int s = 0; s < ks0; s++)
+                        if (32 * mt + (lane & 31) < W)
+                            si[slot(mt * ks0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + (lane & 31)) * E + fmap80(s, lane >> 5, j));
+        NRC_HIP(hipMalloc(&d_src_inf_, si.size() * 4));
+        NRC_HIP(hipMemcpy(d_src_inf_, si.data(), si.size() * 4, hipMemcpyHostToDevice));
+    }
     NRC_HIP(hipMemcpy(d_src_bwd_, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
     for (auto& p : d_pk_infer_) NRC_HIP(hipMalloc(&p, sf.size() * 2));
     NRC_HIP(hipMalloc(&d_pk_fwd_, sf.size() * 2));
@@ -1463,6 +1675,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 
 Mlp::~Mlp()
 {
+    if (d_src_inf_ != d_src_fwd_ && d_src_inf_) (void)hipFree(d_src_inf_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_[0], d_feat_[1], d_t16_train_,
                     d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_};
@@ -1490,7 +1703,7 @@ void Mlp::repack(hipStream_t s)
     const uint32_t nf = n_frag_fwd_ * 512, nb = n_frag_bwd_ * 512;
     const uint32_t nmax = nf > nb ? nf : nb;
     const int next = infer_set_ ^ 1;
-    hipLaunchKernelGGL(k_pack, dim3(ceil_div(nmax, 256)), dim3(256), 0, s, d_w_, d_ema_, d_src_fwd_, nf, d_src_bwd_, nb,
+    hipLaunchKernelGGL(k_pack, dim3(ceil_div(nmax, 256)), dim3(256), 0, s, d_w_, d_ema_, d_src_fwd_, d_src_inf_, nf, d_src_bwd_, nb,
                        (half_t*)d_pk_infer_[next], (half_t*)d_pk_fwd_, (half_t*)d_pk_bwd_);
     if (hash_)
         hipLaunchKernelGGL(k_pack_grid, dim3(ceil_div(n_grid_entries_, 256)), dim3(256), 0, s, d_w_ + n_mlp_, d_ema_ + n_mlp_,
@@ -1565,50 +1778,44 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     if (n == 0) return;
     const uint4* img = (const uint4*)(use_ema ? d_pk_infer_[infer_set_] : d_pk_fwd_);
     if (!fused_) {
-        launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
+        // EMA inference of a Frequency(12) + OneBlob(4) model encodes inside the MLP kernel (image in the encoder's input order);
+        // everything else runs the encoding kernel first
+        const bool enc80 = enc80_generic_ && use_ema;
+        if (!enc80) launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
         const float* skip_in = skip_zero_queries ? d_in : nullptr;
+        const half_t* feat = enc80 ? nullptr : (const half_t*)d_feat_[0];
+        const int ks0 = (int)enc_dims_ / 16;
+        uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
+        auto launch = [&](auto kernel, uint32_t threads, size_t lds, uint32_t per_cu) {
+            const uint32_t cap = (uint32_t)num_cus() * per_cu;
+            hipLaunchKernelGGL(kernel, dim3(blocks > cap ? cap : blocks), dim3(threads), lds, s, feat, d_out, n, img, (int)depth_, ks0, skip_in, d_in);
+        };
         if (kw_ == 32) {
-            uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
-            const uint32_t cap = (uint32_t)num_cus() * 4u;
-            if (blocks > cap) blocks = cap;
-            if (hash_)
-                hipLaunchKernelGGL((k_infer_gen<32, 256, true>), dim3(blocks), dim3(256), 2 * 5 * 1024, s, (const half_t*)d_feat_[0],
-                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
-            else
-                hipLaunchKernelGGL((k_infer_gen<32, 256, false>), dim3(blocks), dim3(256), 2 * 5 * 1024, s, (const half_t*)d_feat_[0],
-                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            if (enc80) launch(k_infer_gen<32, 256, false, 2, true>, 256, 2 * 5 * 1024, 4);
+            else if (hash_) launch(k_infer_gen<32, 256, true>, 256, 2 * 5 * 1024, 4);
+            else launch(k_infer_gen<32, 256, false>, 256, 2 * 5 * 1024, 4);
         } else if (kw_ == 64) {           // 4 waves x 2 tiles = 256 samples per workgroup pass, 20 KB of LDS
-            uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
-            const uint32_t cap = (uint32_t)num_cus() * 4u;
-            if (blocks > cap) blocks = cap;
-            if (hash_)
-                hipLaunchKernelGGL((k_infer_gen<64, 256, true>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0],
-                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
-            else
-                hipLaunchKernelGGL((k_infer_gen<64, 256, false>), dim3(blocks), dim3(256), 2 * 10 * 1024, s, (const half_t*)d_feat_[0],
-                                   d_out, n, img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            if (enc80) launch(k_infer_gen<64, 256, false, 2, true>, 256, 2 * 10 * 1024, 4);
+            else if (hash_) launch(k_infer_gen<64, 256, true>, 256, 2 * 10 * 1024, 4);
+            else launch(k_infer_gen<64, 256, false>, 256, 2 * 10 * 1024, 4);
         } else {
-            // 8 waves x 1 tile = 256 samples per staged layer (32 KB), 64 KB of LDS.  One tile per wave keeps the four 32-row
-            // accumulators of a 128-wide layer (64 VGPRs) and the operands in registers: with two tiles per wave the kernel
-            // spilled 27 VGPRs to scratch.  The staged layers come out of the L2 (the 250 KB image is resident there): 1 KB per
-            // sample instead of 0.5 KB, still far below what the per-tile fragment fetches cost (7.8 KB).
-            uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
-            const uint32_t cap = (uint32_t)num_cus() * 2u;
-            if (blocks > cap) blocks = cap;
+            // 8 waves x 1 tile = 256 samples per staged layer (32 KB), 64 KB of LDS.  One tile per wave and one 32-row block of a
+            // layer at a time keep the kernel at 134-154 VGPRs without scratch (two tiles per wave spilled 27 VGPRs): a workgroup
+            // fits on a CU beside two gen_rays waves per SIMD.  The staged layers come out of the L2 (the 250 KB image is resident
+            // there): 1 KB per sample instead of 0.5 KB, still far below what per-tile fragment fetches cost (7.8 KB).
             const size_t lds = 2 * 32 * 1024;
             if (!attr_infer_set_) {      // per instance = per device: the attribute belongs to the device's code object
                 NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, true, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false, 1, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_infer_set_ = true;
             }
-            if (hash_)
-                hipLaunchKernelGGL((k_infer_gen<128, 512, true, 1>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
-                                   img, (int)depth_, (int)enc_dims_ / 16, skip_in);
-            else
-                hipLaunchKernelGGL((k_infer_gen<128, 512, false, 1>), dim3(blocks), dim3(512), lds, s, (const half_t*)d_feat_[0], d_out, n,
-                                   img, (int)depth_, (int)enc_dims_ / 16, skip_in);
+            if (enc80) launch(k_infer_gen<128, 512, false, 1, true>, 512, lds, 2);
+            else if (hash_) launch(k_infer_gen<128, 512, true, 1>, 512, lds, 2);
+            else launch(k_infer_gen<128, 512, false, 1>, 512, lds, 2);
         }
         NRC_HIP(hipGetLastError());
         return;
@@ -1797,18 +2004,38 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.depth = (int)depth_;
         a.ks0 = (int)enc_dims_ / 16;
         a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
-        // a training batch is a few hundred 32-sample tiles (16 384 rays = 512): one-wave workgroups put a tile on every CU
-        // (two per CU) instead of filling half of the chip with four-wave workgroups; large batches keep four waves
-        const uint32_t cap = (uint32_t)num_cus() * 4u;
-        uint32_t threads = THREADS;
-        if (n_tiles <= cap) { threads = 64; blocks = n_tiles; }
+        // a training batch is a few hundred 32-sample tiles (16 384 rays = 512): four-wave workgroups (128 of them) stream each
+        // layer once per four tiles; large batches use eight waves, two workgroups per CU
+        const bool small = n_tiles <= (uint32_t)num_cus() * 8u;
+        const uint32_t waves = small ? 4u : 8u;
+        blocks = ceil_div(n_tiles, waves);
+        const uint32_t cap = (uint32_t)num_cus() * 2u;
         if (blocks > cap) blocks = cap;
-        if (kw_ == 32)
-            hipLaunchKernelGGL(k_train_gen<32>, dim3(blocks), dim3(threads), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
-        else if (kw_ == 64)
-            hipLaunchKernelGGL(k_train_gen<64>, dim3(blocks), dim3(threads), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
-        else
-            hipLaunchKernelGGL(k_train_gen<128>, dim3(blocks), dim3(threads), 0, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
+        const int mtg = (int)kw_ / 32, ksg = (int)kw_ / 16;
+        // two weight stages + per wave: the k-group transposition scratch and one 64-bit ReLU mask per lane and layer
+        const size_t lds = (size_t)2 * mtg * (ksg > 5 ? ksg : 5) * 1024 + waves * (KG_SCRATCH + (size_t)depth_ * 512);
+        if (lds > 160 * 1024) fail("network too deep for the training kernel's LDS budget");
+        if (!attr_train_set_) {      // per instance = per device: the attribute belongs to the device's code object
+            const int cap_lds = 160 * 1024;
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+            attr_train_set_ = true;
+        }
+        const uint4 *fw = (const uint4*)d_pk_fwd_, *bw = (const uint4*)d_pk_bwd_;
+        if (kw_ == 32) {
+            if (small) hipLaunchKernelGGL((k_train_gen<32, 4>), dim3(blocks), dim3(256), lds, s, a, fw, bw);
+            else hipLaunchKernelGGL((k_train_gen<32, 8>), dim3(blocks), dim3(512), lds, s, a, fw, bw);
+        } else if (kw_ == 64) {
+            if (small) hipLaunchKernelGGL((k_train_gen<64, 4>), dim3(blocks), dim3(256), lds, s, a, fw, bw);
+            else hipLaunchKernelGGL((k_train_gen<64, 8>), dim3(blocks), dim3(512), lds, s, a, fw, bw);
+        } else {
+            if (small) hipLaunchKernelGGL((k_train_gen<128, 4>), dim3(blocks), dim3(256), lds, s, a, fw, bw);
+            else hipLaunchKernelGGL((k_train_gen<128, 8>), dim3(blocks), dim3(512), lds, s, a, fw, bw);
+        }
         if (hash_) {
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];

@@ -72,6 +72,8 @@ private:
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)
     void *d_pk_infer_[2] = {nullptr, nullptr}, *d_pk_fwd_ = nullptr, *d_pk_bwd_ = nullptr;
     int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)
+    int32_t* d_src_inf_ = nullptr;       // the same for the EMA inference image (= d_src_fwd_ unless enc80_generic_)
+    bool enc80_generic_ = false;         // generic model whose EMA inference encodes Frequency(12)+OneBlob(4) inside k_infer_gen
     uint32_t n_frag_fwd_ = 0, n_frag_bwd_ = 0;
 
     // training workspace

@@ -74,18 +74,22 @@ def test_per_frame_loss_poll_does_not_drain_the_pipeline(api, sc, torch_gpu):
                 seen.append(nrc.GetLoss(wait=False))
             elif mode == "block":
                 seen.append(nrc.GetLoss(wait=True))
+        t_enqueued = time.perf_counter() - t0                            # the host is done; the GPU still has frames queued
         torch_gpu.cuda.synchronize()
         dt = (time.perf_counter() - t0) / frames
         final = (nrc.GetLoss(wait=False), nrc.GetLoss(wait=True))
         ren.Destroy()
         nrc.Destroy()
-        return dt, seen, final
+        return dt, seen, final, t_enqueued
 
-    t_none, _, _ = loop("none")
-    t_poll, polled, final = loop("poll")
-    t_block, blocked, _ = loop("block")
+    t_none, _, _, _ = loop("none")
+    t_poll, polled, final, t_enq = loop("poll")
+    t_block, blocked, _, _ = loop("block")
     assert final[0] == final[1]                                      # drained: both polls agree
-    assert np.isfinite(polled).all() and len(set(polled)) > frames // 4   # the poll keeps up with training
+    # the poll keeps up with training: while the host was enqueueing, the GPU retired about t_enq / t_poll frames, each with a new
+    # loss; the poll must have seen at least half of them (it lags by the frames in flight, it does not freeze)
+    retired = min(frames, int(t_enq / t_poll))
+    assert np.isfinite(polled).all() and len(set(polled)) >= max(8, retired // 2), (len(set(polled)), retired, t_enq, t_poll)
     assert set(polled) <= set(blocked)                               # the same deterministic loss sequence, only delayed (the host
     #                                                                  enqueues frames faster than the GPU retires them)
     assert t_poll <= 1.10 * t_none, (t_poll, t_none, t_block)
