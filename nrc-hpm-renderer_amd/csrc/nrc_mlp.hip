@@ -954,6 +954,9 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 #ifndef NRC_GEN128_WPS
 #define NRC_GEN128_WPS 1
 #endif
+#ifndef NRC_GEN128_THREADS
+#define NRC_GEN128_THREADS 512
+#endif
 // ENC80: the input is the raw 5-float query and the Frequency(12) + OneBlob(4) encoding is computed here, k-step by k-step, as
 // k_infer does (no k_encode pass, no 160 B/sample feature buffer); feat is unused, raw_in required, the image is in fmap80 order.
 template <int WIDTH, int THREADS, bool FEAT_LM, int NT = 2, bool ENC80 = false>
@@ -1068,15 +1071,21 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
             if (wave_runs) {
                 if (st == 0) {
                     f32x16 acc[NT][MTG];
+                    half8 fr0[2][MTG];                 // the k-step's fragments, read one k-step ahead
+#pragma unroll
+                    for (int m = 0; m < MTG; m++) fr0[0][m] = ld_frag(lw, m * ks0, lane);
 #pragma unroll
                     for (int k = 0; k < 5; k++) {      // always five k-steps: beyond ks0 the operand is zero (and the fragment a repeat)
+                        if (k + 1 < 5) {
+#pragma unroll
+                            for (int m = 0; m < MTG; m++) fr0[(k + 1) & 1][m] = ld_frag(lw, m * ks0 + (k + 1 < ks0 ? k + 1 : ks0 - 1), lane);
+                        }
 #pragma unroll
                         for (int m = 0; m < MTG; m++) {
-                            const half8 a = ld_frag(lw, m * ks0 + (k < ks0 ? k : ks0 - 1), lane);
 #pragma unroll
-                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(a, f0[t][k], k == 0 ? zero16() : acc[t][m]);
+                            for (int t = 0; t < NT; t++) acc[t][m] = mfma(fr0[k & 1][m], f0[t][k], k == 0 ? zero16() : acc[t][m]);
                         }
-                        __builtin_amdgcn_sched_barrier(0);      // one k-step's fragments in flight, not all five
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int t = 0; t < NT; t++)
@@ -1087,25 +1096,36 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
                         // one 32-row block at a time, converted as soon as the next block's MFMAs are issued: two accumulators
                         // live instead of four (the four-block form needed 167 VGPRs and spilled under a 128-register cap, so a
                         // workgroup only fitted on a CU that gen_rays had all but left)
+                        // The fragments come through a two-deep ring of four (a "region" = four k-steps of one block): the reads of
+                        // region i+1 are issued in front of region i's MFMAs.  With only the current region's reads in flight every
+                        // region began with an exposed LDS latency (~150 cycles per 128 cycles of MFMA: the pipes were 43 % busy).
                         half8 bn[NT][KSG];
                         f32x16 acc[NT][2];
+                        half8 fr[2][4];
+                        constexpr int REGIONS = MTG * (KSG / 4);
 #pragma unroll
-                        for (int m = 0; m <= MTG; m++) {
-                            if (m < MTG) {
+                        for (int j = 0; j < 4; j++) fr[0][j] = ld_frag(lw, j, lane);
 #pragma unroll
-                                for (int k = 0; k < KSG; k++) {
-                                    const half8 a = ld_frag(lw, m * KSG + k, lane);
+                        for (int i = 0; i < REGIONS; i++) {
+                            const int m = i / (KSG / 4), k0 = (i % (KSG / 4)) * 4;
+                            if (i + 1 < REGIONS) {
 #pragma unroll
-                                    for (int t = 0; t < NT; t++) acc[t][m & 1] = mfma(a, b[t][k], k == 0 ? zero16() : acc[t][m & 1]);
-                                    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most four fragments in flight
-                                }
+                                for (int j = 0; j < 4; j++) fr[(i + 1) & 1][j] = ld_frag(lw, (i + 1) * 4 + j, lane);      // = m' * KSG + k'
                             }
-                            if (m > 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                                for (int t = 0; t < NT; t++)
+                                    acc[t][m & 1] = mfma(fr[i & 1][j], b[t][k0 + j], k0 + j == 0 ? zero16() : acc[t][m & 1]);
+                            }
+                            if (k0 == 0 && m > 0) {      // the block before this one is complete: convert it behind this block's first MFMAs
 #pragma unroll
                                 for (int t = 0; t < NT; t++) relu_pack(acc[t][(m - 1) & 1], bn[t][2 * (m - 1)], bn[t][2 * (m - 1) + 1]);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
+#pragma unroll
+                        for (int t = 0; t < NT; t++) relu_pack(acc[t][(MTG - 1) & 1], bn[t][2 * (MTG - 1)], bn[t][2 * (MTG - 1) + 1]);
 #pragma unroll
                         for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -1804,18 +1824,20 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             // fits on a CU beside two gen_rays waves per SIMD.  The staged layers come out of the L2 (the 250 KB image is resident
             // there): 1 KB per sample instead of 0.5 KB, still far below what per-tile fragment fetches cost (7.8 KB).
             const size_t lds = 2 * 32 * 1024;
+            constexpr int T128 = NRC_GEN128_THREADS;
             if (!attr_infer_set_) {      // per instance = per device: the attribute belongs to the device's code object
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false, 1>),
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, false, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, true, 1>),
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, true, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, 512, false, 1, true>),
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, false, 1, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_infer_set_ = true;
             }
-            if (enc80) launch(k_infer_gen<128, 512, false, 1, true>, 512, lds, 2);
-            else if (hash_) launch(k_infer_gen<128, 512, true, 1>, 512, lds, 2);
-            else launch(k_infer_gen<128, 512, false, 1>, 512, lds, 2);
+            blocks = ceil_div(ceil_div(n, 32), T128 / 64);
+            if (enc80) launch(k_infer_gen<128, T128, false, 1, true>, T128, lds, 2);
+            else if (hash_) launch(k_infer_gen<128, T128, true, 1>, T128, lds, 2);
+            else launch(k_infer_gen<128, T128, false, 1>, T128, lds, 2);
         }
         NRC_HIP(hipGetLastError());
         return;
