@@ -848,6 +848,10 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
 #pragma unroll
         for (int k = 0; k < 5; k++) qo[k] = q[k];
     }
+#ifdef NRC_LOOP_PROFILE
+    // per-pixel look-up count in the w component of the origin image (tools/lane_model.py)
+    if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = (float)c.fetches;
+#endif
     count_fetches(fetch_counter, c.fetches);
     // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order)
     if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)

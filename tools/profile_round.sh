@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU session's worth of measurements for profiles/rNN_* (run on the MI355X box from the repo root):
-#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin   (default: all)
+#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin c5   (default: all but c5)
 # Output goes to gpurun_out/<tag>/ ; copy the summaries worth keeping into profiles/ afterwards (tools/profile_collect.py).
 # rocprofv3 is always given the interpreter binary itself after `--` (no env / bash -c / shebang hop) and counters are
 # collected in passes of their own (no trace domains beside --pmc).
@@ -37,6 +37,13 @@ if has pmc; then
   echo "== pmc WRITE_SIZE";  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o b -- $B) > "$OUT/pmc_write.log" 2>&1 || exit 1
   echo "== pmc TCC";         (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tcc" -o b -- $B) > "$OUT/pmc_tcc.log" 2>&1 || exit 1
   echo "== pmc SQ";          (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o b -- $B) > "$OUT/pmc_sq.log" 2>&1 || exit 1
+fi
+if has c5; then
+  echo "== configs[4] bench (plain)" && timeout -k 10 400 "$PY" bench.py --config c5 > "$OUT/c5_bench.json" 2> "$OUT/c5_bench.err" || exit 1
+  echo "== configs[4] kernel trace"
+  (cd /tmp && timeout -k 10 400 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_c5" -o c5 -- "$PY" "$REPO/bench.py" --config c5 --steps 12 --warmup 2 --no-cpu-baseline) > "$OUT/prof_c5.log" 2>&1 || exit 1
+  echo "== dense 8x128 inference kernel trace"
+  (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_mlp128" -o mlp128 -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 20 128 8) > "$OUT/prof_mlp128.log" 2>&1 || exit 1
 fi
 if has pin; then
   echo "== exr pin calibration" && timeout -k 10 600 "$PY" tools/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
