@@ -261,6 +261,7 @@ int nrc_mc_renderer_render(nrc_mc_renderer_t* r);
 int nrc_mc_renderer_set_camera(nrc_mc_renderer_t* r, const nrc_camera* camera);
 int nrc_mc_renderer_set_blend(nrc_mc_renderer_t* r, int blend);
 int nrc_mc_renderer_set_empty_skip(nrc_mc_renderer_t* r, int on);   /* see nrc_renderer_set_empty_skip */
+int nrc_mc_renderer_set_cost_order(nrc_mc_renderer_t* r, int on);   /* see nrc_renderer_set_cost_order */
 int nrc_mc_renderer_is_blending(nrc_mc_renderer_t* r);          /* include/engine/graphics/renderer/McHpmRenderer.hpp */
 int nrc_mc_renderer_set_scene_params(nrc_mc_renderer_t* r, const nrc_scene* scene);   /* see nrc_renderer_set_scene_params */
 int nrc_mc_renderer_set_frame_random(nrc_mc_renderer_t* r, const float random4[4]);

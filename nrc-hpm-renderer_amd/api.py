@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
     "nrc_cache_get_loss_blocking", "nrc_cache_comm_info", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
-    "nrc_renderer_set_cost_order", "nrc_renderer_tile_order",
+    "nrc_renderer_set_cost_order", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -554,6 +554,9 @@ class McHpmRenderer:
 
     def SetEmptySkip(self, on=True):
         _check(self.L.nrc_mc_renderer_set_empty_skip(self.h, C.c_int(int(on))))
+
+    def SetCostOrder(self, on=True):
+        _check(self.L.nrc_mc_renderer_set_cost_order(self.h, C.c_int(int(on))))
 
     def SetSceneParams(self, scene):
         sc_ = make_c_scene(scene.scene if hasattr(scene, "scene") else scene)

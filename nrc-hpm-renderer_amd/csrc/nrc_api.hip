@@ -993,6 +993,14 @@ public:
         NRC_HIP(hipEventCreate(&ev_[0])); NRC_HIP(hipEventCreate(&ev_[1]));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
+        // costliest-first tile launch order, as in the NRC renderer (one stream here: the sort simply follows the sampled frame)
+        cost_order_ = getenv("NRC_NO_COST_ORDER") == nullptr;
+        n_slots_ = camera_slots(w, h);
+        NRC_HIP(hipMalloc(&d_tile_cost_, (size_t)n_slots_ * 4));
+        NRC_HIP(hipMalloc(&d_tile_order_, (size_t)n_slots_ * 4));
+        std::vector<uint32_t> ident(n_slots_);
+        for (uint32_t i = 0; i < n_slots_; i++) ident[i] = i;
+        NRC_HIP(hipMemcpy(d_tile_order_, ident.data(), (size_t)n_slots_ * 4, hipMemcpyHostToDevice));
     }
     ~McRenderer()
     {
@@ -1000,6 +1008,8 @@ public:
         if (d_info_) (void)hipFree(d_info_);
         if (d_fetch_) (void)hipFree(d_fetch_);
         if (d_tile_mask_) (void)hipFree(d_tile_mask_);
+        if (d_tile_cost_) (void)hipFree(d_tile_cost_);
+        if (d_tile_order_) (void)hipFree(d_tile_order_);
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     }
     void set_empty_skip(bool on) { empty_skip_ = on; mask_dirty_ = true; }      // same stream: ordered behind frames in flight
@@ -1018,12 +1028,18 @@ public:
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
         if (blend_) blend_index_++;
+        const bool sample_cost = cost_order_ && frame_index_ % 16 == 0;
+        frame_.tile_order = cost_order_ ? (const uint32_t*)d_tile_order_ : nullptr;
+        frame_.tile_cost = sample_cost ? (uint32_t*)d_tile_cost_ : nullptr;
         NRC_HIP(hipEventRecord(ev_[0], stream_));
         launch_mc_render(scene_.d, cam_, frame_, path_length_, blend_factor, (float*)d_out_, (float*)d_info_,
                          count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
         NRC_HIP(hipEventRecord(ev_[1], stream_));
+        if (sample_cost) launch_tile_order((const uint32_t*)d_tile_cost_, n_slots_, (uint32_t*)d_tile_order_, stream_);
+        frame_index_++;
         timed_ = true;
     }
+    void set_cost_order(bool on) { cost_order_ = on; }
     void set_camera(const nrc_camera& c)
     {
         cam_ = to_dev(c);
@@ -1078,6 +1094,10 @@ private:
     float pinned_random_[4] = {0, 0, 0, 0};
     bool have_pinned_random_ = false;
     bool count_fetches_ = false;
+    bool cost_order_ = true;
+    void *d_tile_cost_ = nullptr, *d_tile_order_ = nullptr;
+    uint32_t n_slots_ = 0;
+    uint64_t frame_index_ = 0;
 };
 
 }  // namespace nrc
@@ -1317,6 +1337,11 @@ size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t cap
     size_t n = 0;
     if (guarded([&] { n = r->impl.tile_order(host_out, capacity); }) != NRC_OK) return 0;
     return n;
+}
+int nrc_mc_renderer_set_cost_order(nrc_mc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.set_cost_order(on != 0); });
 }
 int nrc_mc_renderer_set_empty_skip(nrc_mc_renderer_t* r, int on)
 {

@@ -869,10 +869,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
 {
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
-    uint32_t lx, y;
-    const bool inside = pixel_of_wave_tile(fr, &lx, &y);
+    uint32_t lx, y, slot;
+    const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
     Ctx c{sc, 0.0f, 0u};
     c.occ = occ;
     if (inside) {
@@ -913,6 +914,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
         if (info) info[pix] = a;
     }
     count_fetches(fetch_counter, c.fetches);
+    if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
+        fr.tile_cost[slot] = (uint32_t)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0xffffffffull);
 }
 
 // ------------------------------------------------------------------------------------------------ costliest-first launch order

@@ -718,3 +718,14 @@ def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc,
     rank = np.empty(n, np.int64)
     rank[order] = np.arange(n)
     assert rank[scat].mean() < 0.5 * rank[~scat].mean()
+    # the MC renderer orders its launch the same way (one stream: the sort follows the sampled frame)
+    imgs = {}
+    for on in (True, False):
+        mc = api.McHpmRenderer(W, H, 8, True, cam, scene)
+        mc.SetCostOrder(on)
+        for f in range(3):
+            mc.SetFrameRandom(frs[f])
+            mc.Render()
+        imgs[on] = mc.GetImage().cpu().numpy().copy()
+        mc.Destroy()
+    assert same_bits(imgs[True], imgs[False]) and imgs[True][..., :3].std() > 0.01
