@@ -287,12 +287,34 @@ def main():
                     traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
                 traffic_source = tf + " (committed rocprofv3 --pmc passes of this command; not measured in this run)"
                 break
+        # kernel-only duration of the dense inference launch from the committed rocprofv3 kernel trace of tools/bench_mlp.py (the
+        # event-timed loop above includes the ~17 us between consecutive launches); a constant read from profiles/, labelled so
+        def trace_duration(path, key):
+            full = os.path.join(ROOT, path)
+            if not os.path.exists(full):
+                return None
+            import csv
+            for row in csv.DictReader(open(full)):
+                if key in row["Name"]:
+                    return dict(source=path + " (committed rocprofv3 --kernel-trace --stats; not measured in this run)", calls=int(row["Calls"]),
+                                avg_us=float(row["AverageNs"]) / 1e3, min_us=float(row["MinNs"]) / 1e3,
+                                frac_of_peak_avg=flop * 2073600 / (float(row["AverageNs"]) * 1e-9) / 1e12 / MFMA_F16_PEAK_TFLOPS)
+            return None
+
+        mlp_trace = None
+        if n_inf == 2073600 and north_star:
+            mlp_trace = trace_duration("profiles/r02_mlp_kernel_stats.csv", "k_infer")
+        elif n_inf == 2073600 and (args.pos_id, args.dir_id, args.nn_width, args.nn_depth) == (3, 0, 128, 8):
+            mlp_trace = trace_duration("profiles/r02_mlp128_kernel_stats.csv", "k_infer_gen")
         dominant_is_gen = gen_ms >= mlp_ms
-        mlp_kernel = "k_infer (fused encode + 6x64 MLP)" if north_star else "k_encode + k_infer_gen<%d> (%dx%d MLP)" % (args.nn_width, args.nn_depth, args.nn_width)
+        enc_inside = (args.pos_id, args.dir_id) == (3, 0)      # Frequency + OneBlob: encoded inside the MLP kernel
+        mlp_kernel = ("k_infer (fused encode + 6x64 MLP)" if north_star else
+                      "%sk_infer_gen<%d> (%dx%d MLP%s)" % ("" if enc_inside else "k_encode + ", args.nn_width, args.nn_depth, args.nn_width,
+                                                          ", encoding inside" if enc_inside else ""))
         roof_mlp = dict(bound="mfma", kernel=mlp_kernel, achieved=mlp_tflops, peak=MFMA_F16_PEAK_TFLOPS, flop_per_sample=flop,
                         unit="TFLOP/s", frac=mlp_tflops / MFMA_F16_PEAK_TFLOPS, traffic=traffic.get("k_infer"), traffic_source=traffic_source,
                         algorithmic_bytes=MLP_BYTES_PER_SAMPLE * n_inf, ms_per_launch=mlp_ms, samples_per_launch=n_inf,
-                        data="uniform random queries",
+                        data="uniform random queries", kernel_trace=mlp_trace,
                         on_frame_queries=dict(ms_per_launch=mlp_ms_frame,
                                               achieved=flop * n_inf / (mlp_ms_frame * 1e-3) / 1e12,
                                               frac=flop * n_inf / (mlp_ms_frame * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS))
