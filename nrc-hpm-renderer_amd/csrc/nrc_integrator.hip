@@ -391,7 +391,11 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
         rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
         alive &= a.live1;
+#ifdef NRC_DIAG_CUT_TAIL
+        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
+#else
         if (__ballot(alive) == 0ull) break;
+#endif
         if (alive) NRC_PROF(c, 3);
         const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
         __builtin_amdgcn_sched_barrier(0);
@@ -586,7 +590,11 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         rng = out1 ? a.s1 : rng;
         vexit |= out1;
         alive &= a.live1;
+#ifdef NRC_DIAG_CUT_TAIL
+        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
+#else
         if (__ballot(alive) == 0ull) break;
+#endif
         if (alive) NRC_PROF(c, 2);
         const Fetch2 fa = fetch2_load(c, ia);
         __builtin_amdgcn_sched_barrier(0);
