@@ -89,7 +89,7 @@ int nrc_cache_destroy(nrc_cache_t* c);
  * value; its main loop polls it every frame (src/main.cu:303,376).  Here a one-thread kernel behind every training step stores
  * {loss, step number} into host-mapped pinned memory on the training stream:
  *   nrc_cache_get_loss           the loss of the most recent training step that has COMPLETED; never blocks and never drains
- *                                the renderer's frame pipeline (it lags the enqueued work by at most the pipeline depth, three
+ *                                the renderer's frame pipeline (it lags the enqueued work by at most the pipeline depth, four
  *                                frames).  NaN/Inf polling as in src/main.cu:380-384 works unchanged.
  *   nrc_cache_get_loss_blocking  waits for the last training step that was enqueued (for that step only, not for the device). */
 float nrc_cache_get_loss(nrc_cache_t* c);

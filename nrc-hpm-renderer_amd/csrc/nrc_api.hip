@@ -208,7 +208,7 @@ public:
     // pinned memory (no event polling: the runtime reports a recorded event complete only with the batch it was submitted in):
     //   get_loss(false)  the loss of the most recent step that has COMPLETED -- a plain read of that cell; never blocks, never
     //                    drains the frame pipeline (what a per-frame GetLoss() poll needs: src/main.cu:303,376; it lags the
-    //                    enqueued work by the pipeline depth, at most three frames);
+    //                    enqueued work by the pipeline depth, at most four frames);
     //   get_loss(true)   waits for the last step that was enqueued (only for that step, not for the device).
     void push_loss(hipStream_t st)
     {
@@ -639,14 +639,15 @@ public:
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
         if (blend_) blend_index_++;
         // Frame graph on four streams, pipelined across frames (no host sync anywhere):
-        //   A: [wait composite(N-3), train rays(N-3)] gen_rays(N)
+        //   A: [wait composite(N-4), train rays(N-4)] gen_rays(N)
         //   D: [wait gen_rays(N), train(N-2)] train-ray generation(N)
         //   B: [wait train rays(N)] backward(N) -> (all-reduce) -> [wait inference(N)] optimizer(N)
         //   C: [wait gen_rays(N), train(N-1)] inference(N) -> composite(N)
         // so frame N's train rays, training and inference all overlap frame N+1's gen_rays (the MFMA kernels and the short
         // latency-bound kernels run beside the VALU-bound integrator); inference(N+1) still sees the weights after frame N's
-        // training (quirk Q13 ordering).  gen_rays' outputs are triple-buffered (the chain gen_rays -> train rays -> training
-        // -> next frame's inference -> compositing spans almost three frames), the train rays double-buffered.
+        // training (quirk Q13 ordering).  gen_rays' outputs exist in four sets (the chain gen_rays -> train rays -> training
+        // -> next frame's inference -> compositing spans almost three frame times on one GPU, and the gradient all-reduce of a
+        // multi-GPU run sits on it too), the train rays double-buffered.
         // events: 0 frame start, 1 gen_rays done, 2 train rays done (D), 3 inference done, 4 composite done, 5 training done (B)
         hipStream_t A = stream_, B = stream_b_ ? stream_b_ : stream_, Cs = stream_c_ ? stream_c_ : stream_;
         hipStream_t D = stream_d_ ? stream_d_ : B;
@@ -940,7 +941,7 @@ private:
     size_t ring_entries_ = 0;
     void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
 #ifndef NRC_GEN_SETS
-#define NRC_GEN_SETS 3
+#define NRC_GEN_SETS 4
 #endif
     static constexpr int kGenSets = NRC_GEN_SETS;
     void *d_info2_[kGenSets] = {}, *d_origin2_[kGenSets] = {}, *d_dir2_[kGenSets] = {};
