@@ -2,8 +2,8 @@
 """Measures the statistics of tests/exr_pin.py for the reference's scenes and for perturbed variants -- the numbers the bounds in
 tests/test_oracle_golden.py and tests/test_gpu_integrator.py are set from.
 
-  python tools/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out gpurun_out/exr_pin_gpu.json
-  python tools/exr_pin_calibrate.py --backend oracle --frames 256 --out /tmp/exr_pin_oracle.json
+  python tests/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out gpurun_out/exr_pin_gpu.json
+  python tests/exr_pin_calibrate.py --backend oracle --frames 256 --out /tmp/exr_pin_oracle.json
 gpu: McHpmRenderer at 1920x1080 (PATH_LENGTH 32, progressive blend), down-sampled 8x8 like the fixtures.
 oracle: the CPU restatement at 240x135 (every pixel = the top-left pixel of the fixture's 8x8 block)."""
 import argparse

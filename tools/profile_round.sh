@@ -46,7 +46,7 @@ if has c5; then
   (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_mlp128" -o mlp128 -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 20 128 8) > "$OUT/prof_mlp128.log" 2>&1 || exit 1
 fi
 if has pin; then
-  echo "== exr pin calibration" && timeout -k 10 600 "$PY" tools/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
+  echo "== exr pin calibration" && timeout -k 10 600 "$PY" tests/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
 fi
 # keep the merge-back small: the raw rocprofv3 databases are large, the CSVs are what gets read
 find "$OUT" -name "*.db" -delete 2>/dev/null
