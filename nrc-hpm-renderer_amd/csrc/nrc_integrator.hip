@@ -373,11 +373,100 @@ __device__ __forceinline__ RatioTrip ratio_trip(float rng, float t, float t_max,
     r.second = !(r.t2 >= t_max);
     return r;
 }
+// ---- thin trips: two lanes per surviving walk ---------------------------------------------------------------------------------
+// A tracking loop runs until its last walk ends: the trips issued with at most 32 of the 64 lanes still walking cost 28 % of the
+// launch (NRC_DIAG_CUT_TAIL).  When a loop is down to 32 walks or fewer they are handed to lane PAIRS (lane p and p + 32, state pushed
+// there with ds_permute): an iteration then advances a walk by FOUR collisions -- the hash chain is drawn by both lanes (it is the
+// only serial part, a quarter of a trip's instructions), the two free-flight logs, positions, look-ups and transmittance factors
+// of collisions 1, 2 are lane p's work and those of 3, 4 lane p + 32's, exchanged with v_permlane32_swap, and the free-flight sums
+// and transmittance products are then formed by both lanes in the sequential order -- bit for bit the walk of the one-lane loop.
+#ifndef NRC_PAIR_TAIL
+#define NRC_PAIR_TAIL 1
+#endif
+// (value of the lower-half lane, value of the upper-half lane) of a pair, on both of its lanes
+__device__ __forceinline__ void pair_both(float x, float* lo, float* hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(nrc_f2u(x), nrc_f2u(x), false, false);
+    *lo = nrc_u2f(r[0]);
+    *hi = nrc_u2f(r[1]);
+}
+
+// the surviving walks of a ratio_track loop, two lanes per walk.  On entry: `alive` lanes have a located trip whose base state is
+// (bs, bt) = (chain value before its first draw, free-flight position before it), n collisions done.  On exit: tr / rng of the alive
+// lanes are the finished walks' results.
+__device__ __forceinline__ void ratio_pairs(Ctx& c, unsigned long long am, bool alive, V3 start, V3 dir, float t_max, float inv, float bs,
+                                            float bt, uint32_t n, float& tr, float& rng)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+    const uint32_t k = (uint32_t)__popcll(am);
+    const bool is_b = (lane & 32u) != 0u;
+    // walk state -> lanes rank and rank + 32 (rank = the lane's position among the surviving ones)
+    float y[11];
+    {
+        const float x[11] = {bs, bt, t_max, tr, nrc_u2f(n), start.x, start.y, start.z, dir.x, dir.y, dir.z};
+#pragma unroll
+        for (int q = 0; q < 11; q++) {
+            // every lane pushes (a lane that is masked off neither sends nor receives): the lanes without a walk push to lanes 31 and
+            // 63, which are never part of a pair (at most 31 walks survive)
+            const int lo = __builtin_amdgcn_ds_permute((int)((alive ? rank : 31u) * 4u), (int)nrc_f2u(x[q]));
+            const int hi = __builtin_amdgcn_ds_permute((int)((alive ? rank + 32u : 63u) * 4u), (int)nrc_f2u(x[q]));
+            y[q] = nrc_u2f((uint32_t)(is_b ? hi : lo));
+        }
+    }
+    float R0 = y[0], t0 = y[1], T = y[3];
+    const float tm = y[2];
+    uint32_t nn = nrc_f2u(y[4]);
+    const V3 st = v3(y[5], y[6], y[7]), dr = v3(y[8], y[9], y[10]);
+    bool act = (lane & 31u) < k;
+    float rf = R0;
+    for (;;) {
+        if (__ballot(act) == 0ull) break;
+        const float R1 = random1(R0), R2 = random1(R1), R3 = random1(R2), R4 = random1(R3);
+        const f2 l = logf2(f2{1.0f - (is_b ? R3 : R1), 1.0f - (is_b ? R4 : R2)});
+        float l1, l2, l3, l4;
+        pair_both(l.x, &l1, &l3);
+        pair_both(l.y, &l2, &l4);
+        const float t1 = nrc_fmaf_(-l1, inv, t0), t2 = nrc_fmaf_(-l2, inv, t1), t3 = nrc_fmaf_(-l3, inv, t2), t4 = nrc_fmaf_(-l4, inv, t3);
+        // the sequential walk: draw k is made unless 128 collisions are done; the walk ends on a draw that lies beyond the segment
+        bool go = act;
+        const bool d1 = go & (nn + 1u <= 128u); rf = d1 ? R1 : rf; const bool p1 = d1 & !(t1 >= tm); go = p1;
+        const bool d2 = go & (nn + 2u <= 128u); rf = d2 ? R2 : rf; const bool p2 = d2 & !(t2 >= tm); go = p2;
+        const bool d3 = go & (nn + 3u <= 128u); rf = d3 ? R3 : rf; const bool p3 = d3 & !(t3 >= tm); go = p3;
+        const bool d4 = go & (nn + 4u <= 128u); rf = d4 ? R4 : rf; const bool p4 = d4 & !(t4 >= tm); go = p4;
+        // look-ups: collisions 1, 2 on the lower lane, 3, 4 on the upper one
+        const bool ma = is_b ? p3 : p1, mb = is_b ? p4 : p2;
+        const Addr2 ad = fetch2_addr(c, dr, st, is_b ? t3 : t1, is_b ? t4 : t2, ma, mb);
+        const Fetch2 fa = fetch2_load(c, ad);
+        const f2 dens = fetch2_density(c.sc, fa);
+        c.fetches += (ma ? 1u : 0u) + (mb ? 1u : 0u);
+        float f1, f2_, f3, f4;
+        pair_both(nrc_fmaf_(-dens.x, inv, 1.0f), &f1, &f3);
+        pair_both(nrc_fmaf_(-dens.y, inv, 1.0f), &f2_, &f4);
+        T = p1 ? T * f1 : T;
+        T = p2 ? T * f2_ : T;
+        T = p3 ? T * f3 : T;
+        T = p4 ? T * f4 : T;
+        act = p4 & (nn + 4u < 128u);
+        nn += 4u;
+        R0 = R4;
+        t0 = t4;
+    }
+    // results back to the walks' own lanes (from the lower lane of their pair)
+    const float tr_new = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)nrc_f2u(T)));
+    const float rng_new = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)nrc_f2u(rf)));
+    tr = alive ? tr_new : tr;
+    rng = alive ? rng_new : rng;
+}
+
 #if NRC_TRACK_PIPELINE
 // The loop is wave-uniform (it runs while any lane still walks) and its body is predicated with selects instead of per-lane
 // branches: with `break`s the compiler sinks the look-ahead into the continue path, i.e. behind the wait for the gathers, and
 // the overlap is gone.  Lanes that have finished keep their results and issue no gathers (offset 2^31).
-__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
+// UNI: the call sits in wave-uniform control flow (every lane of the wave executes it, `valid` says which lanes have a walk), so
+// the lanes without a walk can help with the thin trips at the end (ratio_pairs)
+template <bool UNI = false>
+__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool valid = true)
 {
     V3 d = sub(end, start);
     const V3 dir = normalize(d);
@@ -385,9 +474,10 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
     const float inv = c.sc.inv_max_density;
     float tr = 1.0f;
     float rng = c.rng;
-    bool alive = true;
+    bool alive = valid;
     RatioTrip a = ratio_trip(rng, 0.0f, t_max, inv);
     Addr2 ia = fetch2_addr(c, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
+    float bs = rng, bt = 0.0f;                 // base of the located trip `a`: chain value and position before its first draw
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
         rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
         alive &= a.live1;
@@ -395,6 +485,15 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
         if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
 #else
         if (__ballot(alive) == 0ull) break;
+#endif
+#if NRC_PAIR_TAIL
+        if constexpr (UNI) {
+            const unsigned long long am = __ballot(alive);
+            if (__popcll(am) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
+                ratio_pairs(c, am, alive, start, dir, t_max, inv, bs, bt, i, tr, rng);
+                break;
+            }
+        }
 #endif
         if (alive) NRC_PROF(c, 3);
         const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
@@ -411,6 +510,8 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
         tr = two ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
         rng = (alive & (!a.second | last)) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
         alive = more;
+        bs = a.s2;
+        bt = a.t2;
         a = b;
         ia = ib;
     }
@@ -442,8 +543,10 @@ __device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, f
     const uint8_t b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx1, 0, 0);
     return splat(s.density_factor) * (f2{(float)b0, (float)b1} * splat(1.0f / 255.0f));
 }
-__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
+template <bool UNI = false>
+__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool valid = true)
 {
+    if (!valid) return 1.0f;
     V3 d = sub(end, start);
     V3 dir = normalize(d);
     const float t_max = length(d);
@@ -472,25 +575,28 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end)
 }
 #endif
 
-__device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir)
+template <bool UNI = false>
+__device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir, bool valid = true)
 {
     const DevScene& s = c.sc;
     if (s.dir_light_strength == 0.0f) return v3(0, 0, 0);
     V3 ld = v3(s.dir_light_dir[0], s.dir_light_dir[1], s.dir_light_dir[2]);
     V3 en, ex;
+    if constexpr (UNI) pos = valid ? pos : v3(0.0f, 0.0f, 0.0f);
     find_entry_exit(c, pos, neg(normalize(ld)), &en, &ex);
-    float tr = ratio_track(c, pos, ex);
+    float tr = ratio_track<UNI>(c, pos, ex, valid);
     float phase = hg_phase(s, dot(ld, neg(dir)));
     float l = (1.0f * tr) * s.dir_light_strength * phase;
     return v3(l, l, l);
 }
 
-__device__ __forceinline__ V3 trace_point_light(Ctx& c, V3 pos, V3 dir)
+template <bool UNI = false>
+__device__ __forceinline__ V3 trace_point_light(Ctx& c, V3 pos, V3 dir, bool valid = true)
 {
     const DevScene& s = c.sc;
     if (s.point_light_strength == 0.0f) return v3(0, 0, 0);
     V3 lp = v3(s.point_light_pos[0], s.point_light_pos[1], s.point_light_pos[2]);
-    float tr = ratio_track(c, lp, pos);
+    float tr = ratio_track<UNI>(c, lp, pos, valid);
     float phase = hg_phase(s, dot(normalize(sub(lp, pos)), neg(dir)));
     return v3(((s.point_light_color[0] * s.point_light_strength) * tr) * phase,
               ((s.point_light_color[1] * s.point_light_strength) * tr) * phase,
@@ -530,24 +636,32 @@ __device__ __forceinline__ V3 sample_env_dir(const DevScene& s, V3 dir)
     return env_lookup(s, nrc_fmaf_(phi, 0.1591f, 0.5f), nrc_fmaf_(theta, 0.3183f, 0.5f));
 }
 
-__device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir)
+template <bool UNI = false>
+__device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir, bool valid = true)
 {
     if (c.sc.env_strength == 0.0f) return v3(0, 0, 0);
-    V3 rdir = new_ray_dir(c, dir, false);
+    V3 rdir = v3(0.0f, 0.0f, 1.0f);
+    if constexpr (UNI) {
+        if (valid) rdir = new_ray_dir(c, dir, false);      // lanes without a walk draw nothing
+        pos = valid ? pos : v3(0.0f, 0.0f, 0.0f);
+    } else {
+        rdir = new_ray_dir(c, dir, false);
+    }
     float phase = hg_phase(c.sc, dot(rdir, neg(dir)));
     V3 en, ex;
     find_entry_exit(c, pos, rdir, &en, &ex);
-    float tr = ratio_track(c, pos, ex);
+    float tr = ratio_track<UNI>(c, pos, ex, valid);
     V3 e = sample_env_dir(c.sc, rdir);
     return v3((e.x * phase) * tr, (e.y * phase) * tr, (e.z * phase) * tr);
 }
 
-__device__ __forceinline__ V3 trace_scene(Ctx& c, V3 pos, V3 dir)
+template <bool UNI = false>
+__device__ __forceinline__ V3 trace_scene(Ctx& c, V3 pos, V3 dir, bool valid = true)
 {
     NRC_PROF(c, 5);
-    V3 a = trace_dir_light(c, pos, dir);
-    V3 b = trace_point_light(c, pos, dir);
-    V3 e = sample_env(c, pos, dir);
+    V3 a = trace_dir_light<UNI>(c, pos, dir, valid);
+    V3 b = trace_point_light<UNI>(c, pos, dir, valid);
+    V3 e = sample_env<UNI>(c, pos, dir, valid);
     return add(add(a, b), e);
 }
 
@@ -574,14 +688,19 @@ __device__ __forceinline__ DeltaTrip delta_trip(float rng, float t, float t_max,
     return r;
 }
 #if NRC_TRACK_PIPELINE
-__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)
+template <bool UNI = false>
+__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
 {
     V3 en, ex;
-    find_entry_exit(c, ro, rd, &en, &ex);
+    if constexpr (UNI) {      // lanes without a walk march a harmless ray (from the centre along +z): the march must end for them too
+        find_entry_exit(c, valid ? ro : v3(0.0f, 0.0f, 0.0f), valid ? rd : v3(0.0f, 0.0f, 1.0f), &en, &ex);
+    } else {
+        find_entry_exit(c, ro, rd, &en, &ex);
+    }
     const float t_max = length(sub(ex, ro));
     const float inv = c.sc.inv_max_density;
     float rng = c.rng;
-    bool alive = true, hit = false, vexit = false;
+    bool alive = valid, hit = false, vexit = false;
     float t_hit = 0.0f;
     DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
     Addr2 ia = fetch2_addr(c, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
@@ -626,12 +745,17 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
     c.rng = rng;
     *volume_exit = vexit;
     if (hit) return madd(rd, t_hit, ro);
+    if constexpr (UNI) {
+        if (!valid) return ro;          // no walk: no draw
+    }
     return madd(rd, c.rand(t_max), ro);
 }
 #else
-__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)
+template <bool UNI = false>
+__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
 {
     *volume_exit = false;
+    if (!valid) return ro;
     V3 en, ex;
     find_entry_exit(c, ro, rd, &en, &ex);
     const float t_max = length(sub(ex, ro));
@@ -772,7 +896,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
-    uint32_t lx, y, slot;
+    uint32_t lx = 0, y = 0, slot;      // (a padding workgroup's lanes stay at pixel 0: they run the predicated code below with no walk)
     const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -787,46 +911,56 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
 #endif
     Ctx c{sc, 0.0f, 0u};
     c.occ = occ;
+    // Wave-uniform control flow with per-lane predicates from here to the stores: a lane whose path has ended (or that has none)
+    // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
+    const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+    const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+    V3 ro, rd;
+    camera_ray(cam, u, v, &ro, &rd);
+    init_random(c, u, v, fr.random);
+    const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform (the tile is, even where the image ends inside it)
+    const bool enter = inside & !empty;
+    V3 entry = ro, ex;
+    if (__ballot(enter) != 0ull) {
+#ifdef NRC_LOOP_PROFILE
+        c.fee_kind = 0;
+#endif
+        find_entry_exit(c, enter ? ro : v3(0.0f, 0.0f, 0.0f), enter ? rd : v3(0.0f, 0.0f, 1.0f), &entry, &ex);
+#ifdef NRC_LOOP_PROFILE
+        c.fee_kind = 1;
+#endif
+    }
+    const bool entered = enter && !(sky_sdf(sc, entry) > 100000.0f);
+    V3 light = v3(0, 0, 0);
+    V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
+    float factor = 1.0f;
+    bool did_scatter = false, walking = entered;
+    for (int i = 0;; i++) {
+        if (__ballot(walking) == 0ull) break;
+        bool vexit = false;
+        const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
+        cur = walking ? nc : cur;
+        walking &= !vexit;
+        did_scatter |= walking;
+        factor = walking ? factor * 0.5f : factor;
+        if (__ballot(walking) == 0ull) break;
+        const V3 ts = trace_scene<true>(c, cur, dir, walking);
+        if (walking) {
+            light = add(light, mul(ts, factor));
+            dir = new_ray_dir(c, dir, true);
+            if ((uint32_t)i >= primary_ray_length) {
+                if (c.rand(1.0f) >= primary_ray_prob || i == 128) walking = false;
+            }
+        }
+    }
     if (inside) {
-        const uint32_t gx = fr.x_offset + lx * fr.x_stride;
-        const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
-        V3 ro, rd;
-        camera_ray(cam, u, v, &ro, &rd);
-        init_random(c, u, v, fr.random);
         const size_t pix = (size_t)y * fr.w + lx;
         V3 col;
         float thr = 1.0f;
-        bool did_scatter = false;
         float q[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        V3 entry = ro, ex;
-        const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform
-        if (!empty) {
-#ifdef NRC_LOOP_PROFILE
-            c.fee_kind = 0;
-#endif
-            find_entry_exit(c, ro, rd, &entry, &ex);
-#ifdef NRC_LOOP_PROFILE
-            c.fee_kind = 1;
-#endif
-        }
-        if (empty || sky_sdf(sc, entry) > 100000.0f) {
+        if (!entered) {
             col = sample_env_dir(sc, rd);
         } else {
-            V3 light = v3(0, 0, 0);
-            V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
-            float factor = 1.0f;
-            bool vexit = false;
-            for (int i = 0;; i++) {
-                cur = delta_track(c, cur, dir, &vexit);
-                if (vexit) break;
-                did_scatter = true;
-                factor *= 0.5f;
-                light = add(light, mul(trace_scene(c, cur, dir), factor));
-                dir = new_ray_dir(c, dir, true);
-                if ((uint32_t)i >= primary_ray_length) {
-                    if (c.rand(1.0f) >= primary_ray_prob || i == 128) break;
-                }
-            }
             // the NRC vertex images (nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) have one reader besides the query packing
             // fused in here: prep_train_rays, at the pixels (tx * xDist, ty * yDist) of the train grid.  Only those are stored
             // (32 B for 16 384 of 2 073 600 pixels instead of 66 MB per frame) unless the caller asks for the whole images.
