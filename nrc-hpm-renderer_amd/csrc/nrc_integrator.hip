@@ -687,6 +687,94 @@ __device__ __forceinline__ DeltaTrip delta_trip(float rng, float t, float t_max,
     r.second = !(r.t2 >= t_max);
     return r;
 }
+// NRC_PAIR_TAIL_DELTA (off): the same for delta tracking.  Bit-exact like ratio_pairs, but its eight draws and four-way resolution push
+// k_gen_rays past the 102 VGPRs of five waves per SIMD (144 B of scratch: stand-alone 0.242 -> 0.258 ms); at four waves per SIMD it
+// is the fastest stand-alone (0.241 ms) and slower inside the frame (gen_rays 0.283 instead of 0.266 ms).
+#ifndef NRC_PAIR_TAIL_DELTA
+#define NRC_PAIR_TAIL_DELTA 0
+#endif
+// the surviving walks of a delta_track loop, two lanes per walk (see ratio_pairs): four tentative collisions per iteration -- eight
+// draws (flight, acceptance, flight, ...) by both lanes, collisions 1, 2 located and looked up by the lower lane and 3, 4 by the
+// upper one, then resolved in sequence: exit on the first flight beyond the segment, hit on the first accepted collision.
+__device__ __forceinline__ void delta_pairs(Ctx& c, unsigned long long am, bool alive, V3 ro, V3 rd, float t_max, float inv, float bs, float bt,
+                                            uint32_t n, float& rng, bool& hit, float& t_hit, bool& vexit)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+    const uint32_t k = (uint32_t)__popcll(am);
+    const bool is_b = (lane & 32u) != 0u;
+    float y[10];
+    {
+        const float x[10] = {bs, bt, t_max, nrc_u2f(n), ro.x, ro.y, ro.z, rd.x, rd.y, rd.z};
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            const int lo = __builtin_amdgcn_ds_permute((int)((alive ? rank : 31u) * 4u), (int)nrc_f2u(x[q]));
+            const int hi = __builtin_amdgcn_ds_permute((int)((alive ? rank + 32u : 63u) * 4u), (int)nrc_f2u(x[q]));
+            y[q] = nrc_u2f((uint32_t)(is_b ? hi : lo));
+        }
+    }
+    float R0 = y[0], t0 = y[1];
+    const float tm = y[2];
+    uint32_t nn = nrc_f2u(y[3]);
+    const V3 o = v3(y[4], y[5], y[6]), d = v3(y[7], y[8], y[9]);
+    bool act = (lane & 31u) < k;
+    float rf = R0, th = 0.0f;
+    bool hitf = false, vx = false;
+    for (;;) {
+        if (__ballot(act) == 0ull) break;
+        const float s1 = random1(R0), a1 = random1(s1), s2 = random1(a1), a2 = random1(s2);
+        const float s3 = random1(a2), a3 = random1(s3), s4 = random1(a3), a4 = random1(s4);
+        const f2 l = logf2(f2{1.0f - (is_b ? s3 : s1), 1.0f - (is_b ? s4 : s2)});
+        float l1, l2, l3, l4;
+        pair_both(l.x, &l1, &l3);
+        pair_both(l.y, &l2, &l4);
+        const float t1 = nrc_fmaf_(-l1, inv, t0), t2 = nrc_fmaf_(-l2, inv, t1), t3 = nrc_fmaf_(-l3, inv, t2), t4 = nrc_fmaf_(-l4, inv, t3);
+        const bool v1 = !(t1 >= tm), v2 = v1 & !(t2 >= tm), v3_ = v2 & !(t3 >= tm), v4 = v3_ & !(t4 >= tm);
+        // look-ups of every collision the walk can still reach (its acceptance draws decide below): 1, 2 lower lane, 3, 4 upper lane
+        const bool ma = act & (is_b ? (v3_ & (nn + 3u <= 128u)) : (v1 & (nn + 1u <= 128u)));
+        const bool mb = act & (is_b ? (v4 & (nn + 4u <= 128u)) : (v2 & (nn + 2u <= 128u)));
+        const Addr2 ad = fetch2_addr(c, d, o, is_b ? t3 : t1, is_b ? t4 : t2, ma, mb);
+        const Fetch2 fa = fetch2_load(c, ad);
+        const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
+        float d1, d2, d3, d4;
+        pair_both(dens.x, &d1, &d3);
+        pair_both(dens.y, &d2, &d4);
+        // the sequential walk
+        bool go = act;
+        uint32_t nf = 0;
+#define NRC_DELTA_STEP(K, S, A, T, V, D)                                                     \
+        {                                                                                    \
+            const bool dk = go & (nn + (K) <= 128u);      /* the flight draw is made */       \
+            rf = dk ? (S) : rf;                                                              \
+            vx |= dk & !(V);                              /* beyond the exit point */         \
+            const bool ak = dk & (V);                     /* acceptance draw + look-up */     \
+            rf = ak ? (A) : rf;                                                              \
+            nf += ak ? 1u : 0u;                                                              \
+            const bool acc = ak & ((D) > (A));                                               \
+            hitf |= acc;                                                                     \
+            th = acc ? (T) : th;                                                             \
+            go = ak & !acc;                                                                  \
+        }
+        NRC_DELTA_STEP(1u, s1, a1, t1, !(t1 >= tm), d1)
+        NRC_DELTA_STEP(2u, s2, a2, t2, !(t2 >= tm), d2)
+        NRC_DELTA_STEP(3u, s3, a3, t3, !(t3 >= tm), d3)
+        NRC_DELTA_STEP(4u, s4, a4, t4, !(t4 >= tm), d4)
+#undef NRC_DELTA_STEP
+        c.fetches += is_b ? 0u : nf;                     // counted once per walk
+        act = go & (nn + 4u < 128u);
+        nn += 4u;
+        R0 = a4;
+        t0 = t4;
+    }
+    const float rng_new = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)nrc_f2u(rf)));
+    const float th_new = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)nrc_f2u(th)));
+    const uint32_t fl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)((hitf ? 1u : 0u) | (vx ? 2u : 0u)));
+    rng = alive ? rng_new : rng;
+    t_hit = alive ? th_new : t_hit;
+    hit = alive ? ((fl & 1u) != 0u) : hit;
+    vexit = alive ? ((fl & 2u) != 0u) : vexit;
+}
+
 #if NRC_TRACK_PIPELINE
 template <bool UNI = false>
 __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
@@ -704,6 +792,7 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
     float t_hit = 0.0f;
     DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
     Addr2 ia = fetch2_addr(c, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
+    float bs = rng, bt = 0.0f;                 // base of the located trip `a`
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:161); predicated like ratio_track
         const bool out1 = alive & !a.live1;                          // collision 1 beyond the exit point
         rng = out1 ? a.s1 : rng;
@@ -713,6 +802,15 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
 #else
         if (__ballot(alive) == 0ull) break;
+#endif
+#if NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
+        if constexpr (UNI) {
+            const unsigned long long am = __ballot(alive);
+            if (__popcll(am) <= 31) {        // few walks left: two lanes each (delta_pairs)
+                delta_pairs(c, am, alive, ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
+                break;
+            }
+        }
 #endif
         if (alive) NRC_PROF(c, 2);
         const Fetch2 fa = fetch2_load(c, ia);
@@ -738,6 +836,8 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         rng = out2 ? a.s2 : rng;
         rng = (alive3 & (acc2 | last)) ? a.a2 : rng;
         alive = alive3 & !acc2 & !last;
+        bs = a.a2;
+        bt = a.t2;
         a = b;
         ia.i0 = alive ? ib.i0 : 0x80000000u;                         // a lane that has just finished fetches nothing next trip
         ia.i1 = alive ? ib.i1 : 0x80000000u;
@@ -887,7 +987,10 @@ __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint3
 }
 
 // ------------------------------------------------------------------------------------------------ nrc/gen_rays.comp + prep_infer_rays.comp
-__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_SIMD) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
+#ifndef NRC_GEN_WAVES_PER_SIMD
+#define NRC_GEN_WAVES_PER_SIMD NRC_CAMERA_WAVES_PER_SIMD
+#endif
+__global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
                                                  float primary_ray_prob, float4* __restrict__ primary,
                                                  float* __restrict__ info, float4* __restrict__ origin,
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
