@@ -1117,39 +1117,43 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
-    uint32_t lx, y, slot;
+    uint32_t lx = 0, y = 0, slot;
     const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
     Ctx c{sc, 0.0f, 0u};
     c.occ = occ;
-    if (inside) {
-        const uint32_t gx = fr.x_offset + lx * fr.x_stride;
-        const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
-        V3 ro, rd;
-        camera_ray(cam, u, v, &ro, &rd);
-        init_random(c, u, v, fr.random);
-        V3 entry = ro, ex;
-        const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform, see tile_is_empty
-        if (!empty) find_entry_exit(c, ro, rd, &entry, &ex);
-        V3 col;
-        bool did_scatter = false;
-        if (empty || sky_sdf(sc, entry) > 100000.0f) {
-            col = sample_env_dir(sc, rd);
-        } else {
-            V3 light = v3(0, 0, 0);
-            V3 cur = entry, dir = rd;
-            float factor = 1.0f;
-            bool vexit = false;
-            for (uint32_t i = 0; i < path_length; i++) {
-                cur = delta_track(c, cur, dir, &vexit);
-                if (vexit) break;
-                did_scatter = true;
-                factor *= 0.5f;
-                light = add(light, mul(trace_scene(c, cur, dir), factor));
-                dir = new_ray_dir(c, dir, true);
-            }
-            col = light;
-            if (!did_scatter) col = sample_env_dir(sc, rd);
+    // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
+    const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+    const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+    V3 ro, rd;
+    camera_ray(cam, u, v, &ro, &rd);
+    init_random(c, u, v, fr.random);
+    const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform, see tile_is_empty
+    const bool enter = inside & !empty;
+    V3 entry = ro, ex;
+    if (__ballot(enter) != 0ull) find_entry_exit(c, enter ? ro : v3(0.0f, 0.0f, 0.0f), enter ? rd : v3(0.0f, 0.0f, 1.0f), &entry, &ex);
+    const bool entered = enter && !(sky_sdf(sc, entry) > 100000.0f);
+    V3 light = v3(0, 0, 0);
+    V3 cur = entry, dir = rd;
+    float factor = 1.0f;
+    bool did_scatter = false, walking = entered;
+    for (uint32_t i = 0; i < path_length; i++) {
+        if (__ballot(walking) == 0ull) break;
+        bool vexit = false;
+        const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
+        cur = walking ? nc : cur;
+        walking &= !vexit;
+        did_scatter |= walking;
+        factor = walking ? factor * 0.5f : factor;
+        if (__ballot(walking) == 0ull) break;
+        const V3 ts = trace_scene<true>(c, cur, dir, walking);
+        if (walking) {
+            light = add(light, mul(ts, factor));
+            dir = new_ray_dir(c, dir, true);
         }
+    }
+    if (inside) {
+        V3 col = light;
+        if (!did_scatter) col = sample_env_dir(sc, rd);
         const float a = did_scatter ? 1.0f : 0.0f;
         const size_t pix = (size_t)y * fr.w + lx;
         const float4 prev = out_rgba[pix];
