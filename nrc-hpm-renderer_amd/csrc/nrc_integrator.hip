@@ -1325,9 +1325,11 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    if (tx >= tg.tw || ty >= tg.th) return;
+    // wave-uniform control flow with per-lane predicates, as in k_gen_rays: lanes beyond the train grid or done with their path stay in
+    // the instruction stream and help with the last walks of every tracking loop (ratio_pairs)
+    const bool in_grid = tx < tg.tw && ty < tg.th;
     const uint32_t T = tg.tw * tg.th;
-    const uint32_t i = ty * tg.tw + tx;
+    const uint32_t i = in_grid ? ty * tg.tw + tx : 0u;
     Ctx c{sc, 0.0f, 0u};
     c.occ = occ;
     // seed from TRAIN coordinates over the render size (quirk Q6, prep_train_rays.comp:108); sharded: global column
@@ -1335,13 +1337,13 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     init_random(c, (float)gx * fr.inv_gw, (float)ty * fr.inv_gh, fr.random);
     V3 ro = v3(0, 0, 0);
     V3 rdir = normalize(v3(1.0f, 1.0f, 1.0f));
-    const bool scat = scratch[i] != 0u;
+    const bool scat = in_grid && scratch[i] != 0u;
     if (scat) {
         const size_t p = (size_t)(ty * tg.y_dist) * fr.w + tx * tg.x_dist;
         const float4 o = origin[p], d = dirs[p];
         ro = v3(o.x, o.y, o.z);
         rdir = v3(d.x, d.y, d.z);
-    } else if (tg.ring_size > 0) {
+    } else if (in_grid && tg.ring_size > 0) {
         const uint32_t tail = scratch[2 * T + 3];
         const float* r = reinterpret_cast<const float*>(ring + 2) + 6 * (size_t)((tail + scratch[T + i]) % tg.ring_size);
         ro = v3(r[0], r[1], r[2]);
@@ -1351,22 +1353,29 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     for (uint32_t s = 0; s < tg.spp; s++) {
         V3 light = v3(0, 0, 0);
         V3 en, ex;
-        find_entry_exit(c, ro, rdir, &en, &ex);
+        find_entry_exit(c, ro, rdir, &en, &ex);      // (lanes beyond the grid march the default ray from the centre)
         V3 cur = en, dir = rdir;
         float factor = 1.0f;
-        bool vexit = false;
+        bool walking = in_grid;
         for (uint32_t k = 0; k < tg.ray_length; k++) {
-            cur = delta_track(c, cur, dir, &vexit);
-            if (vexit) break;
-            factor *= 0.5f;
-            light = add(light, mul(trace_scene(c, cur, dir), factor));
-            dir = new_ray_dir(c, dir, true);
+            if (__ballot(walking) == 0ull) break;
+            bool vexit = false;
+            const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
+            cur = walking ? nc : cur;
+            walking &= !vexit;
+            factor = walking ? factor * 0.5f : factor;
+            if (__ballot(walking) == 0ull) break;
+            const V3 ts = trace_scene<true>(c, cur, dir, walking);
+            if (walking) {
+                light = add(light, mul(ts, factor));
+                dir = new_ray_dir(c, dir, true);
+            }
         }
         target = add(target, light);
     }
     const float fs = (float)tg.spp;
     target = v3(target.x / fs, target.y / fs, target.z / fs);
-    if (tg.ring_size > 0) {
+    if (in_grid && tg.ring_size > 0) {
         float q[5];
         nrc_query(sc, ro, rdir, q);
 #pragma unroll
