@@ -47,6 +47,8 @@ __device__ __forceinline__ V3 normalize(V3 a)
     float inv = 1.0f / length(a);
     return v3(a.x * inv, a.y * inv, a.z * inv);
 }
+// b ? x : y per component (a ternary on the struct makes hipcc select between two stack copies)
+__device__ __forceinline__ V3 sel(bool b, V3 x, V3 y) { return v3(b ? x.x : y.x, b ? x.y : y.y, b ? x.z : y.z); }
 __device__ __forceinline__ V3 madd(V3 d, float t, V3 o) { return v3(nrc_fmaf_(d.x, t, o.x), nrc_fmaf_(d.y, t, o.y), nrc_fmaf_(d.z, t, o.z)); }   // o + d*t
 
 // ---- include/random.glsl:24-70
@@ -582,7 +584,7 @@ __device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir, bool valid
     if (s.dir_light_strength == 0.0f) return v3(0, 0, 0);
     V3 ld = v3(s.dir_light_dir[0], s.dir_light_dir[1], s.dir_light_dir[2]);
     V3 en, ex;
-    if constexpr (UNI) pos = valid ? pos : v3(0.0f, 0.0f, 0.0f);
+    if constexpr (UNI) pos = sel(valid, pos, v3(0.0f, 0.0f, 0.0f));
     find_entry_exit(c, pos, neg(normalize(ld)), &en, &ex);
     float tr = ratio_track<UNI>(c, pos, ex, valid);
     float phase = hg_phase(s, dot(ld, neg(dir)));
@@ -643,7 +645,7 @@ __device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir, bool valid = tr
     V3 rdir = v3(0.0f, 0.0f, 1.0f);
     if constexpr (UNI) {
         if (valid) rdir = new_ray_dir(c, dir, false);      // lanes without a walk draw nothing
-        pos = valid ? pos : v3(0.0f, 0.0f, 0.0f);
+        pos = sel(valid, pos, v3(0.0f, 0.0f, 0.0f));
     } else {
         rdir = new_ray_dir(c, dir, false);
     }
@@ -781,7 +783,7 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
 {
     V3 en, ex;
     if constexpr (UNI) {      // lanes without a walk march a harmless ray (from the centre along +z): the march must end for them too
-        find_entry_exit(c, valid ? ro : v3(0.0f, 0.0f, 0.0f), valid ? rd : v3(0.0f, 0.0f, 1.0f), &en, &ex);
+        find_entry_exit(c, sel(valid, ro, v3(0.0f, 0.0f, 0.0f)), sel(valid, rd, v3(0.0f, 0.0f, 1.0f)), &en, &ex);
     } else {
         find_entry_exit(c, ro, rd, &en, &ex);
     }
@@ -1028,7 +1030,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
 #ifdef NRC_LOOP_PROFILE
         c.fee_kind = 0;
 #endif
-        find_entry_exit(c, enter ? ro : v3(0.0f, 0.0f, 0.0f), enter ? rd : v3(0.0f, 0.0f, 1.0f), &entry, &ex);
+        find_entry_exit(c, sel(enter, ro, v3(0.0f, 0.0f, 0.0f)), sel(enter, rd, v3(0.0f, 0.0f, 1.0f)), &entry, &ex);
 #ifdef NRC_LOOP_PROFILE
         c.fee_kind = 1;
 #endif
@@ -1042,7 +1044,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         if (__ballot(walking) == 0ull) break;
         bool vexit = false;
         const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
-        cur = walking ? nc : cur;
+        cur = sel(walking, nc, cur);
         walking &= !vexit;
         did_scatter |= walking;
         factor = walking ? factor * 0.5f : factor;
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform, see tile_is_empty
     const bool enter = inside & !empty;
     V3 entry = ro, ex;
-    if (__ballot(enter) != 0ull) find_entry_exit(c, enter ? ro : v3(0.0f, 0.0f, 0.0f), enter ? rd : v3(0.0f, 0.0f, 1.0f), &entry, &ex);
+    if (__ballot(enter) != 0ull) find_entry_exit(c, sel(enter, ro, v3(0.0f, 0.0f, 0.0f)), sel(enter, rd, v3(0.0f, 0.0f, 1.0f)), &entry, &ex);
     const bool entered = enter && !(sky_sdf(sc, entry) > 100000.0f);
     V3 light = v3(0, 0, 0);
     V3 cur = entry, dir = rd;
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
         if (__ballot(walking) == 0ull) break;
         bool vexit = false;
         const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
-        cur = walking ? nc : cur;
+        cur = sel(walking, nc, cur);
         walking &= !vexit;
         did_scatter |= walking;
         factor = walking ? factor * 0.5f : factor;
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
             if (__ballot(walking) == 0ull) break;
             bool vexit = false;
             const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
-            cur = walking ? nc : cur;
+            cur = sel(walking, nc, cur);
             walking &= !vexit;
             factor = walking ? factor * 0.5f : factor;
             if (__ballot(walking) == 0ull) break;
