@@ -76,6 +76,7 @@ __device__ __forceinline__ f32x16 zero16()
 // (v_pk_max_i16: negative halfs have the sign bit set; -0 -> +0).  fmaxf() on fp32 would cost two v_max_f32 per value
 // (hipcc canonicalises MFMA outputs first); rounding commutes with ReLU, so the result is identical.
 using float2v = float __attribute__((ext_vector_type(2)));
+using f32x2 = float2v;
 using half2v = _Float16 __attribute__((ext_vector_type(2)));
 using short2v = short __attribute__((ext_vector_type(2)));
 using uint4v = uint32_t __attribute__((ext_vector_type(4)));
@@ -108,6 +109,36 @@ __device__ __forceinline__ float quartic_cdf4(float x)
     float u4 = u2 * u2;
     float p = (15.0f / 16.0f) * u * ((1.0f - (2.0f / 3.0f) * u2) + (1.0f / 5.0f) * u4) + 0.5f;
     return fminf(fmaxf(p, 0.0f), 1.0f);
+}
+
+// OneBlob(4 bins, periodic, quartic kernel of radius 1/4) of one coordinate.  tiny-cuda-nn sums the kernel's CDF over three periodic
+// images at each of the five bin edges; the kernel is as wide as a bin, so only the two edges next to x are unsaturated: with
+// t = 4x, j = floor(t), A = cdf(edge j), B = cdf(edge j+1) the bin left of x's gets A, x's own B - A, the next 1 - B and the fourth 0
+// (indices mod 4).  Equal to the three-image sum over the whole range the renderer's direction coordinates take (-0.5, 1.5] up to fp32
+// rounding (tests/test_oracle_nn.py::test_oneblob_two_edge_formula_equals_the_three_image_sum); two polynomials instead of five.
+// NaN (quirk Q5): tiny-cuda-nn's fminf/fmaxf clamps give (0, 0, 0, 1).
+__device__ __forceinline__ void oneblob4_bins(float xd, float (&out)[4])
+{
+    const float t = xd * 4.0f;
+    const float jf = __builtin_floorf(t);
+    const float fr = t - jf;
+    const f32x2 u = {-fr, 1.0f - fr};
+    const f32x2 u2 = u * u;
+    const f32x2 u4 = u2 * u2;
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 p = (f32x2{15.0f / 16.0f, 15.0f / 16.0f} * u) * ((one - f32x2{2.0f / 3.0f, 2.0f / 3.0f} * u2) + f32x2{1.0f / 5.0f, 1.0f / 5.0f} * u4) + f32x2{0.5f, 0.5f};
+    const float a = fminf(fmaxf(p[0], 0.0f), 1.0f), b = fminf(fmaxf(p[1], 0.0f), 1.0f);
+    const int j = (int)jf & 3;
+    const bool bad = !(xd == xd);
+    const float own = b - a, next = 1.0f - b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float v = 0.0f;
+        v = (k == ((j + 3) & 3)) ? a : v;
+        v = (k == j) ? own : v;
+        v = (k == ((j + 1) & 3)) ? next : v;
+        out[k] = bad ? (k == 3 ? 1.0f : 0.0f) : v;
+    }
 }
 
 // Input encoding of one sample straight into the five layer-0 B-operand fragments of this lane.
@@ -145,26 +176,11 @@ __device__ __forceinline__ void encode80(const float (&x)[5], int h, half8 (&b)[
         const float t2 = sn + sn;
         b[4][2] = (half_t)(t2 * cs);
         b[4][3] = (half_t)__builtin_fmaf(-t2, sn, 1.0f);
-        // OneBlob(4 bins, periodic): C(b) = cdf(b-x) + cdf(b-x-1) + cdf(b-x+1).  The kernel radius is 1/4, so with
-        // k = rint(b-x), w = (b-x) - k only the m = 0 term of {w+k-1, w+k, w+k+1} can be unsaturated; the others are
-        // exactly 0 or 1:  C(b) = clamp(k+1, 0, 3) + (|k| <= 1 ? cdf(w) : 0).  One polynomial per bin edge instead of 3.
         const float xd = h ? x[4] : x[3];
-        float cdf[5];
+        float ob[4];
+        oneblob4_bins(xd, ob);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const float bx = (float)k * 0.25f - xd;
-            const float kk = __builtin_rintf(bx);
-            const float w = bx - kk;
-            const float sat = __builtin_amdgcn_fmed3f(kk + 1.0f, 0.0f, 3.0f);
-            cdf[k] = sat + (__builtin_fabsf(kk) <= 1.0f ? quartic_cdf4(w) : 0.0f);
-        }
-        const bool bad = !(xd == xd);          // NaN (quirk Q5): tiny-cuda-nn's fminf/fmaxf clamps give (0,0,0,1)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
-            const float v = right - cdf[k];
-            b[4][4 + k] = (half_t)(bad ? (k == 3 ? 1.0f : 0.0f) : v);
-        }
+        for (int k = 0; k < 4; k++) b[4][4 + k] = (half_t)ob[k];
     }
 }
 
@@ -200,22 +216,10 @@ __device__ __forceinline__ half8 encode80_frag(const float (&x)[5], int h)
         b[2] = (half_t)(t2 * cs);
         b[3] = (half_t)__builtin_fmaf(-t2, sn, 1.0f);
         const float xd = h ? x[4] : x[3];
-        float cdf[5];
+        float ob[4];
+        oneblob4_bins(xd, ob);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const float bx = (float)k * 0.25f - xd;
-            const float kk = __builtin_rintf(bx);
-            const float w = bx - kk;
-            const float sat = __builtin_amdgcn_fmed3f(kk + 1.0f, 0.0f, 3.0f);
-            cdf[k] = sat + (__builtin_fabsf(kk) <= 1.0f ? quartic_cdf4(w) : 0.0f);
-        }
-        const bool bad = !(xd == xd);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
-            const float v = right - cdf[k];
-            b[4 + k] = (half_t)(bad ? (k == 3 ? 1.0f : 0.0f) : v);
-        }
+        for (int k = 0; k < 4; k++) b[4 + k] = (half_t)ob[k];
     }
     return b;
 }

@@ -262,3 +262,47 @@ def test_hashgrid_backward_and_sparse_adam(orc):
     assert (w1[nn.n_mlp:][touched] != w0[nn.n_mlp:][touched]).mean() > 0.99
     assert abs(abs(w1[nn.n_mlp + k] - w0[nn.n_mlp + k]) - 0.01) < 1e-3              # first Adam step = lr * sign(g)
     assert np.array_equal(np.array(nn.buffer(2))[nn.n_mlp:][~touched], np.zeros((~touched).sum(), np.float32))
+
+
+def oneblob4_two_edges(x):
+    """The OneBlob(4) bins the HIP kernels compute (nrc_mlp.hip, oneblob4_bins): a quartic kernel of radius 1/4 around x overlaps only
+    the two bin edges next to it, so two CDF values A = cdf(left edge), B = cdf(right edge) give all four bins -- the bin left of x's
+    gets A, x's own B - A, the next 1 - B, the fourth 0 (indices mod 4: the encoding is periodic)."""
+    x = np.asarray(x, np.float32)
+    t = (x * np.float32(4.0)).astype(np.float32)
+    j = np.floor(t).astype(np.float32)
+    fr = (t - j).astype(np.float32)
+
+    def q(u):
+        u = u.astype(np.float32)
+        u2 = (u * u).astype(np.float32)
+        u4 = (u2 * u2).astype(np.float32)
+        p = (np.float32(15.0 / 16.0) * u * ((np.float32(1.0) - np.float32(2.0 / 3.0) * u2) + np.float32(1.0 / 5.0) * u4) + np.float32(0.5)).astype(np.float32)
+        return np.clip(p, 0.0, 1.0).astype(np.float32)
+
+    a, b = q(-fr), q(np.float32(1.0) - fr)
+    ji = j.astype(np.int64) & 3
+    out = np.zeros(x.shape + (4,), np.float32)
+    idx = np.arange(x.size)
+    flat = out.reshape(-1, 4)
+    flat[idx, (ji.reshape(-1) + 3) & 3] = a.reshape(-1)
+    flat[idx, ji.reshape(-1)] = (b - a).reshape(-1)
+    flat[idx, (ji.reshape(-1) + 1) & 3] = (np.float32(1.0) - b).reshape(-1)
+    return out
+
+
+def test_oneblob_two_edge_formula_equals_the_three_image_sum(orc):
+    """tiny-cuda-nn's OneBlob sums the kernel's CDF over three periodic images per bin edge (the oracle's statement); over the whole
+    range the renderer's direction coordinates take, theta / pi + 0.5 in (-0.5, 1.5], that equals the two-edge form to fp32 rounding"""
+    nn = orc.nn_create()
+    xs = np.concatenate([np.linspace(-0.5, 1.5, 20001, dtype=np.float32)[1:], np.float32([0.0, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, -0.25, 0.999999, 1e-7])])
+    q = np.zeros((xs.size, 5), np.float32)
+    q[:, 3] = xs
+    q[:, 4] = xs[::-1]
+    e = nn.encode(q)[:, 72:]                       # fp16 features
+    for got, ref in ((oneblob4_two_edges(xs), e[:, :4]), (oneblob4_two_edges(xs[::-1]), e[:, 4:])):
+        got16 = got.astype(np.float16).astype(np.float32)
+        off = got16 != ref
+        assert off.mean() < 2e-2                                       # fp32 rounding differences (~1e-6) tip one fp16 rounding in a hundred
+        assert np.abs(got16 - ref).max() <= 2.0 ** -11                 # ... by one fp16 ulp of a value below 1
+        assert np.abs(got - ref).max() < 2.0 ** -11                    # and the fp32 values sit inside that rounding interval
