@@ -101,16 +101,6 @@ __device__ __forceinline__ void relu_pack(const f32x16& acc, half8& lo, half8& h
     hi = __builtin_bit_cast(half8, h);
 }
 
-// tiny-cuda-nn one_blob quartic kernel CDF (radius 1/4): fminf(fmaxf(.,0),1) maps NaN to 0
-__device__ __forceinline__ float quartic_cdf4(float x)
-{
-    float u = x * 4.0f;
-    float u2 = u * u;
-    float u4 = u2 * u2;
-    float p = (15.0f / 16.0f) * u * ((1.0f - (2.0f / 3.0f) * u2) + (1.0f / 5.0f) * u4) + 0.5f;
-    return fminf(fmaxf(p, 0.0f), 1.0f);
-}
-
 // OneBlob(4 bins, periodic, quartic kernel of radius 1/4) of one coordinate.  tiny-cuda-nn sums the kernel's CDF over three periodic
 // images at each of the five bin edges; the kernel is as wide as a bin, so only the two edges next to x are unsaturated: with
 // t = 4x, j = floor(t), A = cdf(edge j), B = cdf(edge j+1) the bin left of x's gets A, x's own B - A, the next 1 - B and the fourth 0
@@ -667,24 +657,7 @@ __device__ __forceinline__ float tri_wave(float x, int f)      // TriangleWave: 
     return fabsf(r - 1.0f);
 }
 
-__device__ __forceinline__ void oneblob4(float xd, float (&out)[4])
-{
-    float cdf[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const float bx = (float)k * 0.25f - xd;
-        const float kk = __builtin_rintf(bx);
-        const float w = bx - kk;
-        const float sat = __builtin_amdgcn_fmed3f(kk + 1.0f, 0.0f, 3.0f);
-        cdf[k] = sat + (__builtin_fabsf(kk) <= 1.0f ? quartic_cdf4(w) : 0.0f);
-    }
-    const bool bad = !(xd == xd);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float right = (k == 3) ? cdf[0] + 1.0f : cdf[k + 1];
-        out[k] = bad ? (k == 3 ? 1.0f : 0.0f) : right - cdf[k];
-    }
-}
+__device__ __forceinline__ void oneblob4(float xd, float (&out)[4]) { oneblob4_bins(xd, out); }
 
 // one thread per sample; features in tiny-cuda-nn order: position encoding (dims 0-2) then direction encoding (dims 3-4).
 // POS / DIR are compile-time so that every feature has a static slot.
