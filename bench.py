@@ -170,7 +170,8 @@ def main():
         try:
             parallel.attach_gradient_allreduce(nrc, world)
             r_, w_ = nrc.CommInfo()              # what ncclCommUserRank / ncclCommCount say
-            exchange = dict(path="native (nrc_cache_comm_init -> ncclAllReduce on the training stream)", rccl_rank=r_, rccl_ranks=w_)
+            exchange = dict(path="native (nrc_cache_comm_init -> ncclAllReduce on the training stream)", rccl_rank=r_, rccl_ranks=w_,
+                            grid_gradient_lists=nrc.CommSparse())
             if w_ != world:
                 raise RuntimeError("RCCL communicator reports %d ranks, expected %d" % (w_, world))
         except RuntimeError as e:

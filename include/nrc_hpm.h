@@ -120,6 +120,18 @@ int nrc_comm_unique_id(void* out128);
 int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world);
 /* rank / size as the library's own RCCL communicator reports them (ncclCommUserRank / ncclCommCount); world = 0: none */
 int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world);
+/* HashGrid models (posID 0): the trainable table's gradient -- 57 MB dense, a few per cent of it touched by a batch -- is
+ * exchanged as all-gathered (entry, fp16x2 value) lists that every rank adds in rank order (replicas stay bit-identical), the
+ * matrix gradients and the loss cell by ncclAllReduce as before.  Chosen at nrc_cache_comm_init when world x list capacity
+ * (trainBatchSize x 16 levels x 8 corners, at most the table) < 2 x table entries, i.e. when the padded all-gather moves less
+ * than the ring all-reduce; environment NRC_DENSE_GRID_EXCHANGE=1 / NRC_SPARSE_GRID_EXCHANGE=1 force either.  nrc_cache_comm_sparse: 1 when the list exchange is the one in use.  The two debug entry points expose its
+ * halves on one device (tests): the list of the last nrc_cache_backward -- words {count, 0, (entry, value) x capacity},
+ * padding entries 0xffffffff, list_words >= 2 + 2 * nrc_cache_grid_list_capacity() -- and the gradient vector's table part
+ * := sum of n_lists such lists (2 + 2 * capacity words apart), added in list order. */
+int nrc_cache_comm_sparse(nrc_cache_t* c);
+size_t nrc_cache_grid_list_capacity(nrc_cache_t* c);
+int nrc_cache_grid_grad_pack(nrc_cache_t* c, uint32_t* host_list, size_t list_words);
+int nrc_cache_grid_grad_apply(nrc_cache_t* c, const uint32_t* host_lists, uint32_t n_lists);
 /* multi-GPU: the loss normaliser of InferAndTrain's train batches becomes 3 * trainBatchSize * factor (factor = world size) */
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor);
 /* move the cache's work to another hipStream_t (Init binds the first one) */

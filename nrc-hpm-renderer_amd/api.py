@@ -66,7 +66,8 @@ ABI_SYMBOLS = [
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
-    "nrc_comm_unique_id", "nrc_cache_comm_init",
+    "nrc_comm_unique_id", "nrc_cache_comm_init", "nrc_cache_comm_sparse", "nrc_cache_grid_list_capacity",
+    "nrc_cache_grid_grad_pack", "nrc_cache_grid_grad_apply",
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
     "nrc_cache_get_step", "nrc_cache_set_step",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
@@ -104,6 +105,7 @@ def load_library():
     L.nrc_cache_get_infer_batch_count.restype = C.c_size_t
     L.nrc_cache_get_train_batch_count.restype = C.c_size_t
     L.nrc_cache_get_infer_batch_size.restype = C.c_uint32
+    L.nrc_cache_grid_list_capacity.restype = C.c_size_t
     L.nrc_cache_get_train_batch_size.restype = C.c_uint32
     L.nrc_cache_grad_ptr.restype = C.c_void_p
     L.nrc_cache_loss_ptr.restype = C.c_void_p
@@ -328,6 +330,23 @@ class NeuralRadianceCache:
         r, w = C.c_int(0), C.c_int(0)
         _check(self.L.nrc_cache_comm_info(self.h, C.byref(r), C.byref(w)))
         return r.value, w.value
+
+    def CommSparse(self):
+        """True when the HashGrid table gradient travels as (entry, value) lists (native exchange of a posID 0 model)"""
+        return bool(self.L.nrc_cache_comm_sparse(self.h))
+
+    def GridGradPack(self):
+        """(debug) the table gradient of the last Backward as the exchange list: uint32 words {count, 0, (entry, half2 bits) x
+        capacity}, padding entries 0xffffffff"""
+        cap = int(self.L.nrc_cache_grid_list_capacity(self.h))
+        out = np.zeros(2 + 2 * cap, np.uint32)
+        _check(self.L.nrc_cache_grid_grad_pack(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)))
+        return out
+
+    def GridGradApply(self, lists):
+        """(debug) gradient vector's table part := sum of the lists (GridGradPack layout), added in the order given"""
+        v = np.ascontiguousarray(np.stack(lists), np.uint32)
+        _check(self.L.nrc_cache_grid_grad_apply(self.h, v.ctypes.data_as(C.c_void_p), C.c_uint32(v.shape[0])))
 
     def SetLossNormFactor(self, factor):
         _check(self.L.nrc_cache_set_loss_norm_factor(self.h, C.c_uint32(factor)))

@@ -33,6 +33,9 @@ struct Rccl {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     decltype(&ncclCommCount) comm_count = nullptr;
     decltype(&ncclCommUserRank) comm_user_rank = nullptr;
@@ -49,6 +52,9 @@ struct Rccl {
             x.comm_init_rank = (decltype(x.comm_init_rank))dlsym(x.handle, "ncclCommInitRank");
             x.comm_destroy = (decltype(x.comm_destroy))dlsym(x.handle, "ncclCommDestroy");
             x.all_reduce = (decltype(x.all_reduce))dlsym(x.handle, "ncclAllReduce");
+            x.all_gather = (decltype(x.all_gather))dlsym(x.handle, "ncclAllGather");
+            x.group_start = (decltype(x.group_start))dlsym(x.handle, "ncclGroupStart");
+            x.group_end = (decltype(x.group_end))dlsym(x.handle, "ncclGroupEnd");
             x.error_string = (decltype(x.error_string))dlsym(x.handle, "ncclGetErrorString");
             x.comm_count = (decltype(x.comm_count))dlsym(x.handle, "ncclCommCount");
             x.comm_user_rank = (decltype(x.comm_user_rank))dlsym(x.handle, "ncclCommUserRank");
@@ -191,7 +197,11 @@ public:
                            train_batch_size_ * loss_norm_factor_, st);
             // the one exchange step of the sharded path: sum the fp32 gradient vector + loss cell over the ranks (103 KB,
             // latency-bound) on the training stream; every rank then applies the identical optimizer step
-            if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
+            // A HashGrid model's vector is 57 MB of which a batch touches a few per cent: its table part travels as all-gathered
+            // (entry, value) lists, added in rank order (Mlp::grid_grad_pack / grid_grad_apply); NRC_DENSE_GRID_EXCHANGE=1 keeps
+            // the dense all-reduce.
+            if (comm_ && sparse_grid_) exchange_sparse(st);
+            else if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
                                                                ncclSum, comm_, st), "ncclAllReduce");
             if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
             push_loss(st);
@@ -202,6 +212,52 @@ public:
             mlp_->optimizer_step(st);
         }
     }
+
+    void ensure_grid_lists(uint32_t n_lists)
+    {
+        const uint32_t cap = mlp_->grid_list_capacity(train_batch_size_);
+        if (cap == grid_cap_ && n_lists <= grid_lists_) return;
+        NRC_HIP(hipDeviceSynchronize());
+        if (d_grid_send_) NRC_HIP(hipFree(d_grid_send_));
+        if (d_grid_recv_) NRC_HIP(hipFree(d_grid_recv_));
+        grid_cap_ = cap;
+        grid_lists_ = n_lists;
+        NRC_HIP(hipMalloc(&d_grid_send_, Mlp::grid_list_words(cap) * 4));
+        NRC_HIP(hipMalloc(&d_grid_recv_, Mlp::grid_list_words(cap) * 4 * n_lists));
+    }
+    void exchange_sparse(hipStream_t st)
+    {
+        Rccl& r = Rccl::get();
+        if (!r.all_gather || !r.group_start || !r.group_end) fail("librccl lacks ncclAllGather / ncclGroupStart / ncclGroupEnd");
+        ensure_grid_lists((uint32_t)comm_world_);
+        mlp_->grid_grad_pack(d_grid_send_, grid_cap_, st);
+        r.check(r.group_start(), "ncclGroupStart");
+        r.check(r.all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), mlp_->n_mlp_params(), ncclFloat, ncclSum, comm_, st), "ncclAllReduce");
+        r.check(r.all_reduce(mlp_->loss_ptr(), mlp_->loss_ptr(), 2, ncclFloat, ncclSum, comm_, st), "ncclAllReduce");
+        r.check(r.all_gather(d_grid_send_, d_grid_recv_, Mlp::grid_list_words(grid_cap_), ncclUint32, comm_, st), "ncclAllGather");
+        r.check(r.group_end(), "ncclGroupEnd");
+        mlp_->grid_grad_apply(d_grid_recv_, (uint32_t)comm_world_, grid_cap_, st);
+    }
+    // test surface of the sparse exchange (tests/test_gpu_mlp.py): the list of the last backward() on the host; lists applied in order
+    size_t grid_pack_host(uint32_t* host_list, size_t cap_words)
+    {
+        ensure_grid_lists(1);
+        if (cap_words < Mlp::grid_list_words(grid_cap_)) fail("grid_pack_host: list buffer too small");
+        mlp_->grid_grad_pack(d_grid_send_, grid_cap_, stream_);
+        NRC_HIP(hipMemcpyAsync(host_list, d_grid_send_, Mlp::grid_list_words(grid_cap_) * 4, hipMemcpyDeviceToHost, stream_));
+        NRC_HIP(hipStreamSynchronize(stream_));
+        if (host_list[0] > grid_cap_) fail("grid_pack_host: the batch touched more entries than a train batch can (backward on more than trainBatchSize samples?)");
+        return grid_cap_;
+    }
+    void grid_apply_host(const uint32_t* host_lists, uint32_t n_lists)
+    {
+        ensure_grid_lists(n_lists);
+        NRC_HIP(hipMemcpyAsync(d_grid_recv_, host_lists, Mlp::grid_list_words(grid_cap_) * 4 * n_lists, hipMemcpyHostToDevice, stream_));
+        mlp_->grid_grad_apply(d_grid_recv_, n_lists, grid_cap_, stream_);
+        NRC_HIP(hipStreamSynchronize(stream_));
+    }
+    uint32_t grid_list_capacity() const { return mlp_->has_grid() ? mlp_->grid_list_capacity(train_batch_size_) : 0u; }
+    bool sparse_grid_exchange() const { return comm_ != nullptr && sparse_grid_; }
 
     // m_Loss = trainer->loss(*ctx) after every training step (src/NeuralRadianceCache.cu:154) is a device->host sync in the
     // reference.  Here a one-thread kernel behind every step stores {loss, step number} with one 8-byte store into host-mapped
@@ -243,6 +299,14 @@ public:
         std::memcpy(&id, unique_id, sizeof(id));
         Rccl::get().check(Rccl::get().comm_init_rank(&comm_, world, id, rank), "ncclCommInitRank");
         loss_norm_factor_ = (uint32_t)world;
+        comm_world_ = world;
+        // lists pay when the padded all-gather (world x capacity entries into every rank) moves less than the ring all-reduce of
+        // the dense table gradient (2 x entries through every rank): a rank's share of a sharded frame's train batch, not eight
+        // full 16 384-ray batches.  NRC_DENSE_GRID_EXCHANGE=1 / NRC_SPARSE_GRID_EXCHANGE=1 force either.
+        sparse_grid_ = mlp_->has_grid() &&
+                       (unsigned long long)world * mlp_->grid_list_capacity(train_batch_size_) < 2ull * mlp_->grid_entries();
+        if (getenv("NRC_SPARSE_GRID_EXCHANGE")) sparse_grid_ = mlp_->has_grid();
+        if (getenv("NRC_DENSE_GRID_EXCHANGE")) sparse_grid_ = false;
     }
     // what the communicator itself reports (bench.py prints it: proof that the native exchange path is the one in use)
     void comm_info(int* rank, int* world)
@@ -278,6 +342,10 @@ private:
     nrc_grad_hook hook_ = nullptr;
     void* hook_user_ = nullptr;
     ncclComm_t comm_ = nullptr;
+    int comm_world_ = 0;
+    bool sparse_grid_ = false;              // HashGrid table gradient exchanged as (entry, value) lists
+    uint32_t *d_grid_send_ = nullptr, *d_grid_recv_ = nullptr;
+    uint32_t grid_cap_ = 0, grid_lists_ = 0;
     uint32_t loss_norm_factor_ = 1;
     unsigned long long* h_loss_ = nullptr;    // pinned, host-mapped: LossCell written by k_publish_loss
     unsigned long long* d_loss_cell_ = nullptr;
@@ -1251,6 +1319,18 @@ int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world)
 {
     NRC_REQUIRE(c); NRC_REQUIRE(rank); NRC_REQUIRE(world);
     return guarded([&] { c->impl.comm_info(rank, world); });
+}
+int nrc_cache_comm_sparse(nrc_cache_t* c) { return c && c->impl.sparse_grid_exchange() ? 1 : 0; }
+size_t nrc_cache_grid_list_capacity(nrc_cache_t* c) { return c ? c->impl.grid_list_capacity() : 0; }
+int nrc_cache_grid_grad_pack(nrc_cache_t* c, uint32_t* host_list, size_t list_words)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(host_list);
+    return guarded([&] { c->impl.grid_pack_host(host_list, list_words); });
+}
+int nrc_cache_grid_grad_apply(nrc_cache_t* c, const uint32_t* host_lists, uint32_t n_lists)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(host_lists); NRC_REQUIRE(n_lists > 0);
+    return guarded([&] { c->impl.grid_apply_host(host_lists, n_lists); });
 }
 int nrc_cache_set_loss_norm_factor(nrc_cache_t* c, uint32_t factor)
 {

@@ -35,6 +35,15 @@ public:
     float* grad_ptr() { return d_grad_; }
     float* loss_ptr() { return d_loss_; }
     float* buffer(int which);    // 0 w, 1 ema, 2 m, 3 v, 4 grad
+    // sparse exchange of the HashGrid table gradient (nrc_mlp.hip, k_grid_pack): the gradient vector is
+    // [n_mlp_params() matrix gradients][2 per table entry][2-word loss cell]
+    bool has_grid() const { return hash_; }
+    uint32_t n_mlp_params() const { return n_mlp_; }
+    uint32_t grid_entries() const { return n_grid_entries_; }
+    uint32_t grid_list_capacity(uint32_t n_batch) const;
+    static size_t grid_list_words(uint32_t cap) { return 2 + 2 * (size_t)cap; }
+    void grid_grad_pack(uint32_t* d_list, uint32_t cap, hipStream_t s);
+    void grid_grad_apply(const uint32_t* d_lists, uint32_t n_lists, uint32_t cap, hipStream_t s);
     uint32_t step = 0;
     static constexpr float kLossScale = 128.0f;
 

@@ -29,3 +29,9 @@ def test_native_rccl_exchange_under_torch_distributed_run(torch_gpu, tmp_path):
     assert res["finite"] and res["step"] == 5 and len(res["losses"]) == 5
     assert res["native_equals_no_communicator"]
     assert res["native_equals_hook"]
+    # HashGrid model: the sparse list exchange is the one in use (and not for the dense run or the model without a table), it
+    # trains to the same losses and weights as the dense all-reduce up to the run-to-run noise of the packed-fp16 atomics
+    assert res["hashgrid_sparse_flags"] == [True, False, False] and res["hashgrid_finite"]
+    ls, ld = res["hashgrid_losses_sparse"], res["hashgrid_losses_dense"]
+    assert len(ls) == 5 and all(abs(a - b) <= 2e-2 * abs(b) for a, b in zip(ls, ld)), (ls, ld)
+    assert res["hashgrid_weight_rel_diff"] < 1e-2

@@ -397,6 +397,45 @@ def test_hashgrid_model_matches_oracle(api, orc, torch_gpu, dir_id, width, depth
     c.Destroy()
 
 
+@pytest.mark.parametrize("log2", [12, 19], ids=["2^12", "reference-default-2^19"])
+def test_hashgrid_sparse_exchange_lists_add_up_in_rank_order(api, torch_gpu, log2):
+    """the multi-GPU exchange of the table gradient on one device: three ranks' backward passes (their shard of the batch against
+    the global normaliser) packed as (entry, fp16x2) lists; a list reproduces the rank's dense table gradient exactly, holds every
+    entry once, and the lists applied in rank order give ((0 + g0) + g1) + g2 to the last bit -- what every replica computes"""
+    c = api.NeuralRadianceCache(api.AppConfig(pos_id=0, hashgrid_log2_size=log2, log2_train_batch_size=11))
+    n, ranks = 2048, 3
+    rng = np.random.default_rng(23)
+    n_mlp = 64 * 48 + 5 * 64 * 64 + 3 * 64
+    n_entries = (c.ParamCount() - n_mlp) // 2
+    dense, lists = [], []
+    for r in range(ranks):
+        x = rng.random((n, 5), dtype=np.float32)
+        t = rng.random((n, 3), dtype=np.float32)
+        c.Backward(torch_gpu.from_numpy(x).cuda(), torch_gpu.from_numpy(t).cuda(), nNorm=ranks * n)
+        g = c.GetParams(4)
+        lst = c.GridGradPack()
+        count, cap = int(lst[0]), (lst.size - 2) // 2
+        assert cap == min(n_entries, n * 16 * 8) and 0 < count <= cap
+        ent, val = lst[2::2], lst[3::2]
+        assert (ent[count:] == 0xFFFFFFFF).all() and (ent[:count] < n_entries).all()
+        assert np.unique(ent[:count]).size == count
+        rebuilt = np.zeros((n_entries, 2), np.float32)
+        rebuilt[ent[:count]] = val[:count].copy().view(np.float16).reshape(-1, 2).astype(np.float32)
+        assert np.array_equal(rebuilt.reshape(-1), g[n_mlp:])
+        assert count < cap          # the coarse levels' samples share corners: fewer entries than (sample, level, corner) triples
+        dense.append(g)
+        lists.append(lst)
+    c.GridGradApply(lists)
+    total = c.GetParams(4)
+    expect = np.zeros(2 * n_entries, np.float32)
+    for g in dense:
+        expect = expect + g[n_mlp:]
+    assert np.array_equal(total[n_mlp:], expect)
+    assert np.array_equal(total[:n_mlp], dense[-1][:n_mlp])       # the matrix part is not the lists' business
+    assert not np.array_equal(expect, dense[0][n_mlp:])
+    c.Destroy()
+
+
 def test_hashgrid_default_size_trains(api, torch_gpu):
     """the reference's actual default: 2^19 entries per hashed level = 14.2 M table parameters (57 MB fp32)"""
     c = api.NeuralRadianceCache(api.AppConfig(pos_id=0))

@@ -14,9 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def run(api, sc, parallel, scene, cam, W, H, rank, world, frames, exchange):
+def run(api, sc, parallel, scene, cam, W, H, rank, world, frames, exchange, **model):
     """exchange: None | "native" | "hook"."""
-    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=10, log2_infer_batch_size=14)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=10, log2_infer_batch_size=14, **model)
     nrc = api.NeuralRadianceCache(cfg)
     if exchange == "native":
         parallel.attach_gradient_allreduce(nrc, world, native=True)
@@ -31,7 +31,8 @@ def run(api, sc, parallel, scene, cam, W, H, rank, world, frames, exchange):
         ren.Render(None, True)
         losses.append(nrc.GetLoss())
     img = ren.GetImage().cpu().numpy().copy()
-    out = dict(losses=losses, w=nrc.GetParams(0), ema=nrc.GetParams(1), img=img, comm=nrc.CommInfo(), step=nrc.GetStep())
+    out = dict(losses=losses, w=nrc.GetParams(0), ema=nrc.GetParams(1), img=img, comm=nrc.CommInfo(), step=nrc.GetStep(),
+               sparse=nrc.CommSparse())
     ren.Destroy()
     nrc.Destroy()
     return out
@@ -55,6 +56,17 @@ def main():
                step=native["step"], finite=bool(np.isfinite(native["img"]).all() and np.isfinite(native["losses"]).all()),
                native_equals_hook=bool(np.array_equal(native["w"], hook["w"]) and native["losses"] == hook["losses"]
                                        and np.array_equal(native["img"], hook["img"])))
+    # HashGrid model (the reference's default encoding): the table gradient travels as all-gathered (entry, value) lists; its
+    # packed-fp16 atomics sum in a different order every run, so the dense exchange is the reference only up to that noise
+    hg = dict(pos_id=0, hashgrid_log2_size=14)
+    sparse = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", **hg)
+    os.environ["NRC_DENSE_GRID_EXCHANGE"] = "1"
+    dense = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", **hg)
+    del os.environ["NRC_DENSE_GRID_EXCHANGE"]
+    res["hashgrid_sparse_flags"] = [bool(sparse["sparse"]), bool(dense["sparse"]), bool(native["sparse"])]
+    res["hashgrid_losses_sparse"], res["hashgrid_losses_dense"] = sparse["losses"], dense["losses"]
+    res["hashgrid_finite"] = bool(np.isfinite(sparse["img"]).all() and np.isfinite(sparse["losses"]).all())
+    res["hashgrid_weight_rel_diff"] = float(np.linalg.norm(sparse["w"] - dense["w"]) / np.linalg.norm(dense["w"]))
     if world == 1:
         plain = run(api, sc, parallel, scene, cam, W, H, 0, 1, frames, None)
         res["native_equals_no_communicator"] = bool(np.array_equal(native["w"], plain["w"]) and np.array_equal(native["ema"], plain["ema"])
