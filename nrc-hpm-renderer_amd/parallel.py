@@ -37,6 +37,43 @@ def shard_train_batch(n_global, rank, world):
     return slice(rank * per, (rank + 1) * per)
 
 
+# ---- the list exchange of a HashGrid model's table gradient (nrc_mlp.hip: k_grid_pack / k_grid_apply), host restatement.
+# The product runs it on the device inside the library (ncclAllGather); these helpers state the protocol for the gloo tests
+# and check the device kernels (tests/test_gpu_mlp.py).
+GRID_LIST_PADDING = 0xFFFFFFFF
+
+
+def grid_list_capacity(n_batch, n_entries, levels=16):
+    """list slots a rank needs: one per (sample, level, corner) at most, never more than the table"""
+    return min(n_batch * levels * 8, n_entries)
+
+
+def pack_grid_list(grad16_words, cap):
+    """uint32 words {count, 0, (entry, half2 bits) x cap}: the entries whose packed fp16 gradient word is non-zero"""
+    import numpy as np
+    w = np.asarray(grad16_words, np.uint32)
+    ent = np.flatnonzero(w).astype(np.uint32)
+    if ent.size > cap:
+        raise ValueError("the batch touched %d entries, capacity %d" % (ent.size, cap))
+    out = np.full(2 + 2 * cap, GRID_LIST_PADDING, np.uint32)
+    out[0], out[1] = ent.size, 0
+    out[2:2 + 2 * ent.size:2] = ent
+    out[3:3 + 2 * ent.size:2] = w[ent]
+    return out
+
+
+def apply_grid_lists(lists, n_entries):
+    """fp32 table gradient [n_entries * 2] := the lists' values added in list (= rank) order, starting from zero"""
+    import numpy as np
+    g = np.zeros((n_entries, 2), np.float32)
+    for lst in lists:
+        lst = np.asarray(lst, np.uint32)
+        count = int(lst[0])
+        ent, val = lst[2:2 + 2 * count:2], lst[3:3 + 2 * count:2]
+        g[ent] = g[ent] + val.copy().view(np.float16).reshape(-1, 2).astype(np.float32)      # an entry occurs once per list
+    return g.reshape(-1)
+
+
 def attach_gradient_allreduce(nrc, world, group=None, native=True):
     """Installs the exchange step of the training path on a NeuralRadianceCache: the loss normaliser becomes the global
     batch (3 * trainBatchSize * world) and the fp32 gradient vector + loss cell are all-reduced (sum) between backward and

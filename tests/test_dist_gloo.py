@@ -64,3 +64,55 @@ def test_sharded_gradient_allreduce_equals_full_batch():
     assert abs(res["loss"] - res["loss_full"]) < 1e-5 * max(1.0, abs(res["loss_full"]))
     assert res["replicas_equal"]
     assert res["w_err"] < 1e-5
+
+
+def _list_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nrc_hpm_renderer_amd import parallel
+    n_entries, n_batch = 1 << 16, 64
+    cap = parallel.grid_list_capacity(n_batch, n_entries)
+    rng = np.random.default_rng(100 + rank)
+    # a rank's packed fp16x2 table gradient: a few thousand touched entries, half of them shared with the other rank
+    shared = np.random.default_rng(7).choice(n_entries, 3000, replace=False)
+    own = rng.choice(n_entries, 3000, replace=False)
+    g16 = np.zeros((n_entries, 2), np.float16)
+    for idx in (shared, own):
+        g16[idx] = (rng.standard_normal((idx.size, 2)) * 3.0).astype(np.float16)
+    words = g16.view(np.uint32).reshape(-1)
+    mine = parallel.pack_grid_list(words, cap)
+    gathered = [torch.zeros(mine.size, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(mine.view(np.int32)))          # the padded all-gather of the product
+    lists = [t.numpy().view(np.uint32) for t in gathered]
+    total = parallel.apply_grid_lists(lists, n_entries)
+    dense = torch.from_numpy(g16.astype(np.float32).reshape(-1).copy())
+    dist.all_reduce(dense, op=dist.ReduceOp.SUM)                               # what the dense exchange computes
+    everyone = [torch.zeros(total.size) for _ in range(world)]
+    dist.all_gather(everyone, torch.from_numpy(total))
+    if rank == 0:
+        q.put(dict(count=int(mine[0]), cap=cap, padding_ok=bool((mine[2 + 2 * int(mine[0])::2] == parallel.GRID_LIST_PADDING).all()),
+                   equals_dense=bool(np.array_equal(total, dense.numpy())),
+                   replicas_equal=bool(all(torch.equal(everyone[0], e) for e in everyone)),
+                   touched=int(np.count_nonzero(total.reshape(-1, 2).any(axis=1)))))
+    dist.destroy_process_group()
+
+
+def test_grid_gradient_list_exchange_equals_dense_allreduce():
+    """HashGrid table gradient as all-gathered (entry, value) lists added in rank order: for two ranks the result equals the
+    dense sum to the last bit (a + b in either order), and every replica holds the same vector"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_list_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert 5000 < res["count"] <= 6000 and res["cap"] == 64 * 128 and res["padding_ok"]
+    assert res["equals_dense"] and res["replicas_equal"]
+    assert 8000 < res["touched"] <= 9000

@@ -402,6 +402,7 @@ def test_hashgrid_sparse_exchange_lists_add_up_in_rank_order(api, torch_gpu, log
     """the multi-GPU exchange of the table gradient on one device: three ranks' backward passes (their shard of the batch against
     the global normaliser) packed as (entry, fp16x2) lists; a list reproduces the rank's dense table gradient exactly, holds every
     entry once, and the lists applied in rank order give ((0 + g0) + g1) + g2 to the last bit -- what every replica computes"""
+    from nrc_hpm_renderer_amd import parallel          # the host statement of the protocol (tests/test_dist_gloo.py runs it on two ranks)
     c = api.NeuralRadianceCache(api.AppConfig(pos_id=0, hashgrid_log2_size=log2, log2_train_batch_size=11))
     n, ranks = 2048, 3
     rng = np.random.default_rng(23)
@@ -422,6 +423,10 @@ def test_hashgrid_sparse_exchange_lists_add_up_in_rank_order(api, torch_gpu, log
         rebuilt = np.zeros((n_entries, 2), np.float32)
         rebuilt[ent[:count]] = val[:count].copy().view(np.float16).reshape(-1, 2).astype(np.float32)
         assert np.array_equal(rebuilt.reshape(-1), g[n_mlp:])
+        host = parallel.pack_grid_list(g[n_mlp:].astype(np.float16).view(np.uint32), cap)      # same set, the device's order is free
+        assert int(host[0]) == count
+        order = np.argsort(ent[:count])
+        assert np.array_equal(ent[:count][order], host[2:2 + 2 * count:2]) and np.array_equal(val[:count][order], host[3:3 + 2 * count:2])
         assert count < cap          # the coarse levels' samples share corners: fewer entries than (sample, level, corner) triples
         dense.append(g)
         lists.append(lst)
@@ -431,6 +436,7 @@ def test_hashgrid_sparse_exchange_lists_add_up_in_rank_order(api, torch_gpu, log
     for g in dense:
         expect = expect + g[n_mlp:]
     assert np.array_equal(total[n_mlp:], expect)
+    assert np.array_equal(parallel.apply_grid_lists(lists, n_entries), expect)
     assert np.array_equal(total[:n_mlp], dense[-1][:n_mlp])       # the matrix part is not the lists' business
     assert not np.array_equal(expect, dense[0][n_mlp:])
     c.Destroy()
