@@ -204,12 +204,17 @@ public:
             else if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
                                                                ncclSum, comm_, st), "ncclAllReduce");
             if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
-            push_loss(st);
             // the two inference weight sets alternate with every optimizer step: step 0 overwrites the set the PREVIOUS
             // inference pass read, step 1 the set the CURRENT pass is reading, later steps only sets no pass reads any more
             if (b == 0 && ev_infer_prev) NRC_HIP(hipStreamWaitEvent(st, ev_infer_prev, 0));
             if (b == 1 && ev_infer_cur) NRC_HIP(hipStreamWaitEvent(st, ev_infer_cur, 0));
-            mlp_->optimizer_step(st);
+            // the step's loss is published by the optimizer's own launch where it can be (Mlp::optimizer_step)
+            loss_pushed_++;
+            if (!mlp_->optimizer_step(st, loss_pushed_, d_loss_cell_)) {
+                hipLaunchKernelGGL(k_publish_loss, dim3(1), dim3(1), 0, st, (const float*)mlp_->loss_ptr(), loss_pushed_, d_loss_cell_);
+                NRC_HIP(hipGetLastError());
+            }
+            NRC_HIP(hipEventRecord(ev_loss_, st));
         }
     }
 

@@ -1520,16 +1520,20 @@ __global__ __launch_bounds__(256) void k_reduce_grads(const float* __restrict__ 
 struct AdamArgs {
     float lr_t, inv_loss_scale, ema_old, ema_new, ema_div;
 };
-__global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
-                           float* __restrict__ v, const float* __restrict__ grad, uint32_t n, uint32_t n_matrix, AdamArgs a)
+// (no contraction in the two update rules: k_adam_ema / k_sgd_ema and the one-launch k_opt_pack then round identically, and like the
+// CPU oracle, which is built with -ffp-contract=off)
+#pragma clang fp contract(off)
+__device__ __forceinline__ void adam_ema_update(uint32_t i, float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
+                                                float* __restrict__ v, const float* __restrict__ grad, uint32_t n_matrix,
+                                                const AdamArgs& a, float* w_new, float* ema_new)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, l2 = 1e-8f;
     float wi = w[i];
     const float graw = grad[i];
     if (i >= n_matrix && graw == 0.0f) {      // tiny-cuda-nn: grid entries with a zero gradient keep weight and moments
-        ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+        const float e = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+        ema[i] = e;
+        *w_new = wi; *ema_new = e;
         return;
     }
     float g = graw * a.inv_loss_scale + (i < n_matrix ? l2 * wi : 0.0f);
@@ -1539,21 +1543,71 @@ __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float
     v[i] = vi;
     wi = wi - a.lr_t * mi / (sqrtf(vi) + eps);
     w[i] = wi;
-    ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+    const float e = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+    ema[i] = e;
+    *w_new = wi; *ema_new = e;
 }
-
 // tiny-cuda-nn sgd.h nested in the EMA wrapper: w -= lr * (g / loss_scale + l2 * w), l2_reg 1e-8, every parameter
-__global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad, uint32_t n, float lr,
-                          AdamArgs a)
+__device__ __forceinline__ void sgd_ema_update(uint32_t i, float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad,
+                                               float lr, const AdamArgs& a, float* w_new, float* ema_new)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const float l2 = 1e-8f;
     float wi = w[i];
     const float g = grad[i] * a.inv_loss_scale + l2 * wi;
     wi = wi - lr * g;
     w[i] = wi;
-    ema[i] = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+    const float e = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
+    ema[i] = e;
+    *w_new = wi; *ema_new = e;
+}
+#pragma clang fp contract(fast)
+
+__global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
+                           float* __restrict__ v, const float* __restrict__ grad, uint32_t n, uint32_t n_matrix, AdamArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wn, en;
+    adam_ema_update(i, w, ema, m, v, grad, n_matrix, a, &wn, &en);
+}
+
+__global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad, uint32_t n, float lr,
+                          AdamArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wn, en;
+    sgd_ema_update(i, w, ema, grad, lr, a, &wn, &en);
+}
+
+// The optimizer step of a model without a trainable encoding as ONE launch: every thread updates its parameter and stores the
+// fp16 copies straight into the three fragment images (dst: image slot of parameter i in the forward / EMA inference / backward
+// image, -1 = not in that image; the images' padding slots are zero since construction), thread 0 also publishes the step's loss
+// (the 8-byte {loss, sequence number} store of k_publish_loss).  Replaces k_adam_ema + k_pack + k_publish_loss: two dependent
+// launches (~17 us each on this stack) less on the serial chain backward -> exchange -> optimizer -> next backward.
+struct PackDst {
+    const int32_t *fwd, *inf, *bwd;
+    half_t *pk_fwd, *pk_inf, *pk_bwd;
+};
+template <bool SGD>
+__global__ __launch_bounds__(256) void k_opt_pack(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
+                                                 float* __restrict__ v, const float* __restrict__ grad, uint32_t n, float lr,
+                                                 AdamArgs a, PackDst d, const float* __restrict__ loss, uint32_t loss_seq,
+                                                 unsigned long long* __restrict__ loss_cell)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && loss_cell != nullptr) {
+        const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, loss[0]) | ((unsigned long long)loss_seq << 32);
+        __hip_atomic_store(loss_cell, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (i >= n) return;
+    float wn, en;
+    if (SGD) sgd_ema_update(i, w, ema, grad, lr, a, &wn, &en);
+    else adam_ema_update(i, w, ema, m, v, grad, n, a, &wn, &en);
+    const int32_t df = d.fwd[i], di = d.inf[i], db = d.bwd[i];
+    if (df >= 0) d.pk_fwd[df] = (half_t)wn;
+    if (di >= 0) d.pk_inf[di] = (half_t)en;
+    if (db >= 0) d.pk_bwd[db] = (half_t)wn;
 }
 
 // fragment images from the canonical fp32 vectors
@@ -1719,7 +1773,31 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         NRC_HIP(hipMemcpy(d_src_inf_, si.data(), si.size() * 4, hipMemcpyHostToDevice));
     }
     NRC_HIP(hipMemcpy(d_src_bwd_, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
-    for (auto& p : d_pk_infer_) NRC_HIP(hipMalloc(&p, sf.size() * 2));
+    for (auto& p : d_pk_infer_) {
+        NRC_HIP(hipMalloc(&p, sf.size() * 2));
+        NRC_HIP(hipMemset(p, 0, sf.size() * 2));      // k_opt_pack never writes the padding slots
+    }
+    // inverse maps for the one-launch optimizer step (k_opt_pack): parameter -> its slot in each image
+    fused_opt_ = !hash_ && getenv("NRC_NO_FUSED_OPT") == nullptr;
+    if (fused_opt_) {
+        std::vector<int32_t> dst((size_t)3 * n_mlp_, -1);
+        auto invert = [&](const int32_t* src, size_t n_slots, int32_t* out) {
+            for (size_t j = 0; j < n_slots; j++) {
+                if (src[j] < 0) continue;
+                if ((uint32_t)src[j] >= n_mlp_ || out[src[j]] >= 0) { fused_opt_ = false; return; }      // not a one-to-one image
+                out[src[j]] = (int32_t)j;
+            }
+        };
+        std::vector<int32_t> si_host(sf.size());
+        NRC_HIP(hipMemcpy(si_host.data(), d_src_inf_, sf.size() * 4, hipMemcpyDeviceToHost));
+        invert(sf.data(), sf.size(), dst.data());
+        if (fused_opt_) invert(si_host.data(), si_host.size(), dst.data() + n_mlp_);
+        if (fused_opt_) invert(sb.data(), sb.size(), dst.data() + 2 * (size_t)n_mlp_);
+        if (fused_opt_) {
+            NRC_HIP(hipMalloc(&d_dst_, dst.size() * 4));
+            NRC_HIP(hipMemcpy(d_dst_, dst.data(), dst.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     NRC_HIP(hipMalloc(&d_pk_fwd_, sf.size() * 2));
     NRC_HIP(hipMalloc(&d_pk_bwd_, sb.size() * 2));
     if (hash_) {
@@ -1734,6 +1812,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 Mlp::~Mlp()
 {
     if (d_src_inf_ != d_src_fwd_ && d_src_inf_) (void)hipFree(d_src_inf_);
+    if (d_dst_) (void)hipFree(d_dst_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_[0], d_feat_[1], d_t16_train_,
                     d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_};
@@ -2144,7 +2223,7 @@ void Mlp::grid_grad_apply(const uint32_t* d_lists, uint32_t n_lists, uint32_t ca
     NRC_HIP(hipGetLastError());
 }
 
-void Mlp::optimizer_step(hipStream_t s)
+bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* loss_cell)
 {
     step += 1;
     const double b1 = 0.9, b2 = 0.999;
@@ -2156,6 +2235,19 @@ void Mlp::optimizer_step(hipStream_t s)
     a.ema_old = (float)(d * (1.0 - std::pow(d, t - 1.0)));
     a.ema_new = (float)(1.0 - d);
     a.ema_div = (float)(1.0 - std::pow(d, t));
+    if (fused_opt_) {
+        const int next = infer_set_ ^ 1;
+        const PackDst d{d_dst_, d_dst_ + n_mlp_, d_dst_ + 2 * (size_t)n_mlp_, (half_t*)d_pk_fwd_, (half_t*)d_pk_infer_[next], (half_t*)d_pk_bwd_};
+        if (sgd_)
+            hipLaunchKernelGGL(k_opt_pack<true>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
+                               cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+        else
+            hipLaunchKernelGGL(k_opt_pack<false>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
+                               cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+        NRC_HIP(hipGetLastError());
+        infer_set_ = next;
+        return loss_cell != nullptr;
+    }
     if (sgd_)
         hipLaunchKernelGGL(k_sgd_ema, dim3(ceil_div(n_params_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_grad_, n_params_,
                            cfg_.learning_rate, a);
@@ -2164,6 +2256,7 @@ void Mlp::optimizer_step(hipStream_t s)
                            n_params_, n_mlp_, a);
     NRC_HIP(hipGetLastError());
     repack(s);
+    return false;
 }
 
 }  // namespace nrc

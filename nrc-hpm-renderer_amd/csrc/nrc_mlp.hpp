@@ -26,8 +26,10 @@ public:
     void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries = false);
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
     void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s);
-    // EMA{Adam} step + re-pack of the fp16 MFMA fragment images
-    void optimizer_step(hipStream_t s);
+    // EMA{Adam} step + re-pack of the fp16 MFMA fragment images.  loss_cell (host-mapped, may be null): where the step's
+    // {loss, loss_seq} pair is published; returns true when the step's own launch did that (k_opt_pack), false when the caller
+    // still has to (models with a trainable encoding, NRC_NO_FUSED_OPT=1)
+    bool optimizer_step(hipStream_t s, uint32_t loss_seq = 0, unsigned long long* loss_cell = nullptr);
     void repack(hipStream_t s);
 
     uint32_t n_params() const { return n_params_; }
@@ -81,6 +83,8 @@ private:
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)
     void *d_pk_infer_[2] = {nullptr, nullptr}, *d_pk_fwd_ = nullptr, *d_pk_bwd_ = nullptr;
     int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)
+    int32_t* d_dst_ = nullptr;           // [3][n_mlp_] parameter -> slot in the forward / EMA inference / backward image (k_opt_pack)
+    bool fused_opt_ = false;
     int32_t* d_src_inf_ = nullptr;       // the same for the EMA inference image (= d_src_fwd_ unless enc80_generic_)
     bool enc80_generic_ = false;         // generic model whose EMA inference encodes Frequency(12)+OneBlob(4) inside k_infer_gen
     uint32_t n_frag_fwd_ = 0, n_frag_bwd_ = 0;

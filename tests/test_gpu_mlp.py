@@ -184,6 +184,38 @@ def test_sharded_backward_sums_to_full_batch(api, torch_gpu):
     c.Destroy()
 
 
+@pytest.mark.parametrize("model", [dict(), dict(optimizer="SGD"), dict(nn_width=128, nn_depth=8), dict(nn_width=16, nn_depth=2),
+                                   dict(pos_id=1, dir_id=1, nn_width=32, nn_depth=3)],
+                         ids=["north-star", "sgd", "8x128", "2x16", "identity-3x32"])
+def test_one_launch_optimizer_equals_the_three_launch_path_bitwise(api, torch_gpu, model, monkeypatch):
+    """k_opt_pack (update + scatter into the three fragment images + loss publication in one launch) against k_adam_ema /
+    k_sgd_ema + k_pack (NRC_NO_FUSED_OPT=1, read when the cache is created): gradients, weights, EMA, moments and both
+    inference paths stay identical to the last bit over four training steps"""
+    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    a = api.NeuralRadianceCache(api.AppConfig(**model))
+    monkeypatch.setenv("NRC_NO_FUSED_OPT", "1")
+    b = api.NeuralRadianceCache(api.AppConfig(**model))
+    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    n = 4096
+    x = torch_gpu.from_numpy(queries(n, seed=71, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((n, 3), device="cuda")
+    for step in range(4):
+        state = []
+        for c in (a, b):
+            c.Backward(x, t)
+            g = c.GetParams(4)
+            c.OptimizerStep()
+            o_ema, o_w = torch_gpu.empty((n, 3), device="cuda"), torch_gpu.empty((n, 3), device="cuda")
+            c.Infer(x, o_ema, True)
+            c.Infer(x, o_w, False)
+            state.append([g] + [c.GetParams(k) for k in range(4)] + [o_ema.cpu().numpy(), o_w.cpu().numpy()])
+        for name, p, q in zip(("grad", "w", "ema", "m", "v", "infer(ema)", "infer(w)"), *state):
+            assert np.array_equal(p.view(np.uint32), q.view(np.uint32)), (step, name)
+    assert abs(a.GetLoss() - b.GetLoss()) == 0.0
+    a.Destroy()
+    b.Destroy()
+
+
 def test_loss_decreases_when_training_on_device(api, torch_gpu):
     c = api.NeuralRadianceCache(api.AppConfig())
     x = queries(4096, seed=51, nan_frac=0.0)

@@ -1,0 +1,23 @@
+"""Stand-alone rate of the training chain (backward -> optimizer step) on an idle GPU: python3 tools/train_step_rate.py [batch] [steps]
+(NRC_NO_FUSED_OPT=1 for the three-launch optimizer)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from nrc_hpm_renderer_amd import api
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+c = api.NeuralRadianceCache(api.AppConfig())
+rng = np.random.default_rng(5)
+x = torch.from_numpy(rng.random((n, 5), dtype=np.float32)).cuda()
+t = torch.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
+for _ in range(20):
+    c.Backward(x, t); c.OptimizerStep()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    c.Backward(x, t); c.OptimizerStep()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print("batch %d: %.1f us per training step (fused optimizer: %s), loss %.5f" % (n, dt * 1e6, os.environ.get("NRC_NO_FUSED_OPT") is None, c.GetLoss()))
