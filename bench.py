@@ -193,6 +193,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The like-for-like GPU figure beside cpu_baseline (the same Monte-Carlo algorithm, k_mc_render) is measured FIRST, on every
+    # rank: its ~23 frames (50-250 ms of GPU work) also take the GPU out of its idle clock state -- `--warmup 5` is 6 ms of work,
+    # and the first 30-60 ms after an idle period ran 4 % slower (7 060 against 7 380 Msamples/s over 20 timed steps).
+    mc_baseline = gpu_mc_baseline(api, sc, scene, W, H)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -351,13 +355,13 @@ def main():
             "roofline": roof_gen if dominant_is_gen else roof_mlp,
             "roofline_mlp": roof_mlp,
             "roofline_integrator": roof_gen,
+            "gpu_mc_baseline": mc_baseline,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # cpu_baseline runs the reference's ground-truth algorithm (mc/render.comp, PATH_LENGTH 32: the reference has no CPU
         # renderer); `value` is the NRC path (2 vertices + cache query).  gpu_mc_baseline is the same algorithm as the CPU
         # baseline on the GPU -- the like-for-like ratio is gpu_mc_vs_cpu, gpu_vs_cpu compares the two different estimators.
         out["cpu_baseline"] = cpu_baseline(scene, W, H)
-        out["gpu_mc_baseline"] = gpu_mc_baseline(api, sc, scene, W, H)
         out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
         out["gpu_mc_vs_cpu"] = out["gpu_mc_baseline"]["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
