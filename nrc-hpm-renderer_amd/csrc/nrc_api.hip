@@ -744,7 +744,8 @@ public:
             order_cur_ ^= 1;
             order_pending_ = false;
         }
-        const bool sample_cost = cost_order_ && !order_pending_ && frame_index_ % order_every_ == 0;
+        const bool sample_cost = cost_order_ && !order_pending_ && (frame_index_ % order_every_ == 0 || order_resample_);
+        if (sample_cost) order_resample_ = false;
         frame_.tile_order = cost_order_ ? (const uint32_t*)d_tile_order_[order_cur_] : nullptr;
         frame_.tile_cost = sample_cost ? (uint32_t*)d_tile_cost_ : nullptr;
         NRC_HIP(hipEventRecord(ev_[0], A));
@@ -843,6 +844,7 @@ public:
         cam_ = to_dev(c);
         nrc_cam_ = c;
         mask_dirty_ = true;
+        order_resample_ = true;      // the tile costs belong to the old view: measure again with the next frame
         blend_index_ = 1;
         const size_t px = (size_t)w_ * h_;
         NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
@@ -1045,6 +1047,7 @@ private:
     bool cost_order_ = true, order_pending_ = false;
     int order_cur_ = 0;
     uint64_t order_every_ = 16, order_pending_frame_ = 0;
+    bool order_resample_ = false;
     nrc_camera nrc_cam_{};
     bool mask_dirty_ = true, empty_skip_ = true;
 };

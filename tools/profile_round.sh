@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session's worth of measurements for profiles/rNN_* (run on the MI355X box from the repo root):
 #   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin c5   (default: all but c5)
-# Output goes to gpurun_out/<tag>/ ; copy the summaries worth keeping into profiles/ afterwards (tools/profile_collect.py).
+# Output goes to gpurun_out/<tag>/ ; then: python tools/profile_collect.py gpurun_out/<tag> rNN   (copies the summaries the documents quote into profiles/).
 # rocprofv3 is always given the interpreter binary itself after `--` (no env / bash -c / shebang hop) and counters are
 # collected in passes of their own (no trace domains beside --pmc).
 set -o pipefail
