@@ -193,8 +193,9 @@ public:
         if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
         for (uint32_t b = 0; b < train_batch_count_; b++) {
             const size_t o = (size_t)b * train_batch_size_;
+            const bool vector_read = hook_ != nullptr || (comm_ != nullptr && !sparse_grid_);      // who reads the fp32 table gradient
             mlp_->backward(d_train_in_ + o * 5, d_train_target_ + o * 3, train_batch_size_,
-                           train_batch_size_ * loss_norm_factor_, st);
+                           train_batch_size_ * loss_norm_factor_, st, vector_read);
             // the one exchange step of the sharded path: sum the fp32 gradient vector + loss cell over the ranks (103 KB,
             // latency-bound) on the training stream; every rank then applies the identical optimizer step
             // A HashGrid model's vector is 57 MB of which a batch touches a few per cent: its table part travels as all-gathered
@@ -204,6 +205,7 @@ public:
             else if (comm_) Rccl::get().check(Rccl::get().all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), (size_t)mlp_->n_params() + 2, ncclFloat,
                                                                ncclSum, comm_, st), "ncclAllReduce");
             if (hook_) hook_(hook_user_, mlp_->grad_ptr(), mlp_->n_params(), mlp_->loss_ptr(), (void*)st);
+            if (vector_read) mlp_->grad_vector_is_source();
             // the two inference weight sets alternate with every optimizer step: step 0 overwrites the set the PREVIOUS
             // inference pass read, step 1 the set the CURRENT pass is reading, later steps only sets no pass reads any more
             if (b == 0 && ev_infer_prev) NRC_HIP(hipStreamWaitEvent(st, ev_infer_prev, 0));
@@ -1360,6 +1362,7 @@ int nrc_cache_set_params(nrc_cache_t* c, int which, const float* host_in)
     return guarded([&] {
         NRC_HIP(hipDeviceSynchronize());      // training / inference may be in flight on a renderer's internal streams
         NRC_HIP(hipMemcpy(c->impl.mlp().buffer(which), host_in, (size_t)c->impl.mlp().n_params() * 4, hipMemcpyHostToDevice));
+        if (which == 4) c->impl.mlp().grad_vector_is_source();
         if (which == 0 || which == 1) { c->impl.mlp().repack(c->impl.stream()); NRC_HIP(hipStreamSynchronize(c->impl.stream())); }
     });
 }

@@ -1524,19 +1524,18 @@ struct AdamArgs {
 // CPU oracle, which is built with -ffp-contract=off)
 #pragma clang fp contract(off)
 __device__ __forceinline__ void adam_ema_update(uint32_t i, float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
-                                                float* __restrict__ v, const float* __restrict__ grad, uint32_t n_matrix,
-                                                const AdamArgs& a, float* w_new, float* ema_new)
+                                                float* __restrict__ v, float graw, bool matrix, const AdamArgs& a, float* w_new,
+                                                float* ema_new)
 {
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, l2 = 1e-8f;
     float wi = w[i];
-    const float graw = grad[i];
-    if (i >= n_matrix && graw == 0.0f) {      // tiny-cuda-nn: grid entries with a zero gradient keep weight and moments
+    if (!matrix && graw == 0.0f) {      // tiny-cuda-nn: grid entries with a zero gradient keep weight and moments
         const float e = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
         ema[i] = e;
         *w_new = wi; *ema_new = e;
         return;
     }
-    float g = graw * a.inv_loss_scale + (i < n_matrix ? l2 * wi : 0.0f);
+    float g = graw * a.inv_loss_scale + (matrix ? l2 * wi : 0.0f);
     float mi = b1 * m[i] + (1.0f - b1) * g;
     float vi = b2 * v[i] + (1.0f - b2) * (g * g);
     m[i] = mi;
@@ -1548,12 +1547,12 @@ __device__ __forceinline__ void adam_ema_update(uint32_t i, float* __restrict__ 
     *w_new = wi; *ema_new = e;
 }
 // tiny-cuda-nn sgd.h nested in the EMA wrapper: w -= lr * (g / loss_scale + l2 * w), l2_reg 1e-8, every parameter
-__device__ __forceinline__ void sgd_ema_update(uint32_t i, float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad,
-                                               float lr, const AdamArgs& a, float* w_new, float* ema_new)
+__device__ __forceinline__ void sgd_ema_update(uint32_t i, float* __restrict__ w, float* __restrict__ ema, float graw, float lr,
+                                               const AdamArgs& a, float* w_new, float* ema_new)
 {
     const float l2 = 1e-8f;
     float wi = w[i];
-    const float g = grad[i] * a.inv_loss_scale + l2 * wi;
+    const float g = graw * a.inv_loss_scale + l2 * wi;
     wi = wi - lr * g;
     w[i] = wi;
     const float e = (ema[i] * a.ema_old + wi * a.ema_new) / a.ema_div;
@@ -1568,7 +1567,7 @@ __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float wn, en;
-    adam_ema_update(i, w, ema, m, v, grad, n_matrix, a, &wn, &en);
+    adam_ema_update(i, w, ema, m, v, grad[i], i < n_matrix, a, &wn, &en);
 }
 
 __global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad, uint32_t n, float lr,
@@ -1577,7 +1576,7 @@ __global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float wn, en;
-    sgd_ema_update(i, w, ema, grad, lr, a, &wn, &en);
+    sgd_ema_update(i, w, ema, grad[i], lr, a, &wn, &en);
 }
 
 // The optimizer step of a model without a trainable encoding as ONE launch: every thread updates its parameter and stores the
@@ -1602,12 +1601,44 @@ __global__ __launch_bounds__(256) void k_opt_pack(float* __restrict__ w, float* 
     }
     if (i >= n) return;
     float wn, en;
-    if (SGD) sgd_ema_update(i, w, ema, grad, lr, a, &wn, &en);
-    else adam_ema_update(i, w, ema, m, v, grad, n, a, &wn, &en);
+    if (SGD) sgd_ema_update(i, w, ema, grad[i], lr, a, &wn, &en);
+    else adam_ema_update(i, w, ema, m, v, grad[i], true, a, &wn, &en);
     const int32_t df = d.fwd[i], di = d.inf[i], db = d.bwd[i];
     if (df >= 0) d.pk_fwd[df] = (half_t)wn;
     if (di >= 0) d.pk_inf[di] = (half_t)en;
     if (db >= 0) d.pk_bwd[db] = (half_t)wn;
+}
+
+// The trainable table's share of the step, one thread per entry (two features): the gradient straight from the packed fp16 table
+// the atomics accumulated into (FROM16; no fp32 widening pass) or from the fp32 vector (after an exchange / a caller's hook), the
+// update of k_adam_ema / k_sgd_ema for parameters n_matrix + 2e, + 1, and the two fp16 gather copies (training weights, EMA set
+// `next`) that k_pack_grid would write.  Replaces k_grid_grad_f32 + the table part of k_adam_ema + k_pack_grid.
+template <bool SGD, bool FROM16>
+__global__ __launch_bounds__(256) void k_grid_opt(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
+                                                 float* __restrict__ v, const float* __restrict__ grad,
+                                                 const uint32_t* __restrict__ grad16, uint32_t n_matrix, uint32_t n_entries, float lr,
+                                                 AdamArgs a, uint32_t* __restrict__ t_train, uint32_t* __restrict__ t_ema)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint32_t i0 = n_matrix + 2u * e;
+    float g0, g1;
+    if (FROM16) {
+        const half2v h = __builtin_bit_cast(half2v, grad16[e]);
+        g0 = (float)h[0]; g1 = (float)h[1];
+    } else {
+        g0 = grad[i0]; g1 = grad[i0 + 1u];
+    }
+    float2v wn, en;
+    float x, y;
+    if (SGD) sgd_ema_update(i0, w, ema, g0, lr, a, &x, &y);
+    else adam_ema_update(i0, w, ema, m, v, g0, false, a, &x, &y);
+    wn[0] = x; en[0] = y;
+    if (SGD) sgd_ema_update(i0 + 1u, w, ema, g1, lr, a, &x, &y);
+    else adam_ema_update(i0 + 1u, w, ema, m, v, g1, false, a, &x, &y);
+    wn[1] = x; en[1] = y;
+    t_train[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(wn, half2v));
+    t_ema[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(en, half2v));
 }
 
 // fragment images from the canonical fp32 vectors
@@ -1778,7 +1809,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         NRC_HIP(hipMemset(p, 0, sf.size() * 2));      // k_opt_pack never writes the padding slots
     }
     // inverse maps for the one-launch optimizer step (k_opt_pack): parameter -> its slot in each image
-    fused_opt_ = !hash_ && getenv("NRC_NO_FUSED_OPT") == nullptr;
+    fused_opt_ = getenv("NRC_NO_FUSED_OPT") == nullptr;
     if (fused_opt_) {
         std::vector<int32_t> dst((size_t)3 * n_mlp_, -1);
         auto invert = [&](const int32_t* src, size_t n_slots, int32_t* out) {
@@ -2102,7 +2133,7 @@ void Mlp::ensure_train_workspace(uint32_t n)
     }
 }
 
-void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s)
+void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad)
 {
     if (n == 0 || n % 32 != 0) fail("training batch must be a non-zero multiple of 32 samples");
     ensure_train_workspace(n);
@@ -2180,8 +2211,12 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
             hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
                                (uint32_t*)d_grad16_, n, lv);
-            hipLaunchKernelGGL(k_grid_grad_f32, dim3(ceil_div(n_grid_entries_, 256)), dim3(256), 0, s, (const uint32_t*)d_grad16_,
-                               d_grad_ + n_mlp_, n_grid_entries_);
+            // the fp32 copy in the gradient vector is for whoever reads the vector (exchange, hook, debug read-back): the
+            // optimizer takes the table gradient from grad16 itself (k_grid_opt)
+            grid16_valid_ = fused_opt_;
+            if (widen_grid_grad || !fused_opt_)
+                hipLaunchKernelGGL(k_grid_grad_f32, dim3(ceil_div(n_grid_entries_, 256)), dim3(256), 0, s, (const uint32_t*)d_grad16_,
+                                   d_grad_ + n_mlp_, n_grid_entries_);
         }
     }
     NRC_HIP(hipGetLastError());
@@ -2216,6 +2251,7 @@ void Mlp::grid_grad_pack(uint32_t* d_list, uint32_t cap, hipStream_t s)
 void Mlp::grid_grad_apply(const uint32_t* d_lists, uint32_t n_lists, uint32_t cap, hipStream_t s)
 {
     if (!hash_) fail("grid_grad_apply: this model has no trainable encoding");
+    grid16_valid_ = false;      // the optimizer reads the summed fp32 table gradient
     NRC_HIP(hipMemsetAsync(d_grad_ + n_mlp_, 0, (size_t)n_grid_entries_ * 8, s));
     for (uint32_t r = 0; r < n_lists; r++)
         hipLaunchKernelGGL(k_grid_apply, dim3(ceil_div(cap, 256)), dim3(256), 0, s, d_lists + (size_t)r * grid_list_words(cap), cap,
@@ -2244,6 +2280,19 @@ bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* l
         else
             hipLaunchKernelGGL(k_opt_pack<false>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
                                cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+        if (hash_) {
+            const dim3 g(ceil_div(n_grid_entries_, 256));
+            uint32_t *tt = (uint32_t*)d_t16_train_, *te = (uint32_t*)d_t16_ema_[next];
+            const uint32_t* g16 = (const uint32_t*)d_grad16_;
+            if (sgd_ && grid16_valid_)
+                hipLaunchKernelGGL((k_grid_opt<true, true>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+            else if (sgd_)
+                hipLaunchKernelGGL((k_grid_opt<true, false>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+            else if (grid16_valid_)
+                hipLaunchKernelGGL((k_grid_opt<false, true>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+            else
+                hipLaunchKernelGGL((k_grid_opt<false, false>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+        }
         NRC_HIP(hipGetLastError());
         infer_set_ = next;
         return loss_cell != nullptr;

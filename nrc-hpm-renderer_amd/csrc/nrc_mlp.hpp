@@ -25,7 +25,11 @@ public:
     // skip_zero_queries (renderer only): 32-sample tiles whose queries are all exactly zero store 0 without running the network
     void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries = false);
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
-    void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s);
+    // widen_grid_grad (models with a trainable table): also write the table gradient into the fp32 gradient vector -- needed only
+    // by readers of the vector (dense exchange, gradient hook, debug read-back); the optimizer reads the packed fp16 table itself
+    void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad = true);
+    // the gradient vector was written from outside (exchange result, hook, nrc_cache_set_params): it is what the optimizer reads
+    void grad_vector_is_source() { grid16_valid_ = false; }
     // EMA{Adam} step + re-pack of the fp16 MFMA fragment images.  loss_cell (host-mapped, may be null): where the step's
     // {loss, loss_seq} pair is published; returns true when the step's own launch did that (k_opt_pack), false when the caller
     // still has to (models with a trainable encoding, NRC_NO_FUSED_OPT=1)
@@ -85,6 +89,7 @@ private:
     int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)
     int32_t* d_dst_ = nullptr;           // [3][n_mlp_] parameter -> slot in the forward / EMA inference / backward image (k_opt_pack)
     bool fused_opt_ = false;
+    bool grid16_valid_ = false;          // the packed fp16 table gradient of the last backward() is what the optimizer should read
     int32_t* d_src_inf_ = nullptr;       // the same for the EMA inference image (= d_src_fwd_ unless enc80_generic_)
     bool enc80_generic_ = false;         // generic model whose EMA inference encodes Frequency(12)+OneBlob(4) inside k_infer_gen
     uint32_t n_frag_fwd_ = 0, n_frag_bwd_ = 0;

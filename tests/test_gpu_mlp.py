@@ -216,6 +216,45 @@ def test_one_launch_optimizer_equals_the_three_launch_path_bitwise(api, torch_gp
     b.Destroy()
 
 
+@pytest.mark.parametrize("optimizer", ["Adam", "SGD"])
+def test_hashgrid_one_launch_table_optimizer_equals_the_separate_kernels_bitwise(api, torch_gpu, optimizer, monkeypatch):
+    """HashGrid model: k_opt_pack + k_grid_opt (table gradient read from the packed fp16 table, update, fp16 gather copies) against
+    k_grid_grad_f32 + k_adam_ema / k_sgd_ema + k_pack + k_pack_grid (NRC_NO_FUSED_OPT=1).  The packed-fp16 atomics of the table
+    gradient sum in a different order in every run, so cache B never runs its own backward: it is handed A's gradient vector
+    (which also exercises the path that reads the fp32 vector after an exchange) -- weights, EMA, moments and both inference paths
+    (matrix images and table copies) then agree to the last bit, step after step"""
+    kw = dict(pos_id=0, hashgrid_log2_size=14, nn_depth=3, optimizer=optimizer)
+    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    a = api.NeuralRadianceCache(api.AppConfig(**kw))
+    a2 = api.NeuralRadianceCache(api.AppConfig(**kw))            # fused too, but fed through the fp32 vector
+    monkeypatch.setenv("NRC_NO_FUSED_OPT", "1")
+    b = api.NeuralRadianceCache(api.AppConfig(**kw))
+    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    n = 2048
+    rng = np.random.default_rng(9)
+    x = torch_gpu.from_numpy(rng.random((n, 5), dtype=np.float32)).cuda()
+    t = torch_gpu.rand((n, 3), device="cuda")
+    for step in range(3):
+        a.Backward(x, t)
+        g = a.GetParams(4)
+        assert np.count_nonzero(g[-2 * 16384:]) > 0
+        a.OptimizerStep()                       # table gradient from the packed fp16 table
+        state = []
+        for c in (a2, b):
+            c.SetParams(4, g)                   # table gradient from the fp32 vector
+            c.OptimizerStep()
+        for c in (a, a2, b):
+            o_ema, o_w = torch_gpu.empty((n, 3), device="cuda"), torch_gpu.empty((n, 3), device="cuda")
+            c.Infer(x, o_ema, True)
+            c.Infer(x, o_w, False)
+            state.append([c.GetParams(k) for k in range(4)] + [o_ema.cpu().numpy(), o_w.cpu().numpy()])
+        for other in (1, 2):
+            for name, p, q in zip(("w", "ema", "m", "v", "infer(ema)", "infer(w)"), state[0], state[other]):
+                assert np.array_equal(p.view(np.uint32), q.view(np.uint32)), (step, other, name)
+    for c in (a, a2, b):
+        c.Destroy()
+
+
 def test_loss_decreases_when_training_on_device(api, torch_gpu):
     c = api.NeuralRadianceCache(api.AppConfig())
     x = queries(4096, seed=51, nan_frac=0.0)
