@@ -291,6 +291,14 @@ public:
     uint32_t GetTrainBatchSize() const { return nrc_cache_get_train_batch_size(h_); }
     nrc_cache_t* Handle() const { return h_; }
 
+    // Multi-GPU (not in the reference): one process per GPU, each with its own cache and a renderer created with an nrc_tile.  Rank 0
+    // draws a 128-byte id, the host distributes it (MPI, sockets, ...), every rank calls CommInit; from then on every training
+    // step exchanges the gradients over RCCL on the training stream (include/nrc_hpm.h, nrc_cache_comm_init).
+    static void CommUniqueId(void* out128) { nrc_check(nrc_comm_unique_id(out128)); }
+    void CommInit(const void* uniqueId128, int rank, int world) { nrc_check(nrc_cache_comm_init(h_, uniqueId128, rank, world)); }
+    void CommInfo(int* rank, int* world) const { nrc_check(nrc_cache_comm_info(h_, rank, world)); }
+    bool CommSparse() const { return nrc_cache_comm_sparse(h_) != 0; }      // HashGrid table gradient exchanged as lists
+
 private:
     nrc_cache_t* h_ = nullptr;
 };

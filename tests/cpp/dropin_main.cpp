@@ -48,6 +48,14 @@ int main(int argc, char** argv)
 
         // src/main.cu:175,203-210: the cache first, then the renderer that holds a reference to it
         en::NeuralRadianceCache nrc(appConfig);
+        // the multi-GPU entry points of the C++ mirror, one rank: the library's own RCCL communicator sums the gradients of every
+        // training step -- over one rank the identity, so the frames below still equal the run without a communicator bit for bit
+        unsigned char commId[128];
+        en::NeuralRadianceCache::CommUniqueId(commId);
+        nrc.CommInit(commId, 0, 1);
+        int commRank = -1, commWorld = -1;
+        nrc.CommInfo(&commRank, &commWorld);
+        if (commRank != 0 || commWorld != 1 || nrc.CommSparse()) throw std::runtime_error("CommInfo after CommInit(id, 0, 1)");
         en::HpmScene hpmScene(appConfig, density.data(), nx, ny, nz, env, 1, 1);          // src/main.cu:177
         const float aspectRatio = static_cast<float>(W) / static_cast<float>(H);
         en::Camera camera(en::vec3(64.0f, 0.0f, 0.0f), en::vec3(-1.0f, 0.0f, 0.0f), en::vec3(0.0f, 1.0f, 0.0f), aspectRatio,
