@@ -654,6 +654,7 @@ public:
         NRC_HIP(hipEventCreateWithFlags(&ev_order_done_, hipEventDisableTiming));
         cost_order_ = getenv("NRC_NO_COST_ORDER") == nullptr;
         if (const char* e = getenv("NRC_COST_ORDER_EVERY")) order_every_ = (uint64_t)std::max(2, atoi(e));
+        if (const char* e = getenv("NRC_COST_ORDER_KEEP")) order_keep_ = (uint32_t)std::min(31, std::max(0, atoi(e)));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
         // train-ray generation + backward overlap inference + compositing on a second stream (NRC_SINGLE_STREAM=1 disables)
@@ -750,6 +751,9 @@ public:
         if (sample_cost) order_resample_ = false;
         frame_.tile_order = cost_order_ ? (const uint32_t*)d_tile_order_[order_cur_] : nullptr;
         frame_.tile_cost = sample_cost ? (uint32_t*)d_tile_cost_ : nullptr;
+        // the first samples of a view replace the costs (a cold first launch, another camera); later ones keep a decaying maximum
+        frame_.tile_cost_keep = order_fresh_ > 0 ? 0u : order_keep_;
+        if (sample_cost && order_fresh_ > 0) order_fresh_--;
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
@@ -847,6 +851,7 @@ public:
         nrc_cam_ = c;
         mask_dirty_ = true;
         order_resample_ = true;      // the tile costs belong to the old view: measure again with the next frame
+        order_fresh_ = 2;
         blend_index_ = 1;
         const size_t px = (size_t)w_ * h_;
         NRC_HIP(hipMemsetAsync(d_out_, 0, px * 16, stream_));
@@ -1048,8 +1053,10 @@ private:
     hipEvent_t ev_order_done_ = nullptr;
     bool cost_order_ = true, order_pending_ = false;
     int order_cur_ = 0;
-    uint64_t order_every_ = 16, order_pending_frame_ = 0;
+    uint64_t order_every_ = 4, order_pending_frame_ = 0;
     bool order_resample_ = false;
+    uint32_t order_keep_ = 4;        // DevFrame::tile_cost_keep once the view's first two samples are in
+    int order_fresh_ = 2;
     nrc_camera nrc_cam_{};
     bool mask_dirty_ = true, empty_skip_ = true;
 };
@@ -1107,9 +1114,11 @@ public:
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
         else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
         if (blend_) blend_index_++;
-        const bool sample_cost = cost_order_ && frame_index_ % 16 == 0;
+        const bool sample_cost = cost_order_ && (frame_index_ % 4 == 0 || order_fresh_ == 2);
         frame_.tile_order = cost_order_ ? (const uint32_t*)d_tile_order_ : nullptr;
         frame_.tile_cost = sample_cost ? (uint32_t*)d_tile_cost_ : nullptr;
+        frame_.tile_cost_keep = order_fresh_ > 0 ? 0u : 4u;      // see Renderer::render
+        if (sample_cost && order_fresh_ > 0) order_fresh_--;
         NRC_HIP(hipEventRecord(ev_[0], stream_));
         launch_mc_render(scene_.d, cam_, frame_, path_length_, blend_factor, (float*)d_out_, (float*)d_info_,
                          count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
@@ -1124,6 +1133,7 @@ public:
         cam_ = to_dev(c);
         nrc_cam_ = c;
         mask_dirty_ = true;
+        order_fresh_ = 2;
         blend_index_ = 1;
         NRC_HIP(hipMemsetAsync(d_out_, 0, (size_t)w_ * h_ * 16, stream_));
     }
@@ -1174,6 +1184,7 @@ private:
     bool have_pinned_random_ = false;
     bool count_fetches_ = false;
     bool cost_order_ = true;
+    int order_fresh_ = 2;            // samples that replace the tile costs instead of keeping their decaying maximum
     void *d_tile_cost_ = nullptr, *d_tile_order_ = nullptr;
     uint32_t n_slots_ = 0;
     uint64_t frame_index_ = 0;

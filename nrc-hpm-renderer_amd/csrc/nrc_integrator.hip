@@ -979,6 +979,17 @@ __device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, u
     return ignore == 0u && ((word >> (id & 31u)) & 1u) == 0u;
 }
 
+// what a tile cost in this launch, kept as a decaying maximum over the sampled launches (DevFrame::tile_cost_keep)
+__device__ __forceinline__ void store_tile_cost(const DevFrame& fr, uint32_t slot, unsigned long long cycles)
+{
+    uint32_t c = (uint32_t)min(cycles, 0xffffffffull);
+    if (fr.tile_cost_keep != 0u) {
+        const uint32_t old = fr.tile_cost[slot];
+        c = max(c, old - (old >> fr.tile_cost_keep));
+    }
+    fr.tile_cost[slot] = c;
+}
+
 __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint32_t n)
 {
     if (counter == nullptr) return;
@@ -1101,8 +1112,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
 #endif
     count_fetches(fetch_counter, c.fetches);
     // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order)
-    if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)
-        fr.tile_cost[slot] = (uint32_t)min(__builtin_amdgcn_s_memtime() - t_start, 0xffffffffull);
+    if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
 #if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
     for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
 #endif
@@ -1166,7 +1176,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     }
     count_fetches(fetch_counter, c.fetches);
     if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
-        fr.tile_cost[slot] = (uint32_t)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0xffffffffull);
+        store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4);
 }
 
 // ------------------------------------------------------------------------------------------------ costliest-first launch order

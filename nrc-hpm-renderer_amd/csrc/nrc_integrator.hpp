@@ -46,6 +46,10 @@ struct DevFrame {
     // took in this launch (written by k_gen_rays when non-null)
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    // 0: tile_cost[slot] = this launch's cycles; k > 0: max(this launch's cycles, old - (old >> k)) -- a decaying maximum over the
+    // sampled launches: the costliest-first order is hurt by tiles it under-estimates (a long tile started late ends the launch),
+    // not by tiles it over-estimates
+    uint32_t tile_cost_keep;
 };
 
 // forward camera transform for the tile mask: clip = m * (x, y, z, 1), column-major like DevCamera::m

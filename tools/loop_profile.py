@@ -41,6 +41,10 @@ def main():
     for _ in range(frames):
         r.Render(None, False)
     assert L.nrc_debug_loop_profile(out, 0) == 0
+    # more frames before the time line is read: the launch order in use then comes from a warm frame's tile costs (sampled every
+    # 16 frames, applied two frames later)
+    for _ in range(int(os.environ.get("LOOP_PROFILE_WARM_FRAMES", "0"))):
+        r.Render(None, False)
     px = W * H * frames
     print("%-28s %14s %14s %8s %12s" % ("kind", "useful", "issued", "util", "issued/px"))
     for k, name in enumerate(KINDS[:6]):
@@ -76,6 +80,73 @@ def main():
     print("waves %d, launch span %.1f us, wave duration mean %.1f / p50 %.1f / p90 %.1f / max %.1f us" %
           (nw, span, dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max()))
     print("mean resident waves %.0f (sum of durations / span)" % (dur.sum() / span))
+    # the cheap waves (tiles the empty-space mask rejects, tiles off the cloud) against the walking ones
+    cheap = dur < 6.0
+    print("waves shorter than 6 us: %d (%.1f %% of the waves, %.2f %% of the wave time); they start between %.1f and %.1f us; the last "
+          "longer wave ends at %.1f us of %.1f; wave time still to run after the first cheap wave starts: %.1f %% in longer waves" %
+          (cheap.sum(), 100.0 * cheap.mean(), 100.0 * dur[cheap].sum() / dur.sum(), np.percentile(start[cheap], 1), start[cheap].max(),
+           end[~cheap].max(), span,
+           100.0 * (np.minimum(end[~cheap], span) - np.maximum(start[~cheap], np.percentile(start[cheap], 1))).clip(min=0).sum() / dur.sum()))
+    late = (~cheap) & (start > np.percentile(start[cheap], 1))
+    print("longer waves that start after the first cheap ones: %d, durations p50 %.1f / p90 %.1f / max %.1f us; the 12 waves that end last "
+          "(start, duration): %s" % (late.sum(), np.median(dur[late]) if late.any() else 0, np.percentile(dur[late], 90) if late.any() else 0,
+                                     dur[late].max() if late.any() else 0,
+                                     [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in np.argsort(end)[-12:]]))
+    last = np.argsort(end)[-400:]
+    print("the 400 waves that end last: start p10 %.1f / p50 %.1f / p90 %.1f us, duration p10 %.1f / p50 %.1f / p90 %.1f us, the same launch "
+          "slots one frame later: duration p10 %.1f / p50 %.1f / p90 %.1f us" %
+          (np.percentile(start[last], 10), np.median(start[last]), np.percentile(start[last], 90), np.percentile(dur[last], 10),
+           np.median(dur[last]), np.percentile(dur[last], 90), np.percentile(dur2[last], 10), np.median(dur2[last]), np.percentile(dur2[last], 90)))
+    first = np.argsort(start)[:4096]
+    print("the 4096 waves that start first: duration p10 %.1f / p50 %.1f / p90 %.1f us" %
+          (np.percentile(dur[first], 10), np.median(dur[first]), np.percentile(dur[first], 90)))
+    # what a better launch order could give: greedy list scheduling of the measured wave durations on the chip's wave slots (no
+    # contention model: durations as measured), in the launch order used, in the order of this frame's own durations (the ideal
+    # predictor) and in the order of the next frame's durations (a one-sample predictor)
+    import heapq
+
+    def makespan(order, slots=5120):
+        free = [0.0] * slots
+        heapq.heapify(free)
+        t_end = 0.0
+        for i in order:
+            t = heapq.heappop(free) + dur[i]
+            t_end = max(t_end, t)
+            heapq.heappush(free, t)
+        return t_end
+    print("list-scheduling model on 5120 slots: launch order used %.1f us, sorted by this frame's durations %.1f us, by the next frame's "
+          "durations %.1f us, by the mean of both %.1f us; sum of durations / slots %.1f us" %
+          (makespan(np.argsort(start)), makespan(np.argsort(-dur)), makespan(np.argsort(-dur2)), makespan(np.argsort(-(dur + dur2))),
+           dur.sum() / 5120))
+    # how much a better predictor could give: order by the mean duration of K earlier frames (same launch order, so the same
+    # launch-position bias), evaluated on a frame that is not in the mean
+    if os.environ.get("LOOP_PROFILE_PREDICTOR"):
+        hist = [dur, dur2]
+        for _ in range(9):
+            r.Render(None, False)
+            s_k, e_k = wave_times()
+            hist.append(e_k - s_k)
+        held = hist[-1]
+
+        def makespan_on(order, d, slots=5120):
+            free = [0.0] * slots
+            heapq.heapify(free)
+            t_end = 0.0
+            for i in order:
+                t = heapq.heappop(free) + d[i]
+                t_end = max(t_end, t)
+                heapq.heappush(free, t)
+            return t_end
+        print("held-out frame: sum / slots %.1f us, its own order %.1f us" % (held.sum() / 5120, makespan_on(np.argsort(-held), held)))
+        for K in (1, 2, 4, 8):
+            mean_k = np.mean(hist[-1 - K:-1], axis=0)
+            max_k = np.max(hist[-1 - K:-1], axis=0)
+            print("  predictor = mean of %d earlier frames: %.1f us; max of them: %.1f us; rank correlation of the mean with the held-out frame among the 11 000 longest: %.3f" %
+                  (K, makespan_on(np.argsort(-mean_k), held), makespan_on(np.argsort(-max_k), held),
+                   np.corrcoef(mean_k[np.argsort(-held)[:11000]], held[np.argsort(-held)[:11000]])[0, 1]))
+    for thr in (0.90, 0.95, 0.99, 0.999):
+        order_e = np.sort(end[~cheap])
+        print("  %.1f %% of the longer waves have ended at %.1f us" % (100 * thr, order_e[int(thr * (order_e.size - 1))]))
     edges = np.linspace(0, span, 21)
     for a, b in zip(edges[:-1], edges[1:]):
         resident = (np.minimum(end, b) - np.maximum(start, a)).clip(min=0).sum() / (b - a)
