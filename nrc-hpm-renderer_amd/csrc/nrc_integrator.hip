@@ -121,6 +121,9 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
 // tools/loop_profile.py builds a second library with -DNRC_LOOP_PROFILE: per loop kind, iterations summed over lanes
 // ("useful") and 64 x iterations issued by the wave ("issued"); never defined in the product build
 #ifdef NRC_LOOP_PROFILE
+// wave-level trips of the tracking loops by the number of walks alive: [0] ratio, 64-lane trips; [1] ratio, pair trips; [2] delta;
+// classes 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64
+__device__ unsigned long long g_live_hist[3][8];
 __device__ unsigned long long g_loop_prof[16];
 __device__ unsigned long long g_wave_times[4 * 65536];
 #endif
@@ -138,8 +141,17 @@ __device__ unsigned long long g_wave_times[4 * 65536];
             }                                                                             \
         }                                                                                 \
     } while (0)
+#define NRC_PROF_LIVE(which, mask)                                                           \
+    do {                                                                                     \
+        const int n_ = __popcll(mask);                                                       \
+        if (n_ > 0 && (threadIdx.x & 63u) == 0u) {                                           \
+            const int cls_ = n_ <= 1 ? 0 : n_ <= 2 ? 1 : n_ <= 4 ? 2 : n_ <= 8 ? 3 : n_ <= 16 ? 4 : n_ <= 32 ? 5 : 6; \
+            atomicAdd(&g_live_hist[which][cls_], 1ull);                                      \
+        }                                                                                    \
+    } while (0)
 #else
 #define NRC_PROF(c, k) do { } while (0)
+#define NRC_PROF_LIVE(which, mask) do { } while (0)
 #endif
 
 struct Ctx {
@@ -424,6 +436,7 @@ __device__ __forceinline__ void ratio_pairs(Ctx& c, unsigned long long am, bool 
     float rf = R0;
     for (;;) {
         if (__ballot(act) == 0ull) break;
+        NRC_PROF_LIVE(1, __ballot(act) & 0xffffffffull);
         const float R1 = random1(R0), R2 = random1(R1), R3 = random1(R2), R4 = random1(R3);
         const f2 l = logf2(f2{1.0f - (is_b ? R3 : R1), 1.0f - (is_b ? R4 : R2)});
         float l1, l2, l3, l4;
@@ -498,6 +511,7 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool vali
         }
 #endif
         if (alive) NRC_PROF(c, 3);
+        NRC_PROF_LIVE(0, __ballot(alive));
         const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
         __builtin_amdgcn_sched_barrier(0);
         const bool last = i + 2 >= 128;
@@ -815,6 +829,7 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         }
 #endif
         if (alive) NRC_PROF(c, 2);
+        NRC_PROF_LIVE(2, __ballot(alive));
         const Fetch2 fa = fetch2_load(c, ia);
         __builtin_amdgcn_sched_barrier(0);
         const bool last = i + 2 >= 128;
@@ -1664,9 +1679,16 @@ extern "C" int nrc_debug_loop_profile(unsigned long long* out16, int reset)
     if (hipDeviceSynchronize() != hipSuccess) return 1;
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(nrc::g_loop_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(nrc::g_loop_prof), z, sizeof(z)) != hipSuccess) return 1;
+        unsigned long long z[24] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nrc::g_loop_prof), z, 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nrc::g_live_hist), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
+}
+// trips of the tracking loops by the number of walks alive (g_live_hist)
+extern "C" int nrc_debug_live_hist(unsigned long long* out24)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out24, HIP_SYMBOL(nrc::g_live_hist), 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif

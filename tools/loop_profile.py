@@ -50,6 +50,14 @@ def main():
     for k, name in enumerate(KINDS[:6]):
         u, i = out[k], out[8 + k]
         print("%-28s %14d %14d %8.3f %12.2f" % (name, u, i, u / max(i, 1), i / px))
+    if hasattr(L, "nrc_debug_live_hist") and any(out[:8]):
+        hist = (C.c_ulonglong * 24)()
+        assert L.nrc_debug_live_hist(hist) == 0
+        names = ["ratio tracking, 64-lane trips", "ratio tracking, pair trips (walks alive)", "delta tracking trips"]
+        total = float(sum(hist)) or 1.0
+        print("wave-level trips by walks alive (1, 2, 3-4, 5-8, 9-16, 17-32, 33-64), %% of all %d trips:" % sum(hist))
+        for w in range(3):
+            print("  %-44s %s" % (names[w], "  ".join("%5.1f" % (100.0 * hist[8 * w + k] / total) for k in range(7))))
     trk = out[8 + 2] + out[8 + 3]
     if trk:
         print("tracking-loop trips issued with <= 32 lanes active: %.1f %%, with <= 16: %.1f %% (issued kinds 6/7 of the "
