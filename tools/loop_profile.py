@@ -88,26 +88,27 @@ def main():
     print("waves %d, launch span %.1f us, wave duration mean %.1f / p50 %.1f / p90 %.1f / max %.1f us" %
           (nw, span, dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max()))
     print("mean resident waves %.0f (sum of durations / span)" % (dur.sum() / span))
-    # the cheap waves (tiles the empty-space mask rejects, tiles off the cloud) against the walking ones
     cheap = dur < 6.0
-    print("waves shorter than 6 us: %d (%.1f %% of the waves, %.2f %% of the wave time); they start between %.1f and %.1f us; the last "
-          "longer wave ends at %.1f us of %.1f; wave time still to run after the first cheap wave starts: %.1f %% in longer waves" %
-          (cheap.sum(), 100.0 * cheap.mean(), 100.0 * dur[cheap].sum() / dur.sum(), np.percentile(start[cheap], 1), start[cheap].max(),
-           end[~cheap].max(), span,
-           100.0 * (np.minimum(end[~cheap], span) - np.maximum(start[~cheap], np.percentile(start[cheap], 1))).clip(min=0).sum() / dur.sum()))
-    late = (~cheap) & (start > np.percentile(start[cheap], 1))
-    print("longer waves that start after the first cheap ones: %d, durations p50 %.1f / p90 %.1f / max %.1f us; the 12 waves that end last "
-          "(start, duration): %s" % (late.sum(), np.median(dur[late]) if late.any() else 0, np.percentile(dur[late], 90) if late.any() else 0,
-                                     dur[late].max() if late.any() else 0,
-                                     [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in np.argsort(end)[-12:]]))
-    last = np.argsort(end)[-400:]
-    print("the 400 waves that end last: start p10 %.1f / p50 %.1f / p90 %.1f us, duration p10 %.1f / p50 %.1f / p90 %.1f us, the same launch "
-          "slots one frame later: duration p10 %.1f / p50 %.1f / p90 %.1f us" %
-          (np.percentile(start[last], 10), np.median(start[last]), np.percentile(start[last], 90), np.percentile(dur[last], 10),
-           np.median(dur[last]), np.percentile(dur[last], 90), np.percentile(dur2[last], 10), np.median(dur2[last]), np.percentile(dur2[last], 90)))
-    first = np.argsort(start)[:4096]
-    print("the 4096 waves that start first: duration p10 %.1f / p50 %.1f / p90 %.1f us" %
-          (np.percentile(dur[first], 10), np.median(dur[first]), np.percentile(dur[first], 90)))
+    if cheap.any() and (~cheap).any():      # (the counter build slows every wave: no cheap class there)
+        # the cheap waves (tiles the empty-space mask rejects, tiles off the cloud) against the walking ones
+        print("waves shorter than 6 us: %d (%.1f %% of the waves, %.2f %% of the wave time); they start between %.1f and %.1f us; the last "
+              "longer wave ends at %.1f us of %.1f; wave time still to run after the first cheap wave starts: %.1f %% in longer waves" %
+              (cheap.sum(), 100.0 * cheap.mean(), 100.0 * dur[cheap].sum() / dur.sum(), np.percentile(start[cheap], 1), start[cheap].max(),
+               end[~cheap].max(), span,
+               100.0 * (np.minimum(end[~cheap], span) - np.maximum(start[~cheap], np.percentile(start[cheap], 1))).clip(min=0).sum() / dur.sum()))
+        late = (~cheap) & (start > np.percentile(start[cheap], 1))
+        print("longer waves that start after the first cheap ones: %d, durations p50 %.1f / p90 %.1f / max %.1f us; the 12 waves that end last "
+              "(start, duration): %s" % (late.sum(), np.median(dur[late]) if late.any() else 0, np.percentile(dur[late], 90) if late.any() else 0,
+                                         dur[late].max() if late.any() else 0,
+                                         [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in np.argsort(end)[-12:]]))
+        last = np.argsort(end)[-400:]
+        print("the 400 waves that end last: start p10 %.1f / p50 %.1f / p90 %.1f us, duration p10 %.1f / p50 %.1f / p90 %.1f us, the same launch "
+              "slots one frame later: duration p10 %.1f / p50 %.1f / p90 %.1f us" %
+              (np.percentile(start[last], 10), np.median(start[last]), np.percentile(start[last], 90), np.percentile(dur[last], 10),
+               np.median(dur[last]), np.percentile(dur[last], 90), np.percentile(dur2[last], 10), np.median(dur2[last]), np.percentile(dur2[last], 90)))
+        first = np.argsort(start)[:4096]
+        print("the 4096 waves that start first: duration p10 %.1f / p50 %.1f / p90 %.1f us" %
+              (np.percentile(dur[first], 10), np.median(dur[first]), np.percentile(dur[first], 90)))
     # what a better launch order could give: greedy list scheduling of the measured wave durations on the chip's wave slots (no
     # contention model: durations as measured), in the launch order used, in the order of this frame's own durations (the ideal
     # predictor) and in the order of the next frame's durations (a one-sample predictor)
