@@ -8,11 +8,15 @@ NRC inference for every pixel, train-ray generation, 16 384 train rays + one Ada
 `--train 0` drops the training step.  One sample = one pixel path.
 
   python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
-N > 1: launched by torch.distributed.run, one rank per GPU; the frame is sharded by interleaved pixel columns and the MLP
-gradients are all-reduced over RCCL each training step (by the library itself: nrc_cache_comm_init).  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU under torch.distributed.run.  Started WITHOUT that launcher (`python bench.py --gpus 8`), this script
+launches it itself -- before anything touches the GPU -- relays rank 0's single JSON line and exits with the job's status; it never
+runs fewer ranks than it was asked for.  The frame is sharded by interleaved strips of 8 pixel columns and the MLP gradients are
+all-reduced over RCCL each training step (by the library itself: nrc_cache_comm_init).  Rank 0 prints ONE JSON line.
 
   --config c2 (default)  configs[1]+[2]: 1920x1080 per GPU, 256^3 cloud, 4 spp, 6x64; N > 1 is WEAK scaling (every rank keeps a
-                         1920x1080-pixel tile of a larger frame, 16 384 train rays per rank)
+                         1920x1080-pixel tile of a larger frame, 16 384 train rays per rank).  With N > 1 the line also carries
+                         `strong_scaling_c4` (the configs[3] figure below, measured after the timed region) and the per-step
+                         all-reduce time.
   --config c4            configs[3]: ONE 3840x2160 frame, 8 spp, sharded over the N ranks; STRONG scaling (the global frame and the
                          global train batch of 16 384 rays are fixed: each rank gets 1/N of both)
   --config c5            configs[4]: 512^3 seeded smoke, 8x128 MLP + one-blob, 1920x1080 per GPU, 4 spp (weak scaling like c2)
@@ -20,12 +24,13 @@ gradients are all-reduced over RCCL each training step (by the library itself: n
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the renderer overlaps two HIP streams; give the runtime enough hardware queues that they never share one (must be set
+# the renderer overlaps four HIP streams; give the runtime enough hardware queues that they never share one (must be set
 # before the HIP runtime initialises)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -35,8 +40,98 @@ MLP_FLOP_PER_SAMPLE = 51584.0      # 2*(80*64 + 5*64*64 + 64*3), SURVEY.md 8(d)
 MLP_BYTES_PER_SAMPLE = 32.0        # 20 B query + 12 B radiance
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--train", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--volume", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    # model overrides (default = the north-star model of BASELINE.json: Frequency+OneBlob, 6x64)
+    ap.add_argument("--pos-id", type=int, default=3)
+    ap.add_argument("--dir-id", type=int, default=0)
+    ap.add_argument("--nn-width", type=int, default=64)
+    ap.add_argument("--nn-depth", type=int, default=6)
+    ap.add_argument("--smoke-volume", action="store_true", help="configs[4]: seeded smoke plume instead of the fBm cloud")
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="BASELINE.json preset (see the module docstring)")
+    return ap.parse_args(argv)
+
+
+def apply_preset(args):
+    """returns `strong`: the preset fixes the GLOBAL frame and train batch (configs[3])"""
+    strong = False
+    if args.config == "c4":        # configs[3]: one 4K frame, 8 spp, tile shard, global train batch fixed
+        args.width, args.height, args.spp, strong = 3840, 2160, 8, True
+    elif args.config == "c5":      # configs[4]: 512^3 smoke + 8x128
+        args.volume, args.smoke_volume, args.nn_width, args.nn_depth = 512, True, 128, 8
+    return strong
+
+
+# ---------------------------------------------------------------------------------------------------------------- self-launch
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT initialising the HIP runtime (a parent that has touched the GPU must not start
+    the ranks): the KFD topology's nodes with SIMDs, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES"""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        n = 0
+    if n == 0:                       # no KFD view (containers): torch's count does not initialise the runtime on this image
+        import torch
+        n = torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a fresh child job, relay rank 0's line"""
+    shared = os.environ.get("NRC_BENCH_SHARED_GPU") == "1"      # rehearsal on ONE device: all ranks on cuda:0, gloo + hook exchange
+    have = visible_gpus()
+    if have < args.gpus and not shared:
+        print("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run under an %d-GPU label"
+              % (args.gpus, have, args.gpus), file=sys.stderr)
+        return 2
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for ln in child.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = child.wait()
+    if line is not None:
+        print(line)
+    elif rc == 0:
+        print("bench.py: the %d-rank job ended without a result line" % args.gpus, file=sys.stderr)
+        rc = 3
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------- workloads
 def global_frame(n_gpus, w, h, strong=False):
-    """weak scaling: every rank renders w*h pixels (interleaved columns) of a larger frame; strong: w x h IS the global frame"""
+    """weak scaling: every rank renders w*h pixels (interleaved column strips) of a larger frame; strong: w x h IS the global frame"""
     if strong:
         return (w, h)
     table = {1: (w, h), 2: (2 * w, h), 4: (2 * w, 2 * h), 8: (4 * w, 2 * h)}
@@ -99,32 +194,104 @@ def cpu_baseline(scene, W, H, budget_s=float(os.environ.get("NRC_BENCH_CPU_BUDGE
                        "same 256^3 cloud/scene/camera, %.1f s" % (threads, sample, t_all))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--train", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--volume", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    # model overrides (default = the north-star model of BASELINE.json: Frequency+OneBlob, 6x64)
-    ap.add_argument("--pos-id", type=int, default=3)
-    ap.add_argument("--dir-id", type=int, default=0)
-    ap.add_argument("--nn-width", type=int, default=64)
-    ap.add_argument("--nn-depth", type=int, default=6)
-    ap.add_argument("--smoke-volume", action="store_true", help="configs[4]: seeded smoke plume instead of the fBm cloud")
-    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="BASELINE.json preset (see the module docstring)")
-    args = ap.parse_args()
-    strong = False
-    if args.config == "c4":        # configs[3]: one 4K frame, 8 spp, tile shard, global train batch fixed
-        args.width, args.height, args.spp, strong = 3840, 2160, 8, True
-    elif args.config == "c5":      # configs[4]: 512^3 smoke + 8x128
-        args.volume, args.smoke_volume, args.nn_width, args.nn_depth = 512, True, 128, 8
+class Job:
+    """one preset on this rank: scene, cache, renderer, exchange; `timed(steps, warmup)` is the contract's timed region"""
 
-    import numpy as np
+    def __init__(self, args, strong, rank, world, use_dist, shared_gpu):
+        import torch
+        import torch.distributed as dist
+        from nrc_hpm_renderer_amd import api, scene as sc, parallel
+        self.torch, self.dist, self.api, self.sc, self.parallel = torch, dist, api, sc, parallel
+        self.args, self.strong, self.rank, self.world, self.use_dist = args, strong, rank, world, use_dist
+        W, H = args.width, args.height
+        # ---- synthetic inputs (SURVEY.md 8d): seeded 256^3 fBm cloud, procedural HDR sky, scene preset 4 values
+        vol = sc.cached_volume("smoke" if args.smoke_volume else "cloud", args.volume, seed=1337)
+        self.scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky())
+        self.gw, self.gh = global_frame(world, W, H, strong)
+        tile = parallel.column_tile(rank, world, self.gw, self.gh)       # (x_offset, x_stride, global_w, global_h, x_block)
+        self.local_w = parallel.local_width(rank, world, self.gw)
+        cam = sc.make_camera(aspect=self.gw / self.gh)
+        # strong scaling keeps the GLOBAL train batch at 16 384 rays (2^14 / world per rank; world must be a power of two <= 512)
+        self.log2_train = 14
+        if strong:
+            if world & (world - 1) or world > 512:
+                raise SystemExit("--config c4 needs a power-of-two world size")
+            self.log2_train = 14 - (world.bit_length() - 1)
+        cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=self.log2_train, log2_infer_batch_size=21, scene_id=4,
+                            primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337,
+                            pos_id=args.pos_id, dir_id=args.dir_id, nn_width=args.nn_width, nn_depth=args.nn_depth)
+        self.nrc = api.NeuralRadianceCache(cfg)
+        self.ren = api.NrcHpmRenderer(self.local_w, self.gh, True, cam, cfg, self.scene, self.nrc, tile=tile)
+        self.exchange = dict(path="none", rccl_rank=None, rccl_ranks=0)
+        if use_dist and args.train:
+            # RCCL all-reduce of the MLP gradients every training step: issued by the library itself on its training stream; if the
+            # library cannot bring up its own communicator the same exchange goes through torch.distributed's communicator
+            try:
+                if shared_gpu:
+                    raise RuntimeError("NRC_BENCH_SHARED_GPU=1: all ranks share one device, RCCL needs one device per rank")
+                parallel.attach_gradient_allreduce(self.nrc, world)
+                r_, w_ = self.nrc.CommInfo()              # what ncclCommUserRank / ncclCommCount say
+                self.exchange = dict(path="native (nrc_cache_comm_init -> ncclAllReduce on the training stream)", rccl_rank=r_, rccl_ranks=w_,
+                                     grid_gradient_lists=self.nrc.CommSparse())
+                if w_ != world:
+                    raise RuntimeError("RCCL communicator reports %d ranks, expected %d" % (w_, world))
+            except RuntimeError as e:
+                print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
+                parallel.attach_gradient_allreduce(self.nrc, world, native=False)
+                self.exchange = dict(path="torch.distributed hook (%s)" % dist.get_backend(), rccl_rank=rank, rccl_ranks=world)
+        self.randoms = None
+        self.ri = 0
+
+    def step(self):
+        self.ren.SetBlend(True)            # progressive blend restarts: sub-frame i has blendFactor 1/(i+1)
+        for _ in range(self.args.spp):
+            self.ren.SetFrameRandom(self.randoms[self.ri % len(self.randoms)])
+            self.ri += 1
+            self.ren.Render(None, bool(self.args.train))
+
+    def barrier(self):
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """W untimed warm-up steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize; MAX over ranks"""
+        self.randoms = self.sc.frame_randoms((steps + warmup) * self.args.spp + 8, seed=1337)
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        self.ren.StageStats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        self.stats = self.ren.StageStats(reset=True)
+        if self.use_dist:
+            tt = self.torch.tensor([dt], device="cuda", dtype=self.torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        # every rank's own pixel count (interleaved strips: local widths differ by at most one strip)
+        samples = float(sum(self.parallel.local_width(r, self.world, self.gw) for r in range(self.world))) * self.gh * self.args.spp * steps
+        return dict(value=samples / dt / 1e6, ms_per_step=dt / steps * 1e3, seconds=dt)
+
+    def allreduce_us(self):
+        """per-step all-reduce time of the native exchange (collective); None on the hook path"""
+        if self.exchange["path"].startswith("native"):
+            return self.nrc.CommTimeExchange(100)
+        return None
+
+    def close(self):
+        self.ren.Destroy()
+        self.nrc.Destroy()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # nothing has touched the GPU (or imported torch.cuda state) in this process
+    strong = apply_preset(args)
+
     import torch
     import torch.distributed as dist
 
@@ -132,100 +299,50 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        # a launcher-provided world size that contradicts --gpus is a mis-launch: the line would carry the wrong label
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    shared_gpu = os.environ.get("NRC_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no device (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from nrc_hpm_renderer_amd import api, scene as sc, parallel
+    from nrc_hpm_renderer_amd import api, scene as sc
 
     W, H, spp = args.width, args.height, args.spp
-    # ---- synthetic inputs: seeded 256^3 fBm cloud, procedural HDR sky, scene preset 4 values
-    vol = sc.cached_volume("smoke" if args.smoke_volume else "cloud", args.volume, seed=1337)
-    scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky())
-    gw, gh = global_frame(world, W, H, strong)
-    tile = parallel.column_tile(rank, world, gw, gh)          # (x_offset, x_stride, global_w, global_h), local width
-    local_w = parallel.local_width(rank, world, gw)
-    cam = sc.make_camera(aspect=gw / gh)
-    # strong scaling keeps the GLOBAL train batch at 16 384 rays (2^14 / world per rank; world must be a power of two <= 512)
-    log2_train = 14
-    if strong:
-        if world & (world - 1) or world > 512:
-            raise SystemExit("--config c4 needs a power-of-two world size")
-        log2_train = 14 - (world.bit_length() - 1)
-    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=log2_train, log2_infer_batch_size=21, scene_id=4,
-                        primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337,
-                        pos_id=args.pos_id, dir_id=args.dir_id, nn_width=args.nn_width, nn_depth=args.nn_depth)
+    job = Job(args, strong, rank, world, use_dist, shared_gpu)
+    ren, nrc, scene, exchange = job.ren, job.nrc, job.scene, job.exchange
+    gw, gh, local_w, log2_train = job.gw, job.gh, job.local_w, job.log2_train
     north_star = (args.pos_id, args.dir_id, args.nn_width, args.nn_depth) == (3, 0, 64, 6)
-    nrc = api.NeuralRadianceCache(cfg)
-    ren = api.NrcHpmRenderer(local_w, gh, True, cam, cfg, scene, nrc, tile=tile)
-    exchange = dict(path="none", rccl_rank=None, rccl_ranks=0)
-    if use_dist and args.train:
-        # RCCL all-reduce of the MLP gradients every training step: issued by the library itself on its training stream; if the
-        # library cannot bring up its own communicator the same exchange goes through torch.distributed's RCCL communicator
-        try:
-            parallel.attach_gradient_allreduce(nrc, world)
-            r_, w_ = nrc.CommInfo()              # what ncclCommUserRank / ncclCommCount say
-            exchange = dict(path="native (nrc_cache_comm_init -> ncclAllReduce on the training stream)", rccl_rank=r_, rccl_ranks=w_,
-                            grid_gradient_lists=nrc.CommSparse())
-            if w_ != world:
-                raise RuntimeError("RCCL communicator reports %d ranks, expected %d" % (w_, world))
-        except RuntimeError as e:
-            print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
-            parallel.attach_gradient_allreduce(nrc, world, native=False)
-            exchange = dict(path="torch.distributed hook (fallback)", rccl_rank=rank, rccl_ranks=world)
-    randoms = sc.frame_randoms((args.steps + args.warmup) * spp + 8, seed=1337)
-    ri = [0]
-
-    def step():
-        ren.SetBlend(True)            # progressive blend restarts: sub-frame i has blendFactor 1/(i+1)
-        for _ in range(spp):
-            ren.SetFrameRandom(randoms[ri[0] % len(randoms)])
-            ri[0] += 1
-            ren.Render(None, bool(args.train))
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # The like-for-like GPU figure beside cpu_baseline (the same Monte-Carlo algorithm, k_mc_render) is measured FIRST, on every
     # rank: its ~23 frames (50-250 ms of GPU work) also take the GPU out of its idle clock state -- `--warmup 5` is 6 ms of work,
     # and the first 30-60 ms after an idle period ran 4 % slower (7 060 against 7 380 Msamples/s over 20 timed steps).
     mc_baseline = gpu_mc_baseline(api, sc, scene, W, H)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ren.StageStats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    stats = ren.StageStats(reset=True)
-    if use_dist:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    res = job.timed(args.steps, args.warmup)
+    stats = job.stats
+    value, ms_per_step = res["value"], res["ms_per_step"]
     loss = nrc.GetLoss() if args.train else None
     # what the host spends enqueueing one frame (through the Python mirror, queues empty, nothing awaited): the launch path is on
     # the critical path only if this approaches the GPU's frame time
     ren.SetBlend(True)
     t_h = time.perf_counter()
     for _ in range(8):
-        ren.SetFrameRandom(randoms[0])
+        ren.SetFrameRandom(job.randoms[0])
         ren.Render(None, bool(args.train))
     host_enqueue_ms = (time.perf_counter() - t_h) / 8 * 1e3
     torch.cuda.synchronize()
     ren.StageStats(reset=True)
-    # every rank's own pixel count (interleaved columns: local widths differ by at most one column)
-    samples = float(sum(parallel.local_width(r, world, gw) for r in range(world))) * gh * spp * args.steps
-    value = samples / dt / 1e6
-    ms_per_step = dt / args.steps * 1e3
+    allreduce_us = job.allreduce_us() if use_dist and args.train else None
 
     # ---- integrator traffic model: density look-ups counted on the device for extra (untimed) sub-frames of the same seed --
     # n_fetch: the ALGORITHM's look-ups (every camera ray walked, as the reference and the oracle do; empty-space early-out off),
@@ -233,7 +350,7 @@ def main():
     def count(skip):
         ren.SetEmptySkip(skip)
         ren.CountFetches(True)
-        ren.SetFrameRandom(randoms[0])
+        ren.SetFrameRandom(job.randoms[0])
         ren.Render(None, False)
         torch.cuda.synchronize()
         return ren.CountFetches(False)
@@ -286,7 +403,7 @@ def main():
         # (FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 corrections of MI355X_MICROARCH.md) -- a constant read from that
         # file, not measured in this run; quoted only when this run is the profiled workload, and labelled with its source.
         traffic, traffic_source = {}, None
-        for tf in ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"):
+        for tf in ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"):
             if os.path.exists(os.path.join(ROOT, tf)) and (W, H, args.volume, world, args.config) == (1920, 1080, 256, 1, "c2"):
                 with open(os.path.join(ROOT, tf)) as f:
                     traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
@@ -294,23 +411,24 @@ def main():
                 break
         # kernel-only duration of the dense inference launch from the committed rocprofv3 kernel trace of tools/bench_mlp.py (the
         # event-timed loop above includes the ~17 us between consecutive launches); a constant read from profiles/, labelled so
-        def trace_duration(path, key):
-            full = os.path.join(ROOT, path)
-            if not os.path.exists(full):
-                return None
+        def trace_duration(paths, key):
             import csv
-            for row in csv.DictReader(open(full)):
-                if key in row["Name"]:
-                    return dict(source=path + " (committed rocprofv3 --kernel-trace --stats; not measured in this run)", calls=int(row["Calls"]),
-                                avg_us=float(row["AverageNs"]) / 1e3, min_us=float(row["MinNs"]) / 1e3,
-                                frac_of_peak_avg=flop * 2073600 / (float(row["AverageNs"]) * 1e-9) / 1e12 / MFMA_F16_PEAK_TFLOPS)
+            for path in paths:
+                full = os.path.join(ROOT, path)
+                if not os.path.exists(full):
+                    continue
+                for row in csv.DictReader(open(full)):
+                    if key in row["Name"]:
+                        return dict(source=path + " (committed rocprofv3 --kernel-trace --stats; not measured in this run)", calls=int(row["Calls"]),
+                                    avg_us=float(row["AverageNs"]) / 1e3, min_us=float(row["MinNs"]) / 1e3,
+                                    frac_of_peak_avg=flop * 2073600 / (float(row["AverageNs"]) * 1e-9) / 1e12 / MFMA_F16_PEAK_TFLOPS)
             return None
 
         mlp_trace = None
         if n_inf == 2073600 and north_star:
-            mlp_trace = trace_duration("profiles/r02_mlp_kernel_stats.csv", "k_infer")
+            mlp_trace = trace_duration(("profiles/r03_mlp_kernel_stats.csv", "profiles/r02_mlp_kernel_stats.csv"), "k_infer")
         elif n_inf == 2073600 and (args.pos_id, args.dir_id, args.nn_width, args.nn_depth) == (3, 0, 128, 8):
-            mlp_trace = trace_duration("profiles/r02_mlp128_kernel_stats.csv", "k_infer_gen")
+            mlp_trace = trace_duration(("profiles/r03_mlp128_kernel_stats.csv", "profiles/r02_mlp128_kernel_stats.csv"), "k_infer_gen")
         dominant_is_gen = gen_ms >= mlp_ms
         enc_inside = (args.pos_id, args.dir_id) == (3, 0)      # Frequency + OneBlob: encoded inside the MLP kernel
         mlp_kernel = ("k_infer (fused encode + 6x64 MLP)" if north_star else
@@ -323,9 +441,18 @@ def main():
                         on_frame_queries=dict(ms_per_launch=mlp_ms_frame,
                                               achieved=flop * n_inf / (mlp_ms_frame * 1e-3) / 1e12,
                                               frac=flop * n_inf / (mlp_ms_frame * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS))
+        # `achieved` is the contract's figure: ALGORITHMIC bytes (the look-ups the algorithm makes, counted with every ray
+        # walked) over the kernel's duration.  The kernel answers part of them without touching memory (the empty-space early-out;
+        # look-ups into cells the LDS occupancy bits prove empty): `executed` is the rate of the look-ups the timed kernel really
+        # walks -- an upper bound of what reaches the memory system, not credited as bandwidth.
+        gen_s = gen_ms * 1e-3
         roof_gen = dict(bound="hbm", kernel="k_gen_rays (delta/ratio tracking path integrator; ALU/latency-bound, quoted against HBM)",
-                        achieved=gen_bytes / (gen_ms * 1e-3) / 1e9 if gen_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=(gen_bytes / (gen_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0,
+                        achieved=gen_bytes / gen_s / 1e9 if gen_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=(gen_bytes / gen_s / 1e9) / HBM_PEAK_GBS if gen_ms > 0 else 0.0,
+                        achieved_is="algorithmic-equivalent bytes / kernel time (SURVEY 8d); not bytes that reached memory",
+                        executed=dict(bytes=n_fetch_executed * 1.0 + n_px * (16.0 + 32.0),
+                                      gb_per_s=(n_fetch_executed * 1.0 + n_px * (16.0 + 32.0)) / gen_s / 1e9 if gen_ms > 0 else 0.0,
+                                      note="look-ups walked by the timed kernel (early-out on); those answered from the LDS occupancy bits included"),
                         traffic=traffic.get("k_gen_rays"), traffic_source=traffic_source, algorithmic_bytes=gen_bytes,
                         bytes_per_pixel="fetches x 1 B + 16 B framebuffer + 32 B query I/O (SURVEY 8d)", stored_bytes=gen_store_bytes,
                         ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px, fetches_executed_per_pixel=n_fetch_executed / n_px)
@@ -334,13 +461,14 @@ def main():
         volume = "%d^3 seeded %s" % (args.volume, "smoke plume" if args.smoke_volume else "fBm cloud")
         train_rays = 1 << log2_train
         if args.config == "c4":
-            workload = ("configs[3]: ONE %dx%d frame sharded into %d interleaved column tiles (%d columns on rank 0), %s, %d spp/step, %s, HDR sky "
+            workload = ("configs[3]: ONE %dx%d frame sharded into %d tiles of interleaved 8-column strips (%d columns on rank 0), %s, %d spp/step, %s, HDR sky "
                         "env map, scene preset 4, train=%d (global batch 16384 rays = %d per rank + 1 Adam step per sub-frame)"
                         % (gw, gh, world, local_w, volume, spp, model, args.train, train_rays))
         else:
-            workload = ("%s: %dx%d per GPU (global %dx%d, interleaved column tiles), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
+            workload = ("%s: %dx%d per GPU (global %dx%d, tiles of interleaved 8-column strips), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
                         "train=%d (%d train rays + 1 Adam step per sub-frame)"
                         % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", W, H, gw, gh, volume, spp, model, args.train, train_rays))
+        exchange = dict(exchange, allreduce_us_per_step=allreduce_us)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -357,6 +485,25 @@ def main():
             "roofline_integrator": roof_gen,
             "gpu_mc_baseline": mc_baseline,
         }
+    job.close()
+
+    # ---- N > 1, default preset: the configs[3] strong-scaling figure beside the weak-scaling one (same ranks, after the timed region)
+    if world > 1 and args.config == "c2" and (W, H) == (1920, 1080):
+        a4 = parse_args(sys.argv[1:])
+        a4.config = "c4"
+        s4 = apply_preset(a4)
+        j4 = Job(a4, s4, rank, world, use_dist, shared_gpu)
+        k4, w4 = max(3, args.steps // 4), max(1, args.warmup // 2)
+        r4 = j4.timed(k4, w4)
+        ar4 = j4.allreduce_us() if a4.train else None
+        if rank == 0:
+            out["strong_scaling_c4"] = dict(value=r4["value"], unit="Msamples/s", ms_per_step=r4["ms_per_step"], ms_per_frame=r4["ms_per_step"] / a4.spp,
+                                            steps=k4, warmup=w4, scaling="strong", exchange=dict(j4.exchange, allreduce_us_per_step=ar4),
+                                            stage_ms={k: j4.stats[k] for k in ("gen_rays", "prep_train", "train", "infer", "render", "total")},
+                                            workload="configs[3]: ONE 3840x2160 frame, 8 spp/step, %d tiles of interleaved 8-column strips (%d columns per rank), "
+                                                     "global train batch 16384 rays = %d per rank" % (world, j4.local_w, 1 << j4.log2_train))
+        j4.close()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # cpu_baseline runs the reference's ground-truth algorithm (mc/render.comp, PATH_LENGTH 32: the reference has no CPU
         # renderer); `value` is the NRC path (2 vertices + cache query).  gpu_mc_baseline is the same algorithm as the CPU
@@ -366,8 +513,6 @@ def main():
         out["gpu_mc_vs_cpu"] = out["gpu_mc_baseline"]["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    ren.Destroy()
-    nrc.Destroy()
     if use_dist:
         dist.destroy_process_group()
 

@@ -88,12 +88,16 @@ int nrc_cache_destroy(nrc_cache_t* c);
  * The reference reads the loss back synchronously inside every training step (trainer->loss, :154) and GetLoss() returns that
  * value; its main loop polls it every frame (src/main.cu:303,376).  Here a one-thread kernel behind every training step stores
  * {loss, step number} into host-mapped pinned memory on the training stream:
- *   nrc_cache_get_loss           the loss of the most recent training step that has COMPLETED; never blocks and never drains
- *                                the renderer's frame pipeline (it lags the enqueued work by at most the pipeline depth, four
- *                                frames).  NaN/Inf polling as in src/main.cu:380-384 works unchanged.
- *   nrc_cache_get_loss_blocking  waits for the last training step that was enqueued (for that step only, not for the device). */
+ *   nrc_cache_get_loss        reference semantics: the loss of the last training step that was ENQUEUED (InferAndTrain / Render
+ *                             with train, nrc_cache_backward); waits for that step only, not for the device.  0 before the first.
+ *                             (nrc_cache_get_loss_blocking is the same call under its round-2 name.)
+ *   nrc_cache_get_loss_async  never blocks and never drains the renderer's frame pipeline: *loss = the loss of the most recent
+ *                             step that has COMPLETED, *step = that step's number (1-based; 0: none yet), *steps_enqueued = the
+ *                             number of the newest step enqueued -- so a caller sees how stale the value is (at most the
+ *                             pipeline depth, four frames).  step / steps_enqueued may be NULL. */
 float nrc_cache_get_loss(nrc_cache_t* c);
 float nrc_cache_get_loss_blocking(nrc_cache_t* c);
+int nrc_cache_get_loss_async(nrc_cache_t* c, float* loss, uint32_t* step, uint32_t* steps_enqueued);
 size_t nrc_cache_get_infer_batch_count(nrc_cache_t* c);
 size_t nrc_cache_get_train_batch_count(nrc_cache_t* c);
 uint32_t nrc_cache_get_infer_batch_size(nrc_cache_t* c);
@@ -109,7 +113,9 @@ int nrc_cache_backward(nrc_cache_t* c, const float* d_input, const float* d_targ
 int nrc_cache_optimizer_step(nrc_cache_t* c);
 /* device pointer / length of the fp32 gradient vector (sum over the local batch, times loss_scale 128) and of the
  * 2-float {loss, unused} cell, which directly follows the gradient vector in memory (loss_ptr == grad_ptr +
- * param_count): the multi-GPU driver all-reduces param_count + 2 floats between backward and optimizer_step */
+ * param_count): the multi-GPU driver all-reduces param_count + 2 floats between backward and optimizer_step.  From the first
+ * call on, nrc_cache_optimizer_step reads this vector for EVERY parameter (a HashGrid table's gradient otherwise comes from the
+ * packed fp16 table the backward pass accumulated into; unmodified, the vector holds the same values) */
 float* nrc_cache_grad_ptr(nrc_cache_t* c);
 uint32_t nrc_cache_param_count(nrc_cache_t* c);
 float* nrc_cache_loss_ptr(nrc_cache_t* c);
@@ -120,6 +126,9 @@ int nrc_comm_unique_id(void* out128);
 int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world);
 /* rank / size as the library's own RCCL communicator reports them (ncclCommUserRank / ncclCommCount); world = 0: none */
 int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world);
+/* measurement: *avg_us = average duration of the training step's ncclAllReduce (gradient vector + loss cell, zeroed first), issued
+ * `reps` times back to back on the cache's stream; collective -- every rank calls it with the same reps.  0 without a communicator. */
+int nrc_cache_comm_time_exchange(nrc_cache_t* c, uint32_t reps, float* avg_us);
 /* HashGrid models (posID 0): the trainable table's gradient -- 57 MB dense, a few per cent of it touched by a batch -- is
  * exchanged as all-gathered (entry, fp16x2 value) lists that every rank adds in rank order (replicas stay bit-identical), the
  * matrix gradients and the loss cell by ncclAllReduce as before.  Chosen at nrc_cache_comm_init when world x list capacity
@@ -171,11 +180,14 @@ typedef struct nrc_camera {
     float pos[3];
 } nrc_camera;
 
-/* Pixel-tile shard of a frame (new: SURVEY.md section 8e).  This instance renders the columns
- * x = x_offset + i*x_stride (i = 0..width-1) of a global_w x global_h frame; width passed to create is the LOCAL
- * column count.  {0,1,W,H} = whole frame. */
+/* Pixel-tile shard of a frame (new: SURVEY.md section 8e).  This instance renders strips of x_block adjacent columns of a
+ * global_w x global_h frame, every x_stride-th strip starting with strip x_offset: local column i (i = 0..width-1) is the global
+ * column (x_offset + (i / x_block) * x_stride) * x_block + i % x_block; width passed to create is the LOCAL column count.
+ * x_block must be a power of two; 0 means 1 (single interleaved columns).  {0,1,W,H,0} = whole frame.  Strips of 8 columns keep
+ * the 8x8-pixel tile a wavefront renders contiguous on the screen (coherent walks, as on one GPU) at the same load balance. */
 typedef struct nrc_tile {
     uint32_t x_offset, x_stride, global_w, global_h;
+    uint32_t x_block;
 } nrc_tile;
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -281,10 +281,17 @@ public:
     {
         if (h_) { nrc_cache_destroy(h_); h_ = nullptr; }
     }
-    // loss of the most recent training step that has completed: never blocks, so the per-frame poll of src/main.cu:303,376 does
-    // not drain the frame pipeline; GetLossBlocking() waits for the last step enqueued
+    // GetLoss(): the reference's value -- the loss of the training step the last InferAndTrain / Render enqueued (m_Loss =
+    // trainer->loss, src/NeuralRadianceCache.cu:154); waits for that step only.  GetLossAsync(): never blocks -- the most recent
+    // COMPLETED step's loss and number, for a per-frame poll (src/main.cu:303,376) that must not drain the frame pipeline.
     float GetLoss() const { return nrc_cache_get_loss(h_); }
-    float GetLossBlocking() const { return nrc_cache_get_loss_blocking(h_); }
+    float GetLossBlocking() const { return nrc_cache_get_loss(h_); }
+    float GetLossAsync(uint32_t* step = nullptr, uint32_t* stepsEnqueued = nullptr) const
+    {
+        float loss = 0.0f;
+        nrc_check(nrc_cache_get_loss_async(h_, &loss, step, stepsEnqueued));
+        return loss;
+    }
     size_t GetInferBatchCount() const { return nrc_cache_get_infer_batch_count(h_); }
     size_t GetTrainBatchCount() const { return nrc_cache_get_train_batch_count(h_); }
     uint32_t GetInferBatchSize() const { return nrc_cache_get_infer_batch_size(h_); }

@@ -51,7 +51,8 @@ class NrcCamera(C.Structure):
 
 
 class NrcTile(C.Structure):
-    _fields_ = [("x_offset", C.c_uint32), ("x_stride", C.c_uint32), ("global_w", C.c_uint32), ("global_h", C.c_uint32)]
+    _fields_ = [("x_offset", C.c_uint32), ("x_stride", C.c_uint32), ("global_w", C.c_uint32), ("global_h", C.c_uint32),
+                ("x_block", C.c_uint32)]
 
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)
@@ -60,7 +61,7 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.
 ABI_SYMBOLS = [
     "nrc_last_error", "nrc_version", "nrc_config_default",
     "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
-    "nrc_cache_get_loss_blocking", "nrc_cache_comm_info", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
+    "nrc_cache_get_loss_blocking", "nrc_cache_get_loss_async", "nrc_cache_comm_info", "nrc_cache_comm_time_exchange", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
     "nrc_renderer_set_cost_order", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
@@ -274,12 +275,18 @@ class NeuralRadianceCache:
             self.h = None
 
     def GetLoss(self, wait=True):
-        """wait=True: the loss of the last training step enqueued (waits for that step; what the parity tests compare).
-        wait=False: en::NeuralRadianceCache::GetLoss() of the C++ surface -- the most recent COMPLETED step, never blocks (the
-        per-frame poll of src/main.cu:303,376)."""
+        """en::NeuralRadianceCache::GetLoss(): the loss of the last training step enqueued (src/NeuralRadianceCache.cu:154; waits for
+        that step only).  wait=False = GetLossAsync()[0]."""
         if wait:
-            return float(self.L.nrc_cache_get_loss_blocking(self.h))
-        return float(self.L.nrc_cache_get_loss(self.h))
+            return float(self.L.nrc_cache_get_loss(self.h))
+        return self.GetLossAsync()[0]
+
+    def GetLossAsync(self):
+        """never blocks: (loss of the most recent COMPLETED step, that step's number, number of the newest step enqueued) -- the
+        per-frame poll of src/main.cu:303,376 without draining the frame pipeline"""
+        loss, step, enq = C.c_float(0), C.c_uint32(0), C.c_uint32(0)
+        _check(self.L.nrc_cache_get_loss_async(self.h, C.byref(loss), C.byref(step), C.byref(enq)))
+        return float(loss.value), int(step.value), int(enq.value)
 
     def GetInferBatchCount(self):
         return int(self.L.nrc_cache_get_infer_batch_count(self.h))
@@ -330,6 +337,12 @@ class NeuralRadianceCache:
         r, w = C.c_int(0), C.c_int(0)
         _check(self.L.nrc_cache_comm_info(self.h, C.byref(r), C.byref(w)))
         return r.value, w.value
+
+    def CommTimeExchange(self, reps=100):
+        """average microseconds of one gradient all-reduce of the native exchange (collective call; 0.0 without a communicator)"""
+        us = C.c_float(0)
+        _check(self.L.nrc_cache_comm_time_exchange(self.h, C.c_uint32(reps), C.byref(us)))
+        return float(us.value)
 
     def CommSparse(self):
         """True when the HashGrid table gradient travels as (entry, value) lists (native exchange of a posID 0 model)"""

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <vector>
 
@@ -269,10 +270,11 @@ public:
     // m_Loss = trainer->loss(*ctx) after every training step (src/NeuralRadianceCache.cu:154) is a device->host sync in the
     // reference.  Here a one-thread kernel behind every step stores {loss, step number} with one 8-byte store into host-mapped
     // pinned memory (no event polling: the runtime reports a recorded event complete only with the batch it was submitted in):
-    //   get_loss(false)  the loss of the most recent step that has COMPLETED -- a plain read of that cell; never blocks, never
-    //                    drains the frame pipeline (what a per-frame GetLoss() poll needs: src/main.cu:303,376; it lags the
-    //                    enqueued work by the pipeline depth, at most four frames);
-    //   get_loss(true)   waits for the last step that was enqueued (only for that step, not for the device).
+    //   get_loss(true)   GetLoss(): waits for the last step that was enqueued (only for that step, not for the device) -- the
+    //                    reference's value, m_Loss of the step InferAndTrain just ran (src/NeuralRadianceCache.cu:154);
+    //   get_loss(false)  GetLossAsync(): the loss of the most recent step that has COMPLETED and that step's number -- a plain
+    //                    read of the cell; never blocks, never drains the frame pipeline (a per-frame poll like src/main.cu:303,376
+    //                    that must not stall the renderer; lags the enqueued work by the pipeline depth, at most four frames).
     void push_loss(hipStream_t st)
     {
         loss_pushed_++;
@@ -280,15 +282,20 @@ public:
         NRC_HIP(hipGetLastError());
         NRC_HIP(hipEventRecord(ev_loss_, st));
     }
-    float get_loss(bool wait)
+    float get_loss(bool wait, uint32_t* seq = nullptr)
     {
+        if (seq) *seq = 0;
         if (loss_pushed_ == 0) return 0.0f;
         if (wait) NRC_HIP(hipEventSynchronize(ev_loss_));
         LossCell c;
         const unsigned long long bits = __atomic_load_n(h_loss_, __ATOMIC_ACQUIRE);
         std::memcpy(&c, &bits, 8);
-        return c.loss;       // c.seq = the step it belongs to (0: none has completed yet)
+        if (seq) *seq = c.seq;      // the training step the value belongs to (0: none has completed yet)
+        return c.loss;
     }
+    uint32_t loss_steps_enqueued() const { return loss_pushed_; }
+    bool grad_ptr_exposed() const { return grad_ptr_exposed_; }
+    void expose_grad_ptr() { grad_ptr_exposed_ = true; }
 
     Mlp& mlp() { return *mlp_; }
     hipStream_t stream() const { return stream_; }
@@ -325,6 +332,30 @@ public:
         r.check(r.comm_count(comm_, world), "ncclCommCount");
         r.check(r.comm_user_rank(comm_, rank), "ncclCommUserRank");
     }
+    // measurement (bench.py, N > 1): average duration of the training step's all-reduce -- the gradient vector + loss cell, zeroed
+    // first -- issued `reps` times back to back on the stand-alone stream; a collective call (every rank, same reps)
+    float time_exchange(uint32_t reps)
+    {
+        if (!comm_ || reps == 0) return 0.0f;
+        NRC_HIP(hipDeviceSynchronize());
+        Rccl& r = Rccl::get();
+        const size_t n = (sparse_grid_ ? (size_t)mlp_->n_mlp_params() : (size_t)mlp_->n_params()) + (sparse_grid_ ? 0 : 2);
+        NRC_HIP(hipMemsetAsync(mlp_->grad_ptr(), 0, ((size_t)mlp_->n_params() + 2) * sizeof(float), stream_));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        NRC_HIP(hipEventCreate(&e0));
+        NRC_HIP(hipEventCreate(&e1));
+        for (uint32_t i = 0; i < 3; i++) r.check(r.all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), n, ncclFloat, ncclSum, comm_, stream_), "ncclAllReduce");
+        NRC_HIP(hipEventRecord(e0, stream_));
+        for (uint32_t i = 0; i < reps; i++) r.check(r.all_reduce(mlp_->grad_ptr(), mlp_->grad_ptr(), n, ncclFloat, ncclSum, comm_, stream_), "ncclAllReduce");
+        NRC_HIP(hipEventRecord(e1, stream_));
+        NRC_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        NRC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        mlp_->grad_vector_is_source();
+        return ms * 1000.0f / (float)reps;
+    }
     ~Cache()
     {
         if (comm_) (void)Rccl::get().comm_destroy(comm_);
@@ -358,6 +389,7 @@ private:
     unsigned long long* d_loss_cell_ = nullptr;
     hipEvent_t ev_loss_ = nullptr;            // behind the newest publish (blocking GetLoss)
     uint32_t loss_pushed_ = 0;
+    bool grad_ptr_exposed_ = false;           // nrc_cache_grad_ptr has handed the gradient vector to the caller
     const void* owner_ = nullptr;
     hipStream_t owner_infer_stream_ = nullptr, owner_train_stream_ = nullptr;
     hipEvent_t ev_owner_infer_ = nullptr, ev_owner_train_ = nullptr;
@@ -560,11 +592,17 @@ static DevFrame make_frame(uint32_t w, uint32_t h, const nrc_tile* tile)
 {
     DevFrame f{};
     f.w = w; f.h = h;
-    nrc_tile t = tile ? *tile : nrc_tile{0, 1, w, h};
+    nrc_tile t = tile ? *tile : nrc_tile{0, 1, w, h, 1};
+    if (t.x_block == 0) t.x_block = 1;
     if (t.x_stride == 0 || t.global_w == 0 || t.global_h == 0) fail("bad tile description");
+    if (t.x_block & (t.x_block - 1)) fail("tile: x_block must be a power of two");
     if (t.global_h != h) fail("tile: global_h must equal the local height (column sharding)");
-    if ((uint64_t)t.x_offset + (uint64_t)(w - 1) * t.x_stride >= t.global_w) fail("tile columns exceed the global frame");
-    f.x_offset = t.x_offset; f.x_stride = t.x_stride;
+    uint32_t b = 0;
+    while ((1u << b) < t.x_block) b++;
+    // the last local column's global column (see global_x in nrc_integrator.hip)
+    const uint64_t last = (((uint64_t)t.x_offset + (uint64_t)((w - 1) >> b) * t.x_stride) << b) + ((w - 1) & (t.x_block - 1));
+    if (last >= t.global_w) fail("tile columns exceed the global frame");
+    f.x_offset = t.x_offset; f.x_stride = t.x_stride; f.x_block_log2 = b;
     f.inv_gw = 1.0f / (float)t.global_w;      // ONE_OVER_RENDER_WIDTH (nrc-constants.glsl:28)
     f.inv_gh = 1.0f / (float)t.global_h;
     return f;
@@ -602,6 +640,42 @@ static void write_exr(const std::string& path, const std::vector<float>& rgba, u
             for (uint32_t x = 0; x < w; x++) line[(size_t)c * w + x] = rgba[((size_t)y * w + x) * 4 + order[c]];
         put(line.data(), line.size() * 4);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------- empty-space skip
+// DevFrame::flight_table: one table per device for the life of the process (32 MB, a function of the hash RNG alone), built by
+// the first renderer that applies a tile mask
+static const float* flight_table()
+{
+    static std::mutex mu;
+    static std::vector<float*> tables;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    NRC_HIP(hipGetDevice(&dev));
+    if ((size_t)dev >= tables.size()) tables.resize((size_t)dev + 1, nullptr);
+    if (tables[dev] == nullptr) {
+        float* t = nullptr;
+        NRC_HIP(hipMalloc(&t, (size_t)kFlightStates * sizeof(float)));
+        launch_flight_table(t, nullptr);
+        NRC_HIP(hipStreamSynchronize(nullptr));
+        tables[dev] = t;
+    }
+    return tables[dev];
+}
+// The tile mask's guarantee -- a camera ray through provably empty space leaves the volume unscattered -- needs the walk to end
+// before DeltaTrack's 128-collision cap (path_trace.glsl:161-173).  skip_lambda bounds the optical depth of ANY ray of the scene:
+// a segment between two points the sphere tracing of find_entry_exit stops at (within 0.125 of the box) is at most the box
+// diagonal + 0.25 long; 0.2 % on top covers the rounding of the walk's and the table's fp32 sums.  Past ~100 most RNG states can
+// reach the cap (the 128 flights cover 128 +- 11 on average) and the mask would be rejected tile after tile: it is not built.
+static bool skip_setup(const DevScene& d, DevFrame* fr)
+{
+    const double diag = std::sqrt((double)d.size[0] * d.size[0] + (double)d.size[1] * d.size[1] + (double)d.size[2] * d.size[2]);
+    const double lambda = (double)d.density_factor * (diag + 0.5) * 1.002;
+    fr->flight_table = nullptr;
+    fr->skip_lambda = (float)lambda;
+    if (!(lambda <= 100.0)) return false;
+    fr->flight_table = flight_table();
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------- Renderer
@@ -817,7 +891,7 @@ public:
         mask_dirty_ = false;
         DevProjView pv;
         frame_.tile_mask = nullptr;
-        if (!empty_skip_ || !forward_transform(nrc_cam_, &pv)) return;
+        if (!empty_skip_ || !forward_transform(nrc_cam_, &pv) || !skip_setup(scene_.d, &frame_)) return;
         launch_tile_mask((const float*)scene_.d_boxes, scene_.n_boxes, pv, frame_, (uint32_t*)d_tile_mask_, A);
         frame_.tile_mask = (const uint32_t*)d_tile_mask_;
     }
@@ -861,7 +935,7 @@ public:
         }
     }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }      // :606-610
-    void set_scene_params(const nrc_scene& s) { scene_.set_params(s); }
+    void set_scene_params(const nrc_scene& s) { scene_.set_params(s); mask_dirty_ = true; }      // density_factor enters skip_lambda
     void set_show_nrc(bool s) { show_nrc_ = s ? 1u : 0u; }
     void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
     void set_count_fetches(bool on)
@@ -1105,7 +1179,7 @@ public:
             mask_dirty_ = false;
             DevProjView pv;
             frame_.tile_mask = nullptr;
-            if (empty_skip_ && forward_transform(nrc_cam_, &pv)) {
+            if (empty_skip_ && forward_transform(nrc_cam_, &pv) && skip_setup(scene_.d, &frame_)) {
                 launch_tile_mask((const float*)scene_.d_boxes, scene_.n_boxes, pv, frame_, (uint32_t*)d_tile_mask_, stream_);
                 frame_.tile_mask = (const uint32_t*)d_tile_mask_;
             }
@@ -1137,7 +1211,7 @@ public:
         blend_index_ = 1;
         NRC_HIP(hipMemsetAsync(d_out_, 0, (size_t)w_ * h_ * 16, stream_));
     }
-    void set_scene_params(const nrc_scene& s) { scene_.set_params(s); }
+    void set_scene_params(const nrc_scene& s) { scene_.set_params(s); mask_dirty_ = true; }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }
     bool is_blending() const { return blend_; }
     void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
@@ -1269,8 +1343,16 @@ int nrc_cache_destroy(nrc_cache_t* c)
 float nrc_cache_get_loss(nrc_cache_t* c)
 {
     float v = NAN;
-    if (c) guarded([&] { v = c->impl.get_loss(false); });
+    if (c) guarded([&] { v = c->impl.get_loss(true); });
     return v;
+}
+int nrc_cache_get_loss_async(nrc_cache_t* c, float* loss, uint32_t* step, uint32_t* steps_enqueued)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(loss);
+    return guarded([&] {
+        *loss = c->impl.get_loss(false, step);
+        if (steps_enqueued) *steps_enqueued = c->impl.loss_steps_enqueued();
+    });
 }
 float nrc_cache_get_loss_blocking(nrc_cache_t* c)
 {
@@ -1302,6 +1384,10 @@ int nrc_cache_backward(nrc_cache_t* c, const float* d_in, const float* d_target,
     return guarded([&] {
         c->impl.acquire(&c->impl, c->impl.stream(), c->impl.stream());
         c->impl.mlp().backward(d_in, d_target, n, n_norm ? n_norm : n, c->impl.stream());
+        // the documented protocol (nrc_hpm.h): backward, all-reduce of nrc_cache_grad_ptr, optimizer step -- once a caller holds
+        // the pointer, the fp32 vector (which it may have reduced) is what the optimizer must read, also for a trainable table
+        // (whose packed fp16 gradient is read otherwise); unmodified, the widened fp32 copy holds the same values
+        if (c->impl.grad_ptr_exposed()) c->impl.mlp().grad_vector_is_source();
         c->impl.push_loss(c->impl.stream());
     });
 }
@@ -1313,7 +1399,13 @@ int nrc_cache_optimizer_step(nrc_cache_t* c)
         c->impl.mlp().optimizer_step(c->impl.stream());
     });
 }
-float* nrc_cache_grad_ptr(nrc_cache_t* c) { return c ? c->impl.mlp().grad_ptr() : nullptr; }
+float* nrc_cache_grad_ptr(nrc_cache_t* c)
+{
+    if (!c) return nullptr;
+    c->impl.expose_grad_ptr();      // from now on the stand-alone optimizer step reads this vector, not the packed table gradient
+    c->impl.mlp().grad_vector_is_source();
+    return c->impl.mlp().grad_ptr();
+}
 uint32_t nrc_cache_param_count(nrc_cache_t* c) { return c ? c->impl.mlp().n_params() : 0; }
 float* nrc_cache_loss_ptr(nrc_cache_t* c) { return c ? c->impl.mlp().loss_ptr() : nullptr; }
 int nrc_cache_set_grad_hook(nrc_cache_t* c, nrc_grad_hook hook, void* user)
@@ -1340,6 +1432,11 @@ int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world)
 {
     NRC_REQUIRE(c); NRC_REQUIRE(rank); NRC_REQUIRE(world);
     return guarded([&] { c->impl.comm_info(rank, world); });
+}
+int nrc_cache_comm_time_exchange(nrc_cache_t* c, uint32_t reps, float* avg_us)
+{
+    NRC_REQUIRE(c); NRC_REQUIRE(avg_us);
+    return guarded([&] { *avg_us = c->impl.time_exchange(reps); });
 }
 int nrc_cache_comm_sparse(nrc_cache_t* c) { return c && c->impl.sparse_grid_exchange() ? 1 : 0; }
 size_t nrc_cache_grid_list_capacity(nrc_cache_t* c) { return c ? c->impl.grid_list_capacity() : 0; }

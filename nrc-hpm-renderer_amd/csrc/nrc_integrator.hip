@@ -934,6 +934,13 @@ __device__ __forceinline__ void nrc_query(const DevScene& s, V3 pos, V3 dir, flo
     q[4] = phi / NRC_PI;
 }
 
+// global column of local column lx (nrc_tile: strips of 2^x_block_log2 columns, every x_stride-th strip)
+__device__ __forceinline__ uint32_t global_x(const DevFrame& fr, uint32_t lx)
+{
+    const uint32_t b = fr.x_block_log2;
+    return ((fr.x_offset + (lx >> b) * fr.x_stride) << b) + (lx & ((1u << b) - 1u));
+}
+
 // 16x16 pixel tile per 256-thread workgroup, 8x8 per wave (coherent paths inside a wave)
 __device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx, uint32_t* y)
 {
@@ -981,17 +988,41 @@ __device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t*
 
 // Empty-space early-out, exact: the tile mask (k_tile_mask) clears the bit of an 8x8 tile only when no camera ray of the tile can
 // come within a voxel of non-empty density.  Every density such a ray's delta tracking fetches is 0, so every tentative collision
-// is rejected, the walk leaves the volume without scattering and the pixel is env(rd) with didScatter = 0 and an all-zero query
-// -- whatever the random numbers are, and the RNG state after the walk is never used.  The tile's waves skip the walk (a third
-// of the kernel's work on the bench view sits in such tiles) and write exactly what the walk would have produced.
-__device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, uint32_t y)
+// is rejected and the walk can end in two ways only: it leaves the volume (the pixel is env(rd), didScatter = 0, an all-zero
+// query, and the RNG state behind the walk is never used), or it runs into DeltaTrack's cap of 128 collisions
+// (path_trace.glsl:161-173) and "scatters" at a random point of the segment.  Which of the two happens is a function of the
+// pixel's RNG state alone: the hash chain has only 2^23 states, and DevFrame::flight_table holds, for every state, the optical
+// distance the 128 free flights drawn from it cover (k_flight_table).  A lane whose table entry exceeds the largest optical
+// depth any ray of the scene can have (DevFrame::skip_lambda, with a margin for the rounding of the walk's own sums) provably
+// leaves the volume before the cap; the tile's waves skip the walk only when that holds for every pixel of the tile (all but a
+// handful of states near the chain's fixed point 0 -- hash(0) = 0, every flight has length 0 -- once the bound is below ~90).
+__device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, uint32_t y, bool inside, float rng0)
 {
-    if (fr.tile_mask == nullptr) return false;
+    if (fr.tile_mask == nullptr || fr.flight_table == nullptr) return false;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
     const uint32_t id = __builtin_amdgcn_readfirstlane((y >> 3) * tiles_x + (lx >> 3));      // wave-uniform: one tile per wave
     const uint32_t n_words = (tiles_x * tiles_y + 31u) >> 5;
     const uint32_t word = fr.tile_mask[id >> 5], ignore = fr.tile_mask[n_words];
-    return ignore == 0u && ((word >> (id & 31u)) & 1u) == 0u;
+    if (!(ignore == 0u && ((word >> (id & 31u)) & 1u) == 0u)) return false;
+    // state -> mantissa: the states are the multiples of 2^-23 in [0, 1), so rng0 + 1 is exact
+    const uint32_t m = nrc_f2u(rng0 + 1.0f) & 0x007fffffu;
+    const bool capped = inside && !(fr.flight_table[m] > fr.skip_lambda);
+    return __ballot(capped) == 0ull;
+}
+
+// optical distance (in units of 1 / sigma_max) covered by the 128 free flights of a delta walk that starts in RNG state
+// float_construct(m) and rejects every tentative collision: draws alternate flight, acceptance (path_trace.glsl:163-170)
+__global__ __launch_bounds__(256) void k_flight_table(float* __restrict__ table)
+{
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    float r = float_construct(m);
+    float d = 0.0f;
+    for (int k = 0; k < 128; k++) {
+        const float s = random1(r);
+        d = d - nrc_logf(1.0f - s);
+        r = random1(s);
+    }
+    table[m] = d;
 }
 
 // what a tile cost in this launch, kept as a decaying maximum over the sampled launches (DevFrame::tile_cost_keep)
@@ -1044,12 +1075,12 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     c.occ = occ;
     // Wave-uniform control flow with per-lane predicates from here to the stores: a lane whose path has ended (or that has none)
     // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
-    const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+    const uint32_t gx = global_x(fr, lx);
     const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
     V3 ro, rd;
     camera_ray(cam, u, v, &ro, &rd);
     init_random(c, u, v, fr.random);
-    const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform (the tile is, even where the image ends inside it)
+    const bool empty = tile_is_empty(fr, lx, y, inside, c.rng);      // wave-uniform (the tile is, even where the image ends inside it)
     const bool enter = inside & !empty;
     V3 entry = ro, ex;
     if (__ballot(enter) != 0ull) {
@@ -1149,12 +1180,12 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     Ctx c{sc, 0.0f, 0u};
     c.occ = occ;
     // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
-    const uint32_t gx = fr.x_offset + lx * fr.x_stride;
+    const uint32_t gx = global_x(fr, lx);
     const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
     V3 ro, rd;
     camera_ray(cam, u, v, &ro, &rd);
     init_random(c, u, v, fr.random);
-    const bool empty = tile_is_empty(fr, lx, y);      // wave-uniform, see tile_is_empty
+    const bool empty = tile_is_empty(fr, lx, y, inside, c.rng);      // wave-uniform, see tile_is_empty
     const bool enter = inside & !empty;
     V3 entry = ro, ex;
     if (__ballot(enter) != 0ull) find_entry_exit(c, sel(enter, ro, v3(0.0f, 0.0f, 0.0f)), sel(enter, rd, v3(0.0f, 0.0f, 1.0f)), &entry, &ex);
@@ -1262,8 +1293,11 @@ __global__ __launch_bounds__(256) void k_tile_mask(const float* __restrict__ box
     const float gw = 1.0f / fr.inv_gw, gh = 1.0f / fr.inv_gh;
     float gx0 = floorf((xmin + 1.0f) * 0.5f * gw) - 1.0f, gx1 = ceilf((xmax + 1.0f) * 0.5f * gw) + 1.0f;
     float gy0 = floorf((ymin + 1.0f) * 0.5f * gh) - 1.0f, gy1 = ceilf((ymax + 1.0f) * 0.5f * gh) + 1.0f;
-    // local columns: gx = x_offset + lx * x_stride
-    float lx0 = floorf((gx0 - (float)fr.x_offset) / (float)fr.x_stride), lx1 = ceilf((gx1 - (float)fr.x_offset) / (float)fr.x_stride);
+    // local columns: strip s = gx >> b of the global frame is the local strip (s - x_offset) / x_stride (global_x); every local
+    // column of the local strips the rectangle can touch is taken (conservative)
+    const float blk = (float)(1u << fr.x_block_log2);
+    float lx0 = floorf((floorf(gx0 / blk) - (float)fr.x_offset) / (float)fr.x_stride) * blk;
+    float lx1 = (ceilf((floorf(gx1 / blk) - (float)fr.x_offset) / (float)fr.x_stride) + 1.0f) * blk - 1.0f;
     lx0 = fmaxf(lx0, 0.0f); gy0 = fmaxf(gy0, 0.0f);
     lx1 = fminf(lx1, (float)(fr.w - 1u)); gy1 = fminf(gy1, (float)(fr.h - 1u));
     if (!(lx0 <= lx1) || !(gy0 <= gy1)) return;             // off screen
@@ -1360,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     Ctx c{sc, 0.0f, 0u};
     c.occ = occ;
     // seed from TRAIN coordinates over the render size (quirk Q6, prep_train_rays.comp:108); sharded: global column
-    const uint32_t gx = fr.x_offset + tx * fr.x_stride;
+    const uint32_t gx = global_x(fr, tx);
     init_random(c, (float)gx * fr.inv_gw, (float)ty * fr.inv_gh, fr.random);
     V3 ro = v3(0, 0, 0);
     V3 rdir = normalize(v3(1.0f, 1.0f, 1.0f));
@@ -1606,6 +1640,12 @@ void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& p
     NRC_HIP(hipMemsetAsync(mask, 0, (size_t)tile_mask_words(fr.w, fr.h) * 4, s));
     if (n_boxes == 0) return;
     hipLaunchKernelGGL(k_tile_mask, dim3(ceil_div(n_boxes, 256)), dim3(256), 0, s, boxes, n_boxes, pv, fr, mask);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_flight_table(float* table, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_flight_table, dim3(kFlightStates / 256u), dim3(256), 0, s, table);
     NRC_HIP(hipGetLastError());
 }
 

@@ -36,11 +36,17 @@ struct DevCamera {
 struct DevFrame {
     float random[4];              // UniformData.random
     uint32_t w, h;                // local image: w columns x h rows
-    uint32_t x_offset, x_stride;  // global x = x_offset + lx * x_stride
+    uint32_t x_offset, x_stride;  // global x = ((x_offset + (lx >> x_block_log2) * x_stride) << x_block_log2) + (lx & block - 1)
+    uint32_t x_block_log2;        // log2 of the strip width (nrc_tile::x_block)
     float inv_gw, inv_gh;         // 1/global width, 1/global height (ONE_OVER_RENDER_WIDTH/HEIGHT)
     // one bit per 8x8 pixel tile (index ty * ceil(w/8) + tx), set when a camera ray of the tile can meet a non-empty voxel; the
     // word behind the last tile word is non-zero when the mask must be ignored.  nullptr: no mask (every tile is traced).
     const uint32_t* tile_mask;
+    // the mask may only be applied to a pixel whose delta walk through empty space provably leaves the volume before DeltaTrack's
+    // cap of 128 collisions: flight_table[state] (kFlightStates floats, launch_flight_table) > skip_lambda, the scene's largest
+    // optical depth with a rounding margin.  nullptr: the mask is not applied.
+    const float* flight_table;
+    float skip_lambda;
     // launch order of the camera kernels' 8x8 tiles: launch slot (workgroup * 4 + wave) -> default slot (the centre-out order of
     // pixel_of_wave_tile), costliest first (k_tile_order); nullptr: default order.  tile_cost: cycles each default slot's wave
     // took in this launch (written by k_gen_rays when non-null)
@@ -70,6 +76,9 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 // {lo.xyz, hi.xyz} that together cover every non-empty voxel with a margin of one voxel.  mask: ceil(tiles/32) + 1 words, zeroed.
 void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s);
 uint32_t tile_mask_words(uint32_t w, uint32_t h);
+// table[m] = optical distance covered by the 128 free flights a delta walk draws from RNG state m when it rejects every collision
+constexpr uint32_t kFlightStates = 1u << 23;
+void launch_flight_table(float* table, hipStream_t s);
 // launch slots of the camera kernels (rows padded to an odd number of workgroups) and the costliest-first order over them
 uint32_t camera_slots(uint32_t w, uint32_t h);
 void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, hipStream_t s);

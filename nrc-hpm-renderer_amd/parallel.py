@@ -2,32 +2,66 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Pixels are independent (the RNG seed depends
 only on the global pixel coordinate and the per-frame random, data/shader/include/random.glsl:61-64), so a frame shards
-by pixel columns with NO data-path collective: rank r renders the global columns x = r, r+N, r+2N, ... (interleaved, so
-every rank sees the same mix of cloud and empty sky).  Training has one exchange step: every rank back-propagates its
+by pixel columns with NO data-path collective: strips of 8 adjacent columns are dealt to the ranks round-robin (rank r renders
+strips r, r+N, r+2N, ...: every rank sees the same mix of cloud and empty sky, and a wavefront's 8x8-pixel tile stays contiguous).  Training has one exchange step: every rank back-propagates its
 own train rays against the GLOBAL loss normaliser, the gradient vectors (25 792 fp32 + the loss cell = 103 KB:
 latency-bound, one small all-reduce) are summed, and every rank applies the identical optimizer step, so the weight
 replicas stay bit-identical.  The train ring buffer is per rank.
 """
 
 
-def local_width(rank, world, global_w):
-    """number of columns x in [0, global_w) with x % world == rank"""
-    return (global_w - rank + world - 1) // world
+# width of the column strips the ranks interleave (nrc_tile::x_block): 8 keeps the 8x8-pixel tile a wavefront renders contiguous on
+# the screen -- single interleaved columns spread it over 8 * world global columns (less coherent walks, more distinct cache lines
+# per gather); measured with tools/c4_rank_emulation.py, DESIGN.md section 5.  NRC_TILE_BLOCK overrides.
+import os as _os
+
+DEFAULT_BLOCK = int(_os.environ.get("NRC_TILE_BLOCK", "8"))
 
 
-def column_tile(rank, world, global_w, global_h):
-    """nrc_tile of include/nrc_hpm.h: (x_offset, x_stride, global_w, global_h)"""
-    return (rank, world, global_w, global_h)
+def _columns(rank, world, global_w, block):
+    """global columns of `rank`, in local order: strips of `block` columns, strip s belongs to rank s % world"""
+    cols = []
+    s = rank
+    while s * block < global_w:
+        cols.extend(range(s * block, min((s + 1) * block, global_w)))
+        s += world
+    return cols
 
 
-def gather_columns(local_images, global_w):
+def local_width(rank, world, global_w, block=None):
+    """number of columns of the global frame that rank renders (strips of `block` columns dealt round-robin)"""
+    block = DEFAULT_BLOCK if block is None else block
+    if world == 1:
+        return global_w
+    full, rest = divmod(global_w, block * world)
+    return full * block + min(max(rest - rank * block, 0), block)
+
+
+def column_tile(rank, world, global_w, global_h, block=None):
+    """nrc_tile of include/nrc_hpm.h: (x_offset, x_stride, global_w, global_h, x_block)"""
+    block = DEFAULT_BLOCK if block is None else block
+    if world == 1:
+        return (0, 1, global_w, global_h, 1)
+    return (rank, world, global_w, global_h, block)
+
+
+def rank_columns(rank, world, global_w, block=None):
+    """the global column of every local column of `rank` (numpy index array)"""
+    import numpy as np
+    block = DEFAULT_BLOCK if block is None else block
+    return np.asarray(_columns(rank, world, global_w, block) if world > 1 else list(range(global_w)), np.int64)
+
+
+def gather_columns(local_images, global_w, block=None):
     """inverse of the sharding, for tests: list of [h, local_w, c] arrays (rank order) -> [h, global_w, c]"""
     import numpy as np
     world = len(local_images)
     h, _, c = local_images[0].shape
     out = np.zeros((h, global_w, c), local_images[0].dtype)
     for r, img in enumerate(local_images):
-        out[:, r::world, :] = img
+        cols = rank_columns(r, world, global_w, block)
+        assert img.shape[1] == len(cols)
+        out[:, cols, :] = img
     return out
 
 

@@ -69,10 +69,10 @@ int main(int argc, char** argv)
             en::nrc_check(nrc_renderer_set_frame_random(nrcHpmRenderer.Handle(), &randoms[(size_t)i * 4]));
             if (hpmScene.Update(false, 0.016f)) nrcHpmRenderer.SetSceneParams(hpmScene);  // src/main.cu:264 (static presets: no-op)
             nrcHpmRenderer.Render(nullptr, true);                 // src/main.cu:287
-            polled = nrc.GetLoss();                                 // src/main.cu:376 -- non-blocking: last completed step
+            polled = nrc.GetLossAsync();                            // src/main.cu:376 as a non-blocking poll: last completed step
             if (std::isnan(polled) || std::isinf(polled)) throw std::runtime_error("NaN loss");   // src/main.cu:380-384
         }
-        const float loss = nrc.GetLossBlocking();
+        const float loss = nrc.GetLoss();
         nrcHpmRenderer.EvaluateTimestampQueries();
         std::vector<float> image((size_t)W * H * 4);
         const float* d_image = nrcHpmRenderer.GetImage();

@@ -96,15 +96,16 @@ GW, GH, WORLD = 3840, 2160, 8
 
 
 def test_c4_one_rank_tile_of_the_4k_frame_bitwise_against_oracle(api, orc, sc, torch_gpu):
-    """rank 3 of 8 of the 3840x2160 frame (480 interleaved columns x 2160 rows, training on, global loss normaliser): its
-    gen_rays outputs equal columns 3, 11, 19, ... of the oracle's full-width rows bit for bit"""
+    """rank 3 of 8 of the 3840x2160 frame (480 columns in interleaved strips of 8 x 2160 rows, training on, global loss
+    normaliser): its gen_rays outputs equal columns 24..31, 88..95, ... of the oracle's full-width rows bit for bit"""
     from nrc_hpm_renderer_amd import parallel
     rank = 3
     vol = sc.cached_volume("cloud", 256, seed=1337)
     scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky(64, 32))
     cam = sc.make_camera(aspect=GW / GH)
     lw = parallel.local_width(rank, WORLD, GW)
-    assert lw == 480
+    cols = parallel.rank_columns(rank, WORLD, GW)
+    assert lw == 480 and cols[:9].tolist() == [24, 25, 26, 27, 28, 29, 30, 31, 88]
     # configs[3] keeps the global train batch at 16 384 rays: 2 048 per rank
     cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=11, log2_infer_batch_size=21)
     nrc = api.NeuralRadianceCache(cfg)
@@ -119,10 +120,10 @@ def test_c4_one_rank_tile_of_the_4k_frame_bitwise_against_oracle(api, orc, sc, t
     scattered = 0
     for y0, y1 in ((0, 2), (1078, 1084), (2158, 2160)):
         o = orc.nrc_gen_rays(scene, cam, GW, GH, 1, 0.0, FRAME_RANDOM, rows=(y0, y1), threads=8)
-        assert np.array_equal(info[y0:y1], o["info"][y0:y1, rank::WORLD])
-        assert np.array_equal(prim[y0:y1].view(np.uint32), o["primary"][y0:y1, rank::WORLD].view(np.uint32))
-        assert same_bits(q[:, y0:y1], o["infer_input"].reshape(GW, GH, 5)[rank::WORLD, y0:y1])
-        scattered += int(o["info"][y0:y1, rank::WORLD].sum())
+        assert np.array_equal(info[y0:y1], o["info"][y0:y1][:, cols])
+        assert np.array_equal(prim[y0:y1].view(np.uint32), o["primary"][y0:y1][:, cols].view(np.uint32))
+        assert same_bits(q[:, y0:y1], o["infer_input"].reshape(GW, GH, 5)[cols][:, y0:y1])
+        scattered += int(o["info"][y0:y1][:, cols].sum())
     assert scattered > 500
     ren.Destroy()
     nrc.Destroy()

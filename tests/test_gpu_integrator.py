@@ -140,16 +140,27 @@ def test_unusual_scenes_and_cameras_match_oracle_bitwise(api, orc, sc, cloud16, 
     nrc.Destroy()
 
 
-@pytest.mark.parametrize("view", ["default", "oblique", "inside", "tile-3-of-8"])
+# pixel (2, 3) of a 256x144 frame starts in RNG state 0 with this frame random (tests/rng_search.py): all its draws are 0, its delta
+# walk never moves and ends in DeltaTrack's 128-collision cap -- it "scatters" at the entry point although its tile sees no density
+STATE0_FRAME_RANDOM = [0.7795426845550537, 0.04615384712815285, 0.75, 0.125]
+
+
+@pytest.mark.parametrize("view", ["default", "oblique", "inside", "tile-3-of-8", "state0-pixel", "density-0.9", "density-1.6-scene5", "empty-volume-1.6"])
 def test_empty_space_early_out_is_exact(api, orc, sc, cloud16, torch_gpu, view):
     """the tile mask that lets camera rays skip a walk through provably empty space: frames with and without it are bit-identical
     (NRC primary pass, query buffer, MC image), the oracle -- which walks every ray -- agrees with both, and the mask really
-    removes work (fewer density look-ups executed) wherever part of the view is empty"""
+    removes work (fewer density look-ups executed) wherever part of the view is empty.  A walk through empty space can also end
+    in DeltaTrack's cap of 128 collisions (path_trace.glsl:161-173) and scatter there: a pixel forced into the RNG's fixed point
+    does so on any scene, and with a dense medium (optical depth of the box diagonal 97 / 172) ordinary pixels do"""
     from nrc_hpm_renderer_amd import parallel
     W, H = 256, 144
-    cam_kw = {"default": {}, "oblique": dict(pos=(40.0, 35.0, -50.0), view_dir=(-0.6, -0.5, 0.7)),
-              "inside": dict(pos=(5.0, 2.0, -3.0), view_dir=(-0.7, 0.1, 0.7)), "tile-3-of-8": {}}[view]
-    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam_kw = {"oblique": dict(pos=(40.0, 35.0, -50.0), view_dir=(-0.6, -0.5, 0.7)),
+              "inside": dict(pos=(5.0, 2.0, -3.0), view_dir=(-0.7, 0.1, 0.7))}.get(view, {})
+    vol = np.zeros_like(cloud16) if view == "empty-volume-1.6" else cloud16
+    scene = sc.make_scene(vol, scene_id=5 if "1.6" in view else 4, env=sc.procedural_sky(32, 16))
+    if view == "density-0.9":
+        scene["density_factor"] = 0.9
+    frame_random = STATE0_FRAME_RANDOM if view == "state0-pixel" else FRAME_RANDOM
     cam = sc.make_camera(aspect=W / H, **cam_kw)
     tile, lw = None, W
     if view == "tile-3-of-8":
@@ -161,12 +172,12 @@ def test_empty_space_early_out_is_exact(api, orc, sc, cloud16, torch_gpu, view):
         ren = api.NrcHpmRenderer(lw, H, False, cam, cfg, scene, nrc, tile=tile)
         ren.SetEmptySkip(skip)
         ren.CountFetches(True)
-        ren.SetFrameRandom(FRAME_RANDOM)
+        ren.SetFrameRandom(frame_random)
         ren.Render(None, False)
         n_fetch = ren.CountFetches(False)
         mc = api.McHpmRenderer(lw, H, 8, False, cam, scene, tile=tile)
         mc.SetEmptySkip(skip)
-        mc.SetFrameRandom(FRAME_RANDOM)
+        mc.SetFrameRandom(frame_random)
         mc.Render()
         out[skip] = (ren.Buffer("primary").cpu().numpy().copy(), ren.Buffer("info").cpu().numpy().copy(),
                      ren.Buffer("infer_input").cpu().numpy().copy(), mc.GetImage().cpu().numpy().copy(), n_fetch)
@@ -175,14 +186,23 @@ def test_empty_space_early_out_is_exact(api, orc, sc, cloud16, torch_gpu, view):
         nrc.Destroy()
     for k in range(4):
         assert same_bits(out[True][k], out[False][k])
-    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, FRAME_RANDOM, threads=8)
-    sel = slice(3, None, 8) if tile else slice(None)
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, frame_random, threads=8)
+    sel = parallel.rank_columns(3, 8, W) if tile else slice(None)
     assert same_bits(out[True][0].reshape(H, lw, 4), o["primary"][:, sel]) and same_bits(out[True][1].reshape(H, lw), o["info"][:, sel])
+    assert same_bits(out[True][2].reshape(lw, H, 5), o["infer_input"].reshape(W, H, 5)[sel])
+    ref_mc, _, _ = orc.mc_render(scene, cam, W, H, 8, frame_random, threads=8)
+    assert same_bits(out[True][3], ref_mc[:, sel])
     if tile is None:
         assert out[False][4] == o["n_fetch"]                      # without the mask the device executes the algorithm's look-ups
     assert out[True][4] <= out[False][4]
-    if view in ("default", "tile-3-of-8", "oblique"):
+    if view in ("default", "tile-3-of-8", "oblique", "state0-pixel", "density-0.9"):
         assert out[True][4] < out[False][4]                        # part of these views is provably empty space
+    if view == "state0-pixel":                                     # the case bites: the pixel scatters where no density is
+        assert o["info"][3, 2] == 1.0 and o["info"][3, 3] == 0.0 and o["info"][2, 2] == 0.0
+    if "1.6" in view:                                              # nearly every RNG state can reach the cap: the mask is not applied
+        assert out[True][4] == out[False][4]
+    if view == "empty-volume-1.6":                                 # ... and some walks through the empty box do (71 of this frame's)
+        assert o["info"].sum() > 20
 
 
 def test_renderer_argument_errors(api, sc, sphere_scene, torch_gpu):
@@ -476,8 +496,10 @@ def test_framebuffer_on_a_consumer_stream(api, sc, cloud16, torch_gpu):
     nrc.Destroy()
 
 
-def test_column_tiles_reproduce_the_whole_frame(api, sc, cloud16, torch_gpu):
-    """pixel-tile sharding: N interleaved column tiles == the single-GPU frame, bit for bit (integrator)"""
+@pytest.mark.parametrize("block", [1, 8])
+def test_column_tiles_reproduce_the_whole_frame(api, sc, cloud16, torch_gpu, block):
+    """pixel-tile sharding: N interleaved column tiles (single columns / strips of 8) == the single-GPU frame, bit
+    for bit (integrator)"""
     from nrc_hpm_renderer_amd import parallel
     W, H, world = 96, 48, 3
     scene = sc.make_scene(cloud16, scene_id=4)
@@ -488,21 +510,21 @@ def test_column_tiles_reproduce_the_whole_frame(api, sc, cloud16, torch_gpu):
     whole = full.GetImage().cpu().numpy()
     parts = []
     for r in range(world):
-        lw = parallel.local_width(r, world, W)
-        t = api.McHpmRenderer(lw, H, 16, False, cam, scene, tile=parallel.column_tile(r, world, W, H))
+        lw = parallel.local_width(r, world, W, block)
+        t = api.McHpmRenderer(lw, H, 16, False, cam, scene, tile=parallel.column_tile(r, world, W, H, block))
         t.SetFrameRandom(FRAME_RANDOM)
         t.Render()
         parts.append(t.GetImage().cpu().numpy())
         t.Destroy()
-    assert np.array_equal(parallel.gather_columns(parts, W), whole)
+    assert np.array_equal(parallel.gather_columns(parts, W, block), whole)
     full.Destroy()
     # the NRC renderer's primary pass shards the same way
     cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=12)
     prim = []
     for r in range(2):
-        lw = parallel.local_width(r, 2, W)
+        lw = parallel.local_width(r, 2, W, block)
         nrc = api.NeuralRadianceCache(cfg)
-        ren = api.NrcHpmRenderer(lw, H, False, cam, cfg, scene, nrc, tile=parallel.column_tile(r, 2, W, H))
+        ren = api.NrcHpmRenderer(lw, H, False, cam, cfg, scene, nrc, tile=parallel.column_tile(r, 2, W, H, block))
         ren.SetFrameRandom(FRAME_RANDOM)
         ren.Render(None, False)
         prim.append(ren.Buffer("primary").cpu().numpy().reshape(H, lw, 4))
@@ -512,11 +534,13 @@ def test_column_tiles_reproduce_the_whole_frame(api, sc, cloud16, torch_gpu):
     ren = api.NrcHpmRenderer(W, H, False, cam, cfg, scene, nrc)
     ren.SetFrameRandom(FRAME_RANDOM)
     ren.Render(None, False)
-    assert np.array_equal(parallel.gather_columns(prim, W), ren.Buffer("primary").cpu().numpy().reshape(H, W, 4))
+    assert np.array_equal(parallel.gather_columns(prim, W, block), ren.Buffer("primary").cpu().numpy().reshape(H, W, 4))
     ren.Destroy()
     nrc.Destroy()
     with pytest.raises(RuntimeError, match="tile"):
         api.McHpmRenderer(W, H, 16, False, cam, scene, tile=(1, 1, W, H))          # columns would exceed the frame
+    with pytest.raises(RuntimeError, match="power of two"):
+        api.McHpmRenderer(W // 3, H, 16, False, cam, scene, tile=(0, 3, W, H, 3))
 
 
 def test_compare_images_and_exr_export(api, orc, sc, sphere_scene, torch_gpu, tmp_path):

@@ -255,6 +255,41 @@ def test_hashgrid_one_launch_table_optimizer_equals_the_separate_kernels_bitwise
         c.Destroy()
 
 
+def test_hashgrid_optimizer_reads_the_gradient_vector_the_caller_reduced(api, torch_gpu):
+    """the documented stand-alone protocol (include/nrc_hpm.h): nrc_cache_backward -> all-reduce of nrc_cache_grad_ptr ->
+    nrc_cache_optimizer_step.  For a HashGrid model the optimizer must take the TABLE gradient from that fp32 vector too, not from
+    the packed fp16 table of the local backward pass: a caller that zeroes the vector gets an untouched table (Adam skips table
+    entries whose gradient is zero), one that leaves it alone gets the step of a cache that never asked for the pointer"""
+    kw = dict(pos_id=0, hashgrid_log2_size=12, nn_depth=3)
+    a, b, c = (api.NeuralRadianceCache(api.AppConfig(**kw)) for _ in range(3))
+    n = 1024
+    rng = np.random.default_rng(3)
+    x = torch_gpu.from_numpy(rng.random((n, 5), dtype=np.float32)).cuda()
+    t = torch_gpu.rand((n, 3), device="cuda")
+    w0 = a.GetParams(0).copy()
+    g_b, g_c = b.GradTensor(), c.GradTensor()      # the pointer is handed out BEFORE the backward pass, as a driver would do once
+    for k in (a, b, c):
+        k.Backward(x, t)
+    torch_gpu.cuda.synchronize()
+    g_ref = a.GetParams(4)
+    table = np.flatnonzero(g_ref != 0)
+    table = table[table >= a.ParamCount() - 2 * 16 * (1 << 12)]          # touched table entries (16 levels x <= 2^12 x 2 features)
+    assert table.size > 1000
+    g_c.zero_()
+    torch_gpu.cuda.synchronize()
+    for k in (a, b, c):
+        k.OptimizerStep()
+    wa, wb, wc = a.GetParams(0), b.GetParams(0), c.GetParams(0)
+    assert (wa[table] != w0[table]).mean() > 0.9                   # the step moves the touched table entries ...
+    assert np.array_equal(wc[table].view(np.uint32), w0[table].view(np.uint32))      # ... unless the caller zeroed their gradient
+    # reading the (unmodified) fp32 vector instead of the packed table gives the same step; the packed fp16 atomics of two backward
+    # passes sum in different orders, so the comparison is by tolerance
+    assert np.abs(wb - wa).max() <= 2.1 * 0.01
+    assert np.linalg.norm(wb - wa) <= 0.05 * np.linalg.norm(wa - w0)
+    for k in (a, b, c):
+        k.Destroy()
+
+
 def test_loss_decreases_when_training_on_device(api, torch_gpu):
     c = api.NeuralRadianceCache(api.AppConfig())
     x = queries(4096, seed=51, nan_frac=0.0)

@@ -54,19 +54,27 @@ def test_quantize_density_truncates(sc):
 
 
 def test_column_tiles_partition_the_frame():
+    """strips of `block` columns dealt round-robin: every global column belongs to exactly one rank, the local widths add up, and
+    the tile tuple states the mapping of include/nrc_hpm.h (local column i -> (x_offset + (i // b) * x_stride) * b + i % b)"""
     from nrc_hpm_renderer_amd import parallel
-    for world in (1, 2, 3, 4, 8):
-        for gw in (16, 1920, 3841):
-            cols = []
-            for r in range(world):
-                x0, st, w_, h_ = parallel.column_tile(r, world, gw, 4)
-                lw = parallel.local_width(r, world, gw)
-                cols += list(range(x0, gw, st))[:lw]
-                assert x0 + (lw - 1) * st < gw
-            assert sorted(cols) == list(range(gw))
-    imgs = [np.full((2, parallel.local_width(r, 2, 5), 1), r, np.float32) for r in range(2)]
-    g = parallel.gather_columns(imgs, 5)
+    for block in (1, 2, 8, None):
+        for world in (1, 2, 3, 4, 8):
+            for gw in (16, 1920, 3841):
+                cols = []
+                for r in range(world):
+                    x0, st, w_, h_, b = parallel.column_tile(r, world, gw, 4, block)
+                    lw = parallel.local_width(r, world, gw, block)
+                    mine = parallel.rank_columns(r, world, gw, block)
+                    assert len(mine) == lw and (w_, h_) == (gw, 4)
+                    assert [(x0 + (i // b) * st) * b + i % b for i in range(lw)] == mine.tolist()
+                    cols += mine.tolist()
+                assert sorted(cols) == list(range(gw))
+    imgs = [np.full((2, parallel.local_width(r, 2, 5, 1), 1), r, np.float32) for r in range(2)]
+    g = parallel.gather_columns(imgs, 5, 1)
     assert g[0, :, 0].tolist() == [0, 1, 0, 1, 0]
+    imgs = [np.full((2, parallel.local_width(r, 2, 11, 2), 1), r, np.float32) for r in range(2)]
+    assert parallel.gather_columns(imgs, 11, 2)[0, :, 0].tolist() == [0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1]
+    assert parallel.DEFAULT_BLOCK == 8
 
 
 def test_frame_randoms_deterministic(sc):
@@ -91,3 +99,19 @@ def test_hpm_scene_update_rotates_only_the_dynamic_preset(sc):
     assert 0.0 <= s.azimuth < 2.0 * 3.141 and abs(s.azimuth - math.fmod(0.25 * 61, 2.0 * 3.141)) < 1e-4
     assert not sc.HpmScene(vol, scene_id=3, dynamic=False).Update(0.5)
     assert not sc.HpmScene(vol, scene_id=4, dynamic=True).Update(0.5)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus 2` without a launcher environment on a box with fewer than two GPUs: a non-zero exit and no result
+    line -- never one rank under an N-GPU label (no GPU is touched: the device count comes from the KFD topology / torch's count)"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NRC_BENCH_SHARED_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "refusing" in r.stderr

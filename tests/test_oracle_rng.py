@@ -43,3 +43,17 @@ def test_draws_in_unit_interval(orc):
     out = orc.rng_kat(0.3, 0.7, [0.1, 0.2, 0.3, 0.4], 4096)
     assert (out >= 0).all() and (out < 1).all()
     assert 0.45 < out[1:].mean() < 0.55
+
+
+def test_state0_frame_random_puts_the_pixel_into_the_rng_fixed_point(orc):
+    """tests/rng_search.py (numpy restatement of random.glsl) agrees with the oracle's hash, and the vector the empty-space test
+    uses really starts pixel (2, 3) of a 256x144 frame in state 0, where every draw is 0 (hash(0) = 0)"""
+    import rng_search as rs
+    xs = np.array([0, 1, 0x3f800000, 0xdeadbeef, 0x7fffffff, 12345], np.uint32)
+    assert [int(h) for h in rs.hash1(xs)] == [orc.hash(int(x)) for x in xs]
+    fr = [0.7795426845550537, 0.04615384712815285, 0.75, 0.125]
+    assert float(rs.init_random(2, 3, 256, 144, fr)) == 0.0
+    assert float(rs.init_random(3, 3, 256, 144, fr)) != 0.0
+    u, v = np.float32(2) * (np.float32(1.0) / np.float32(256)), np.float32(3) * (np.float32(1.0) / np.float32(144))
+    out = orc.rng_kat(u, v, fr, 3)                     # the oracle's own InitRandom + three draws
+    assert [float(x) for x in out] == [0.0, 0.0, 0.0, 0.0]

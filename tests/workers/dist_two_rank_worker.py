@@ -1,0 +1,63 @@
+"""Worker of tests/test_gpu_dist_two_ranks.py: one of TWO ranks of the product's sharded path, launched by
+`python -m torch.distributed.run --nproc-per-node 2`.  Both ranks share cuda:0 (the GPU box has one device), so the exchange
+step runs through the library's gradient hook and torch.distributed's gloo backend (RCCL needs one device per rank); everything
+else -- tile rendering, train-ray generation per tile, sharded backward against the global loss normaliser, identical optimizer
+steps on every replica -- is the code an N-GPU run executes.  Each rank writes what it saw to <out>.<rank>.npz."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path = sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nrc_hpm_renderer_amd import api, parallel, scene as sc
+    vol = sc.quantize_density(sc.fbm_cloud_volume(48, seed=3))
+    scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky(32, 16))
+    W, H, frames = 256, 96, 6
+    cam = sc.make_camera(aspect=W / H)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=9, log2_infer_batch_size=14)
+    nrc = api.NeuralRadianceCache(cfg)
+    parallel.attach_gradient_allreduce(nrc, world, native=False)         # loss normaliser = global batch; gloo all-reduce hook
+    lw = parallel.local_width(rank, world, W)
+    ren = api.NrcHpmRenderer(lw, H, False, cam, cfg, scene, nrc, tile=parallel.column_tile(rank, world, W, H))
+    frs = sc.frame_randoms(frames + 1, seed=77)
+    losses = []
+    state_before_last = None
+    for f in range(frames):
+        if f == frames - 1:
+            torch.cuda.synchronize()
+            state_before_last = nrc.state_dict()
+        ren.SetFrameRandom(frs[f])
+        ren.Render(None, True)
+        losses.append(nrc.GetLoss())
+    torch.cuda.synchronize()
+    grad = nrc.GetParams(4)                                               # the all-reduced gradient of the last step
+    train_in = ren.Buffer("train_input").cpu().numpy().copy()
+    train_target = ren.Buffer("train_target").cpu().numpy().copy()
+    primary = ren.Buffer("primary").cpu().numpy().reshape(H, lw, 4).copy()
+    state = nrc.state_dict()
+    # one more frame without training: inference + compositing of this rank's tile with the replicas' common weights
+    ren.SetFrameRandom(frs[frames])
+    ren.Render(None, False)
+    img = ren.GetImage().cpu().numpy().copy()
+    np.savez(out_path + ".%d.npz" % rank, rank=rank, world=world, losses=np.asarray(losses, np.float64), grad=grad, train_in=train_in,
+             train_target=train_target, primary=primary, img=img, w=state["w"], ema=state["ema"], m=state["m"], v=state["v"], step=state["step"],
+             w_prev=state_before_last["w"], ema_prev=state_before_last["ema"], m_prev=state_before_last["m"], v_prev=state_before_last["v"],
+             step_prev=state_before_last["step"], frame_randoms=frs)
+    ren.Destroy()
+    nrc.Destroy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
