@@ -301,6 +301,11 @@ int nrc_mc_renderer_destroy(nrc_mc_renderer_t* r);
 int nrc_compare_images(const float* d_ref_rgba, const float* d_own_rgba, uint32_t w, uint32_t h, void* stream,
                        float result5[5]);
 
+/* diagnostics (environment, read when the library first allocates): NRC_POISON_ALLOC=1 fills every device allocation with 0xFF
+ * bytes at creation; NRC_GUARD_ALLOC=1 puts 4 KiB canaries around every allocation.  nrc_debug_check_guards returns -1 when the
+ * guard mode is off, otherwise the number of allocations whose canaries were overwritten (0 = clean) and, in message, the first. */
+int nrc_debug_check_guards(char* message, size_t message_bytes);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Test hooks (bit-parity of the math spec and RNG against the oracle; device pointers) */
 int nrc_test_math(int fn, const float* d_a, const float* d_b, uint32_t n, float* d_out, float* d_out2, void* stream);

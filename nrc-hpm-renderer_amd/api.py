@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
     "nrc_mc_renderer_set_frame_random", "nrc_mc_renderer_framebuffer", "nrc_mc_renderer_export_exr",
     "nrc_mc_renderer_frame_time_ms", "nrc_mc_renderer_count_fetches", "nrc_mc_renderer_destroy",
-    "nrc_compare_images", "nrc_test_math", "nrc_test_rng",
+    "nrc_compare_images", "nrc_test_math", "nrc_test_rng", "nrc_debug_check_guards",
 ]
 
 _lib = None
@@ -639,6 +639,13 @@ def CompareImages(ref, own, stream=None):
     _check(load_library().nrc_compare_images(_dev_ptr(ref), _dev_ptr(own), C.c_uint32(w), C.c_uint32(h),
                                              _stream_ptr(stream), r))
     return dict(mse=r[0], ref_mean=r[1], own_mean=r[2], own_var=r[3], valid=r[4])
+
+
+def check_guards():
+    """NRC_GUARD_ALLOC=1: (number of allocations whose canaries were overwritten, description of the first); (-1, "") when off"""
+    buf = C.create_string_buffer(512)
+    n = load_library().nrc_debug_check_guards(buf, C.c_size_t(512))
+    return int(n), buf.value.decode()
 
 
 def test_math(fn, a, b=None):

@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <random>
+#include <unordered_map>
 #include <vector>
 
 #include <dlfcn.h>
@@ -25,6 +26,97 @@
 namespace nrc {
 
 static thread_local std::string g_last_error;
+
+// ---------------------------------------------------------------------------------------------------- device allocations
+namespace {
+constexpr size_t kGuardBytes = 4096;
+struct AllocInfo {
+    void* base;
+    size_t bytes;
+    std::string what;
+};
+struct AllocRegistry {
+    std::mutex mu;
+    std::unordered_map<void*, AllocInfo> live;      // user pointer -> allocation (guard mode only)
+    bool poison = getenv("NRC_POISON_ALLOC") != nullptr && getenv("NRC_POISON_ALLOC")[0] != '0';
+    bool guard = getenv("NRC_GUARD_ALLOC") != nullptr && getenv("NRC_GUARD_ALLOC")[0] != '0';
+    unsigned long long violations = 0;
+    std::string first_violation;
+};
+AllocRegistry& alloc_registry()
+{
+    static AllocRegistry r;
+    return r;
+}
+// canary bytes of one allocation that no longer hold 0xA5 (host copy of both guards)
+size_t guard_damage(const AllocInfo& a, std::string* where)
+{
+    std::vector<unsigned char> g(2 * kGuardBytes);
+    if (hipMemcpy(g.data(), a.base, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (hipMemcpy(g.data() + kGuardBytes, (char*)a.base + kGuardBytes + a.bytes, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    size_t bad = 0;
+    long first = -1;
+    for (size_t i = 0; i < g.size(); i++)
+        if (g[i] != 0xA5) { bad++; if (first < 0) first = (long)i; }
+    if (bad && where)
+        *where = a.what + " (" + std::to_string(a.bytes) + " B): " + std::to_string(bad) + " canary bytes overwritten, first at offset " +
+                 (first < (long)kGuardBytes ? std::to_string(first - (long)kGuardBytes) : "+" + std::to_string(a.bytes + (size_t)first - kGuardBytes)) ;
+    return bad;
+}
+}  // namespace
+
+void dev_alloc(void** p, size_t bytes, const char* what)
+{
+    AllocRegistry& r = alloc_registry();
+    if (!r.guard) {
+        NRC_HIP(hipMalloc(p, bytes));
+        if (r.poison && bytes) NRC_HIP(hipMemset(*p, 0xFF, bytes));
+        return;
+    }
+    const size_t padded = (bytes + 255) & ~(size_t)255;      // keep the rear guard (and the user pointer) 256-byte aligned
+    void* base = nullptr;
+    NRC_HIP(hipMalloc(&base, padded + 2 * kGuardBytes));
+    NRC_HIP(hipMemset(base, 0xA5, padded + 2 * kGuardBytes));
+    *p = (char*)base + kGuardBytes;
+    if (bytes) NRC_HIP(hipMemset(*p, r.poison ? 0xFF : 0x00, bytes));      // bytes..padded stay canary
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.live[*p] = AllocInfo{base, bytes, what ? what : ""};
+}
+
+void dev_free(void* p)
+{
+    if (!p) return;
+    AllocRegistry& r = alloc_registry();
+    if (!r.guard) {
+        (void)hipFree(p);
+        return;
+    }
+    AllocInfo a{nullptr, 0, ""};
+    {
+        std::lock_guard<std::mutex> lock(r.mu);
+        auto it = r.live.find(p);
+        if (it == r.live.end()) { (void)hipFree(p); return; }
+        a = it->second;
+        r.live.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    AllocInfo chk = a;
+    chk.bytes = (a.bytes + 255) & ~(size_t)255;
+    // the slack between bytes and its 256-byte round-up is canary too
+    std::vector<unsigned char> slack(chk.bytes - a.bytes);
+    size_t bad = 0;
+    if (!slack.empty() && hipMemcpy(slack.data(), (char*)a.base + kGuardBytes + a.bytes, slack.size(), hipMemcpyDeviceToHost) == hipSuccess)
+        for (unsigned char c : slack) bad += c != 0xA5;
+    std::string where;
+    bad += guard_damage(chk, &where);
+    if (bad) {
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.violations++;
+        if (r.first_violation.empty()) r.first_violation = where.empty() ? a.what + ": slack bytes behind the allocation overwritten" : where;
+        std::fprintf(stderr, "NRC_GUARD_ALLOC: %s\n", r.first_violation.c_str());
+    }
+    (void)hipFree(a.base);
+}
 
 // RCCL is bound at run time (dlopen by soname: inside a PyTorch process this resolves to the librccl.so.1 torch already
 // loaded, so both share one library instance); the product has no link-time dependency on it.
@@ -226,12 +318,12 @@ public:
         const uint32_t cap = mlp_->grid_list_capacity(train_batch_size_);
         if (cap == grid_cap_ && n_lists <= grid_lists_) return;
         NRC_HIP(hipDeviceSynchronize());
-        if (d_grid_send_) NRC_HIP(hipFree(d_grid_send_));
-        if (d_grid_recv_) NRC_HIP(hipFree(d_grid_recv_));
+        if (d_grid_send_) dev_free(d_grid_send_);
+        if (d_grid_recv_) dev_free(d_grid_recv_);
         grid_cap_ = cap;
         grid_lists_ = n_lists;
-        NRC_HIP(hipMalloc(&d_grid_send_, Mlp::grid_list_words(cap) * 4));
-        NRC_HIP(hipMalloc(&d_grid_recv_, Mlp::grid_list_words(cap) * 4 * n_lists));
+        dev_alloc(&d_grid_send_, Mlp::grid_list_words(cap) * 4, "d_grid_send_");
+        dev_alloc(&d_grid_recv_, Mlp::grid_list_words(cap) * 4 * n_lists, "d_grid_recv_");
     }
     void exchange_sparse(hipStream_t st)
     {
@@ -425,7 +517,7 @@ struct SceneDev {
                         bits[cidx >> 5] |= 1u << (cidx & 31);
                     }
             }
-        NRC_HIP(hipMalloc(&d_occ_bits, bits.size() * 4));
+        dev_alloc(&d_occ_bits, bits.size() * 4, "d_occ_bits");
         NRC_HIP(hipMemcpy(d_occ_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
         d.occ_bits = (const uint32_t*)d_occ_bits;
         d.occ_shift = sh; d.occ_gx = gx; d.occ_gy = gy; d.occ_words = (uint32_t)bits.size();
@@ -470,7 +562,7 @@ struct SceneDev {
             }
         n_boxes = (uint32_t)(boxes.size() / 6);
         if (n_boxes) {
-            NRC_HIP(hipMalloc(&d_boxes, boxes.size() * 4));
+            dev_alloc(&d_boxes, boxes.size() * 4, "d_boxes");
             NRC_HIP(hipMemcpy(d_boxes, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice));
         }
     }
@@ -483,7 +575,7 @@ struct SceneDev {
         // the kernels index voxels with 24-bit multiply-adds and read them through a raw buffer whose out-of-range offset is 2^31
         if (s.nx >= (1u << 24) || (size_t)s.ny * s.nz >= ((size_t)1 << 24) || nvox >= ((size_t)1 << 31))
             fail("density volume too large (needs nx < 2^24, ny*nz < 2^24 and fewer than 2^31 voxels)");
-        NRC_HIP(hipMalloc(&d_density, nvox));
+        dev_alloc(&d_density, nvox, "d_density");
         NRC_HIP(hipMemcpy(d_density, s.density, nvox, hipMemcpyHostToDevice));
         d.density = (const uint8_t*)d_density;
         d.nx = s.nx; d.ny = s.ny; d.nz = s.nz;
@@ -509,7 +601,7 @@ struct SceneDev {
         d.env = nullptr; d.env_w = d.env_h = 0;
         if (s.env && s.env_w && s.env_h) {
             const size_t eb = (size_t)s.env_w * s.env_h * 16;
-            NRC_HIP(hipMalloc(&d_env, eb));
+            dev_alloc(&d_env, eb, "d_env");
             NRC_HIP(hipMemcpy(d_env, s.env, eb, hipMemcpyHostToDevice));
             d.env = (const float*)d_env; d.env_w = s.env_w; d.env_h = s.env_h;
         }
@@ -533,10 +625,10 @@ struct SceneDev {
     }
     ~SceneDev()
     {
-        if (d_density) (void)hipFree(d_density);
-        if (d_env) (void)hipFree(d_env);
-        if (d_boxes) (void)hipFree(d_boxes);
-        if (d_occ_bits) (void)hipFree(d_occ_bits);
+        if (d_density) dev_free(d_density);
+        if (d_env) dev_free(d_env);
+        if (d_boxes) dev_free(d_boxes);
+        if (d_occ_bits) dev_free(d_occ_bits);
     }
 };
 
@@ -655,7 +747,7 @@ static const float* flight_table()
     if ((size_t)dev >= tables.size()) tables.resize((size_t)dev + 1, nullptr);
     if (tables[dev] == nullptr) {
         float* t = nullptr;
-        NRC_HIP(hipMalloc(&t, (size_t)kFlightStates * sizeof(float)));
+        dev_alloc(&t, (size_t)kFlightStates * sizeof(float), "t");
         launch_flight_table(t, nullptr);
         NRC_HIP(hipStreamSynchronize(nullptr));
         tables[dev] = t;
@@ -757,7 +849,7 @@ public:
     ~Renderer()
     {
         (void)hipDeviceSynchronize();
-        for (void* p : allocs_) (void)hipFree(p);
+        for (void* p : allocs_) dev_free(p);
         for (auto& set : ev_pool_)
             for (auto& e : set) if (e) (void)hipEventDestroy(e);
         if (stream_b_) (void)hipStreamDestroy(stream_b_);
@@ -1010,6 +1102,15 @@ public:
         sync();      // intermediate buffers are produced on both streams
         const size_t px = (size_t)w_ * h_, T = (size_t)tg_.tw * tg_.th;
         void* p = nullptr; size_t b = 0;
+        // which + 16 * (k + 1): buffer `which` (0..4) of gen_rays output set k instead of the last frame's set (diagnostics)
+        if (which >= 16) {
+            const int k = which / 16 - 1;
+            if (k >= kGenSets || which % 16 > 4) fail("bad buffer id");
+            void* const* sets[5] = {d_primary2_, d_info2_, d_origin2_, d_dir2_, d_infer_in2_};
+            const size_t sizes[5] = {px * 16, px * 4, px * 16, px * 16, px * 20};
+            if (bytes) *bytes = sizes[which % 16];
+            return sets[which % 16][k];
+        }
         switch (which) {
         case 0: p = d_primary_; b = px * 16; break;
         case 1: p = d_info_; b = px * 4; break;
@@ -1058,7 +1159,7 @@ public:
 private:
     void alloc(void** p, size_t bytes)
     {
-        NRC_HIP(hipMalloc(p, bytes));
+        dev_alloc(p, bytes, "renderer buffer");
         NRC_HIP(hipMemset(*p, 0, bytes));     // the reference never clears its images at creation (quirk Q14); this build does
         allocs_.push_back(*p);
     }
@@ -1146,30 +1247,30 @@ public:
         frame_ = make_frame(w, h, tile);
         scene_.upload(scene);
         const size_t px = (size_t)w * h;
-        NRC_HIP(hipMalloc(&d_out_, px * 16)); NRC_HIP(hipMemset(d_out_, 0, px * 16));
-        NRC_HIP(hipMalloc(&d_info_, px * 4)); NRC_HIP(hipMemset(d_info_, 0, px * 4));
-        NRC_HIP(hipMalloc(&d_fetch_, 8)); NRC_HIP(hipMemset(d_fetch_, 0, 8));
-        NRC_HIP(hipMalloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4));
+        dev_alloc(&d_out_, px * 16, "d_out_"); NRC_HIP(hipMemset(d_out_, 0, px * 16));
+        dev_alloc(&d_info_, px * 4, "d_info_"); NRC_HIP(hipMemset(d_info_, 0, px * 4));
+        dev_alloc(&d_fetch_, 8, "d_fetch_"); NRC_HIP(hipMemset(d_fetch_, 0, 8));
+        dev_alloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4, "d_tile_mask_");
         NRC_HIP(hipEventCreate(&ev_[0])); NRC_HIP(hipEventCreate(&ev_[1]));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
         // costliest-first tile launch order, as in the NRC renderer (one stream here: the sort simply follows the sampled frame)
         cost_order_ = getenv("NRC_NO_COST_ORDER") == nullptr;
         n_slots_ = camera_slots(w, h);
-        NRC_HIP(hipMalloc(&d_tile_cost_, (size_t)n_slots_ * 4));
-        NRC_HIP(hipMalloc(&d_tile_order_, (size_t)n_slots_ * 4));
+        dev_alloc(&d_tile_cost_, (size_t)n_slots_ * 4, "d_tile_cost_");
+        dev_alloc(&d_tile_order_, (size_t)n_slots_ * 4, "d_tile_order_");
         std::vector<uint32_t> ident(n_slots_);
         for (uint32_t i = 0; i < n_slots_; i++) ident[i] = i;
         NRC_HIP(hipMemcpy(d_tile_order_, ident.data(), (size_t)n_slots_ * 4, hipMemcpyHostToDevice));
     }
     ~McRenderer()
     {
-        if (d_out_) (void)hipFree(d_out_);
-        if (d_info_) (void)hipFree(d_info_);
-        if (d_fetch_) (void)hipFree(d_fetch_);
-        if (d_tile_mask_) (void)hipFree(d_tile_mask_);
-        if (d_tile_cost_) (void)hipFree(d_tile_cost_);
-        if (d_tile_order_) (void)hipFree(d_tile_order_);
+        if (d_out_) dev_free(d_out_);
+        if (d_info_) dev_free(d_info_);
+        if (d_fetch_) dev_free(d_fetch_);
+        if (d_tile_mask_) dev_free(d_tile_mask_);
+        if (d_tile_cost_) dev_free(d_tile_cost_);
+        if (d_tile_order_) dev_free(d_tile_order_);
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     }
     void set_empty_skip(bool on) { empty_skip_ = on; mask_dirty_ = true; }      // same stream: ordered behind frames in flight
@@ -1628,14 +1729,34 @@ int nrc_compare_images(const float* d_ref, const float* d_own, uint32_t w, uint3
     return guarded([&] {
         double* scratch = nullptr;
         float* d_res = nullptr;
-        NRC_HIP(hipMalloc(&scratch, (8 + 5 * 256) * sizeof(double)));
-        NRC_HIP(hipMalloc(&d_res, 5 * sizeof(float)));
+        nrc::dev_alloc(&scratch, (8 + 5 * 256) * sizeof(double), "compare scratch");
+        nrc::dev_alloc(&d_res, 5 * sizeof(float), "compare result");
         nrc::launch_compare(d_ref, d_own, w * h, scratch, d_res, (hipStream_t)stream);
         NRC_HIP(hipMemcpyAsync(result5, d_res, 5 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
         NRC_HIP(hipStreamSynchronize((hipStream_t)stream));
-        (void)hipFree(scratch);
-        (void)hipFree(d_res);
+        nrc::dev_free(scratch);
+        nrc::dev_free(d_res);
     });
+}
+
+int nrc_debug_check_guards(char* message, size_t message_bytes)
+{
+    // NRC_GUARD_ALLOC=1: number of allocations (live ones checked now + freed ones found damaged) whose canaries were overwritten
+    nrc::AllocRegistry& r = nrc::alloc_registry();
+    if (message && message_bytes) message[0] = 0;
+    if (!r.guard) return -1;
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lock(r.mu);
+    unsigned long long n = r.violations;
+    std::string first = r.first_violation;
+    for (auto& kv : r.live) {
+        nrc::AllocInfo chk = kv.second;
+        chk.bytes = (chk.bytes + 255) & ~(size_t)255;
+        std::string where;
+        if (nrc::guard_damage(chk, &where)) { n++; if (first.empty()) first = where; }
+    }
+    if (message && message_bytes) { std::strncpy(message, first.c_str(), message_bytes - 1); message[message_bytes - 1] = 0; }
+    return (int)n;
 }
 
 int nrc_test_math(int fn, const float* d_a, const float* d_b, uint32_t n, float* d_out, float* d_out2, void* stream)

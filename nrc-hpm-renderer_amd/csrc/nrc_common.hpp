@@ -29,6 +29,17 @@ struct HipError : std::runtime_error {
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// Every device allocation of the library goes through these two (nrc_api.hip).  Diagnostic environment switches, read once:
+//   NRC_POISON_ALLOC=1  every allocation is filled with 0xFF bytes at creation (fp32 NaN, fp16 NaN, index 0xFFFFFFFF): whatever a
+//                       kernel reads without anyone having written it shows up in the result instead of hiding behind the zeros
+//                       of a freshly booted box;
+//   NRC_GUARD_ALLOC=1   4 KiB of 0xA5 canary bytes in front of and behind every allocation; nrc_debug_check_guards() (and every
+//                       dev_free) verifies them -- a kernel that stores outside its buffer is named by the allocation it ran over.
+void dev_alloc(void** p, size_t bytes, const char* what = "");
+void dev_free(void* p);
+template <class T>
+inline void dev_alloc(T** p, size_t bytes, const char* what = "") { dev_alloc(reinterpret_cast<void**>(p), bytes, what); }
+
 // O'Neill's pcg32 (XSH-RR): the generator tiny-cuda-nn uses for weight init (seed 1337)
 struct Pcg32 {
     uint64_t state = 0, inc = 1;
@@ -48,3 +59,11 @@ struct Pcg32 {
 };
 
 }  // namespace nrc
+
+// DIAGNOSTIC build only (-DNRC_DIAG_SETPRIO, tests/cpp/stress_main.cpp): the side-stream kernels raise their waves' issue priority.
+// Round 2 saw wrong lanes in co-resident k_gen_rays waves with this in place; never defined in the product.
+#ifdef NRC_DIAG_SETPRIO
+#define NRC_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#else
+#define NRC_RAISE_WAVE_PRIORITY() do { } while (0)
+#endif

@@ -154,7 +154,10 @@ __device__ unsigned long long g_wave_times[4 * 65536];
 #define NRC_PROF_LIVE(which, mask) do { } while (0)
 #endif
 
-struct Ctx {
+// COUNT: the density look-ups are counted (nrc_renderer_count_fetches: a measurement launch); in the product launch the counter,
+// its register and its adds do not exist
+template <bool COUNT>
+struct CtxT {
     const DevScene& sc;
     float rng;              // randomState
     uint32_t fetches;
@@ -169,6 +172,10 @@ struct Ctx {
     {
         rng = random1(rng);
         return rng * max_val;
+    }
+    __device__ __forceinline__ void count(uint32_t n)
+    {
+        if constexpr (COUNT) fetches += n;
     }
 };
 
@@ -186,7 +193,8 @@ __device__ __forceinline__ const uint32_t* load_occupancy(const DevScene& sc, ui
     return s_occ;
 }
 
-__device__ __forceinline__ void init_random(Ctx& c, float u, float v, const float* frame_random)
+template <class C>
+__device__ __forceinline__ void init_random(C& c, float u, float v, const float* frame_random)
 {
     c.rng = random2(random2(u, v), random4(frame_random));
 }
@@ -213,7 +221,8 @@ __device__ __forceinline__ float sky_sdf_step(const DevScene& s, V3 p)
     return sqrt_rn_normal(dot(dm, dm)) + fminf(m3, 0.0f);
 }
 
-__device__ __forceinline__ void find_entry_exit(Ctx& c, V3 ro, V3 rd, V3* entry, V3* exit_)
+template <class C>
+__device__ __forceinline__ void find_entry_exit(C& c, V3 ro, V3 rd, V3* entry, V3* exit_)
 {
     const DevScene& s = c.sc;
     float dist;
@@ -245,14 +254,15 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
 // volume.glsl:31-39; sampler: R8 UNORM, NEAREST, CLAMP_TO_BORDER black (src/Texture3D.cpp:79-81,221).
 // One byte per voxel, fetched with a 32-bit voxel index (24-bit mads); the per-axis border test is branch-free and
 // out-of-range lanes read voxel 0 and discard it.
-__device__ __forceinline__ float get_density(Ctx& c, V3 p)
+template <class C>
+__device__ __forceinline__ float get_density(C& c, V3 p)
 {
     const DevScene& s = c.sc;
     float u = nrc_fmaf_(p.x, s.inv_size[0], 0.5f);
     float v = nrc_fmaf_(p.y, s.inv_size[1], 0.5f);
     float w = nrc_fmaf_(p.z, s.inv_size[2], 0.5f);
     float fx = u * s.fnx, fy = v * s.fny, fz = w * s.fnz;
-    c.fetches++;
+    c.count(1u);
     const bool inb = (fx >= 0.0f) & (fx < s.fnx) & (fy >= 0.0f) & (fy < s.fny) & (fz >= 0.0f) & (fz < s.fnz);
     const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
     uint32_t idx = mad24(mad24(iz, s.ny, iy), s.nx, ix);
@@ -273,7 +283,8 @@ struct Addr2 {
 struct Fetch2 {
     uint32_t b0, b1;
 };
-__device__ __forceinline__ Addr2 fetch2_addr(const Ctx& c, V3 dir, V3 start, float t1, float t2, bool first, bool second)
+template <class C>
+__device__ __forceinline__ Addr2 fetch2_addr(const C& c, V3 dir, V3 start, float t1, float t2, bool first, bool second)
 {
     const DevScene& s = c.sc;
     const f2 t = f2{t1, t2};
@@ -302,7 +313,8 @@ __device__ __forceinline__ Addr2 fetch2_addr(const Ctx& c, V3 dir, V3 start, flo
     }
     return Addr2{in0 ? idx0 : 0x80000000u, in1 ? idx1 : 0x80000000u};
 }
-__device__ __forceinline__ Fetch2 fetch2_load(Ctx& c, const Addr2& a)
+template <class C>
+__device__ __forceinline__ Fetch2 fetch2_load(C& c, const Addr2& a)
 {
     Fetch2 f;
     f.b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)a.i0, 0, 0);
@@ -338,7 +350,8 @@ __device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
               nrc_fmaf_(c2.z, v.z, nrc_fmaf_(c1.z, v.y, c0.z * v.x)));
 }
 
-__device__ __forceinline__ V3 new_ray_dir(Ctx& c, V3 old_dir, bool phase_sampling)
+template <class C>
+__device__ __forceinline__ V3 new_ray_dir(C& c, V3 old_dir, bool phase_sampling)
 {
     NRC_PROF(c, 4);
     old_dir = normalize(old_dir);
@@ -408,7 +421,8 @@ __device__ __forceinline__ void pair_both(float x, float* lo, float* hi)
 // the surviving walks of a ratio_track loop, two lanes per walk.  On entry: `alive` lanes have a located trip whose base state is
 // (bs, bt) = (chain value before its first draw, free-flight position before it), n collisions done.  On exit: tr / rng of the alive
 // lanes are the finished walks' results.
-__device__ __forceinline__ void ratio_pairs(Ctx& c, unsigned long long am, bool alive, V3 start, V3 dir, float t_max, float inv, float bs,
+template <class C>
+__device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool alive, V3 start, V3 dir, float t_max, float inv, float bs,
                                             float bt, uint32_t n, float& tr, float& rng)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -454,7 +468,7 @@ __device__ __forceinline__ void ratio_pairs(Ctx& c, unsigned long long am, bool 
         const Addr2 ad = fetch2_addr(c, dr, st, is_b ? t3 : t1, is_b ? t4 : t2, ma, mb);
         const Fetch2 fa = fetch2_load(c, ad);
         const f2 dens = fetch2_density(c.sc, fa);
-        c.fetches += (ma ? 1u : 0u) + (mb ? 1u : 0u);
+        c.count((ma ? 1u : 0u) + (mb ? 1u : 0u));
         float f1, f2_, f3, f4;
         pair_both(nrc_fmaf_(-dens.x, inv, 1.0f), &f1, &f3);
         pair_both(nrc_fmaf_(-dens.y, inv, 1.0f), &f2_, &f4);
@@ -480,8 +494,8 @@ __device__ __forceinline__ void ratio_pairs(Ctx& c, unsigned long long am, bool 
 // the overlap is gone.  Lanes that have finished keep their results and issue no gathers (offset 2^31).
 // UNI: the call sits in wave-uniform control flow (every lane of the wave executes it, `valid` says which lanes have a walk), so
 // the lanes without a walk can help with the thin trips at the end (ratio_pairs)
-template <bool UNI = false>
-__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
 {
     V3 d = sub(end, start);
     const V3 dir = normalize(d);
@@ -521,7 +535,7 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool vali
         __builtin_amdgcn_sched_barrier(0);
         const f2 dens = fetch2_density(c.sc, fa);
         const bool two = alive & a.second;
-        c.fetches += alive ? (a.second ? 2u : 1u) : 0u;
+        c.count(alive ? (a.second ? 2u : 1u) : 0u);
         tr = alive ? tr * nrc_fmaf_(-dens.x, inv, 1.0f) : tr;
         tr = two ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
         rng = (alive & (!a.second | last)) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
@@ -537,7 +551,8 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool vali
 #else
 // reference form of the loop (diagnostic build -DNRC_TRACK_PIPELINE=0): two collisions per trip, gathers awaited in the trip
 // get_density at start + dir*t1 and start + dir*t2 (second fetch masked unless `second`); returns densities
-__device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, float t2, bool second)
+template <class C>
+__device__ __forceinline__ f2 get_density2(C& c, V3 dir, V3 start, float t1, float t2, bool second)
 {
     const DevScene& s = c.sc;
     const f2 t = f2{t1, t2};
@@ -559,8 +574,8 @@ __device__ __forceinline__ f2 get_density2(Ctx& c, V3 dir, V3 start, float t1, f
     const uint8_t b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx1, 0, 0);
     return splat(s.density_factor) * (f2{(float)b0, (float)b1} * splat(1.0f / 255.0f));
 }
-template <bool UNI = false>
-__device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
 {
     if (!valid) return 1.0f;
     V3 d = sub(end, start);
@@ -579,7 +594,7 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool vali
         const float t2 = nrc_fmaf_(-l.y, inv, t1);
         const bool second = !(t2 >= t_max);
         const f2 dens = get_density2(c, dir, start, t1, t2, second);
-        c.fetches += second ? 2u : 1u;
+        c.count(second ? 2u : 1u);
         tr *= nrc_fmaf_(-dens.x, inv, 1.0f);
         rng = s2;
         if (!second) break;
@@ -591,8 +606,8 @@ __device__ __forceinline__ float ratio_track(Ctx& c, V3 start, V3 end, bool vali
 }
 #endif
 
-template <bool UNI = false>
-__device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 trace_dir_light(C& c, V3 pos, V3 dir, bool valid = true)
 {
     const DevScene& s = c.sc;
     if (s.dir_light_strength == 0.0f) return v3(0, 0, 0);
@@ -606,8 +621,8 @@ __device__ __forceinline__ V3 trace_dir_light(Ctx& c, V3 pos, V3 dir, bool valid
     return v3(l, l, l);
 }
 
-template <bool UNI = false>
-__device__ __forceinline__ V3 trace_point_light(Ctx& c, V3 pos, V3 dir, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 trace_point_light(C& c, V3 pos, V3 dir, bool valid = true)
 {
     const DevScene& s = c.sc;
     if (s.point_light_strength == 0.0f) return v3(0, 0, 0);
@@ -652,8 +667,8 @@ __device__ __forceinline__ V3 sample_env_dir(const DevScene& s, V3 dir)
     return env_lookup(s, nrc_fmaf_(phi, 0.1591f, 0.5f), nrc_fmaf_(theta, 0.3183f, 0.5f));
 }
 
-template <bool UNI = false>
-__device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 sample_env(C& c, V3 pos, V3 dir, bool valid = true)
 {
     if (c.sc.env_strength == 0.0f) return v3(0, 0, 0);
     V3 rdir = v3(0.0f, 0.0f, 1.0f);
@@ -671,8 +686,8 @@ __device__ __forceinline__ V3 sample_env(Ctx& c, V3 pos, V3 dir, bool valid = tr
     return v3((e.x * phase) * tr, (e.y * phase) * tr, (e.z * phase) * tr);
 }
 
-template <bool UNI = false>
-__device__ __forceinline__ V3 trace_scene(Ctx& c, V3 pos, V3 dir, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 trace_scene(C& c, V3 pos, V3 dir, bool valid = true)
 {
     NRC_PROF(c, 5);
     V3 a = trace_dir_light<UNI>(c, pos, dir, valid);
@@ -712,7 +727,8 @@ __device__ __forceinline__ DeltaTrip delta_trip(float rng, float t, float t_max,
 // the surviving walks of a delta_track loop, two lanes per walk (see ratio_pairs): four tentative collisions per iteration -- eight
 // draws (flight, acceptance, flight, ...) by both lanes, collisions 1, 2 located and looked up by the lower lane and 3, 4 by the
 // upper one, then resolved in sequence: exit on the first flight beyond the segment, hit on the first accepted collision.
-__device__ __forceinline__ void delta_pairs(Ctx& c, unsigned long long am, bool alive, V3 ro, V3 rd, float t_max, float inv, float bs, float bt,
+template <class C>
+__device__ __forceinline__ void delta_pairs(C& c, unsigned long long am, bool alive, V3 ro, V3 rd, float t_max, float inv, float bs, float bt,
                                             uint32_t n, float& rng, bool& hit, float& t_hit, bool& vexit)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -776,7 +792,7 @@ __device__ __forceinline__ void delta_pairs(Ctx& c, unsigned long long am, bool 
         NRC_DELTA_STEP(3u, s3, a3, t3, !(t3 >= tm), d3)
         NRC_DELTA_STEP(4u, s4, a4, t4, !(t4 >= tm), d4)
 #undef NRC_DELTA_STEP
-        c.fetches += is_b ? 0u : nf;                     // counted once per walk
+        c.count(is_b ? 0u : nf);                     // counted once per walk
         act = go & (nn + 4u < 128u);
         nn += 4u;
         R0 = a4;
@@ -792,8 +808,8 @@ __device__ __forceinline__ void delta_pairs(Ctx& c, unsigned long long am, bool 
 }
 
 #if NRC_TRACK_PIPELINE
-template <bool UNI = false>
-__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
 {
     V3 en, ex;
     if constexpr (UNI) {      // lanes without a walk march a harmless ray (from the centre along +z): the march must end for them too
@@ -838,12 +854,12 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         const Addr2 ib = fetch2_addr(c, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
         __builtin_amdgcn_sched_barrier(0);
         const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
-        c.fetches += alive ? 1u : 0u;
+        c.count(alive ? 1u : 0u);
         const bool acc1 = alive & (dens.x > a.a1);
         const bool alive2 = alive & !acc1;
         const bool out2 = alive2 & !a.second;                        // collision 2 beyond the exit point
         const bool alive3 = alive2 & a.second;
-        c.fetches += alive3 ? 1u : 0u;
+        c.count(alive3 ? 1u : 0u);
         const bool acc2 = alive3 & (dens.y > a.a2);
         hit |= acc1 | acc2;
         t_hit = acc1 ? a.t1 : (acc2 ? a.t2 : t_hit);
@@ -868,8 +884,8 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
     return madd(rd, c.rand(t_max), ro);
 }
 #else
-template <bool UNI = false>
-__device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
 {
     *volume_exit = false;
     if (!valid) return ro;
@@ -891,12 +907,12 @@ __device__ __forceinline__ V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exi
         const float t2 = nrc_fmaf_(-l.y, inv, t1);
         const bool second = !(t2 >= t_max);
         const f2 dens = get_density2(c, rd, ro, t1, t2, second) * splat(inv);
-        c.fetches++;
+        c.count(1u);
         rng = a1;
         if (dens.x > a1) { hit = true; t_hit = t1; break; }
         rng = s2;
         if (!second) { *volume_exit = true; break; }
-        c.fetches++;
+        c.count(1u);
         rng = a2;
         if (dens.y > a2) { hit = true; t_hit = t2; break; }
         t = t2;
@@ -1049,6 +1065,7 @@ __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint3
 #ifndef NRC_GEN_WAVES_PER_SIMD
 #define NRC_GEN_WAVES_PER_SIMD NRC_CAMERA_WAVES_PER_SIMD
 #endif
+template <bool COUNT>
 __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD) void k_gen_rays(DevScene sc, DevCamera cam, DevFrame fr, uint32_t primary_ray_length,
                                                  float primary_ray_prob, float4* __restrict__ primary,
                                                  float* __restrict__ info, float4* __restrict__ origin,
@@ -1071,7 +1088,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         g_wave_times[4 * wave_id + 3] = hw;
     }
 #endif
-    Ctx c{sc, 0.0f, 0u};
+    CtxT<COUNT> c{sc, 0.0f, 0u};
     c.occ = occ;
     // Wave-uniform control flow with per-lane predicates from here to the stores: a lane whose path has ended (or that has none)
     // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
@@ -1093,6 +1110,17 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
 #endif
     }
     const bool entered = enter && !(sky_sdf(sc, entry) > 100000.0f);
+    // The colour of a pixel that does not scatter -- the environment along its camera ray, throughput 1 (gen_rays.comp:86-95) -- is
+    // stored NOW, before the walk; a pixel that scatters overwrites it at the end (same lane, same address: the stores are
+    // performed in order).  The camera ray direction is therefore dead during the walk.  Kept live for the end, two of its
+    // components were the ONE value this kernel spilled (8 bytes per lane of scratch), and that spill is where both non-determinism
+    // events of round 2 came from: with high-priority waves of other queues co-resident, the reload returned -- in lanes 48..63,
+    // i.e. one 64-byte segment of each of the wave's scratch rows -- the direction ANOTHER wave had spilled to the same scratch
+    // slot earlier (tests/cpp/stress_main.cpp).  The kernel has no scratch now (tests/test_abi.py checks that).
+    if (inside) {
+        const V3 e = sample_env_dir(sc, rd);
+        primary[(size_t)y * fr.w + lx] = make_float4(e.x, e.y, e.z, 1.0f);
+    }
     V3 light = v3(0, 0, 0);
     V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
     float factor = 1.0f;
@@ -1117,12 +1145,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     }
     if (inside) {
         const size_t pix = (size_t)y * fr.w + lx;
-        V3 col;
-        float thr = 1.0f;
         float q[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if (!entered) {
-            col = sample_env_dir(sc, rd);
-        } else {
+        if (entered) {
             // the NRC vertex images (nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) have one reader besides the query packing
             // fused in here: prep_train_rays, at the pixels (tx * xDist, ty * yDist) of the train grid.  Only those are stored
             // (32 B for 16 384 of 2 073 600 pixels instead of 66 MB per frame) unless the caller asks for the whole images.
@@ -1135,16 +1159,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
                 dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
             }
-            col = light;
-            thr = factor;
-            if (!did_scatter) {
-                col = sample_env_dir(sc, rd);
-                thr = 1.0f;
-            } else {
+            if (did_scatter) {
                 nrc_query(sc, cur, dir, q);
+                primary[pix] = make_float4(light.x, light.y, light.z, factor);      // replaces the environment colour stored above
             }
         }
-        primary[pix] = make_float4(col.x, col.y, col.z, thr);
         info[pix] = did_scatter ? 1.0f : 0.0f;
         // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
         // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
@@ -1156,7 +1175,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     // per-pixel look-up count in the w component of the origin image (tools/lane_model.py)
     if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = (float)c.fetches;
 #endif
-    count_fetches(fetch_counter, c.fetches);
+    if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
     // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order)
     if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
 #if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
@@ -1168,6 +1187,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
 }
 
 // ------------------------------------------------------------------------------------------------ mc/render.comp
+template <bool COUNT>
 __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_SIMD) void k_mc_render(DevScene sc, DevCamera cam, DevFrame fr, uint32_t path_length,
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
@@ -1177,7 +1197,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const uint32_t* occ = load_occupancy(sc, s_occ);
     uint32_t lx = 0, y = 0, slot;
     const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
-    Ctx c{sc, 0.0f, 0u};
+    CtxT<COUNT> c{sc, 0.0f, 0u};
     c.occ = occ;
     // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
     const uint32_t gx = global_x(fr, lx);
@@ -1220,7 +1240,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                     blend_factor * col.z + ib * prev.z, blend_factor * a + ib * prev.w);
         if (info) info[pix] = a;
     }
-    count_fetches(fetch_counter, c.fetches);
+    if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
     if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
         store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4);
 }
@@ -1317,6 +1337,7 @@ __global__ __launch_bounds__(256) void k_tile_mask(const float* __restrict__ box
 __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, const float* __restrict__ info,
                                                     uint32_t* __restrict__ ring, uint32_t* __restrict__ scratch)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     __shared__ uint32_t wsum[16];
     const uint32_t T = tg.tw * tg.th;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1381,6 +1402,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
                                                    const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
                                                    float* __restrict__ train_target)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1391,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     const bool in_grid = tx < tg.tw && ty < tg.th;
     const uint32_t T = tg.tw * tg.th;
     const uint32_t i = in_grid ? ty * tg.tw + tx : 0u;
-    Ctx c{sc, 0.0f, 0u};
+    CtxT<false> c{sc, 0.0f, 0u};
     c.occ = occ;
     // seed from TRAIN coordinates over the render size (quirk Q6, prep_train_rays.comp:108); sharded: global column
     const uint32_t gx = global_x(fr, tx);
@@ -1450,6 +1472,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
 __global__ void k_ring_push(DevFrame fr, TrainGrid tg, const float4* __restrict__ origin, const float4* __restrict__ dirs,
                             uint32_t* __restrict__ ring, const uint32_t* __restrict__ scratch)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t T = tg.tw * tg.th;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (tg.ring_size == 0) return;
@@ -1475,6 +1498,7 @@ __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nr
                                                   const float4* __restrict__ primary, const float* __restrict__ info,
                                                   const float* __restrict__ infer_out, float4* __restrict__ out_rgba)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     uint32_t lx, y;
     if (!pixel_of_thread(fr, &lx, &y)) return;
     const size_t pix = (size_t)y * fr.w + lx, lin = (size_t)lx * fr.h + y;
@@ -1619,7 +1643,11 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
                      unsigned long long* fetch_counter, const TrainGrid& tg, bool full_vertex_images, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gen_rays, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
+    auto kernel = fetch_counter ? k_gen_rays<true> : k_gen_rays<false>;      // the look-up counter exists only in measurement launches
+#ifdef NRC_LOOP_PROFILE
+    kernel = k_gen_rays<true>;      // (the profiling build's per-pixel look-up counts, tools/lane_model.py)
+#endif
+    hipLaunchKernelGGL(kernel, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
                        fetch_counter, tg, full_vertex_images ? 1 : 0);
     NRC_HIP(hipGetLastError());
@@ -1652,8 +1680,8 @@ void launch_flight_table(float* table, hipStream_t s)
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mc_render, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
-                       path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
+    hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,
+                       cam, fr, path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
     NRC_HIP(hipGetLastError());
 }
 

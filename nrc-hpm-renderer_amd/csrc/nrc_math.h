@@ -6,7 +6,7 @@
  * defined.  To make per-pixel control flow reproducible between the CPU oracle and the HIP kernels this build
  * defines them: Cephes-style single-precision polynomials whose Horner steps are explicit single-rounding fused
  * multiply-adds (v_fma_f32 == fmaf on the host); translation units that include this header are compiled with
- * -ffp-contract=off so that nothing else is contracted; hipcc's default correctly rounded fp32 / and sqrt are relied upon.  tests/test_math_parity.py checks these bit-for-bit against the oracle's own statement.
+ * -ffp-contract=off so that nothing else is contracted; hipcc's default correctly rounded fp32 / and sqrt are relied upon.  tests/test_gpu_math.py checks these bit-for-bit against the oracle's own statement.
  */
 #ifndef NRC_MATH_H
 #define NRC_MATH_H

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
                                                   int skip_zero = 0)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     unsigned long long t0 = 0, r0 = 0;
@@ -543,6 +544,7 @@ template <int DEPTH, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const uint4* __restrict__ img_fwd,
                                                           const uint4* __restrict__ img_bwd)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     uint4* lb = lw + n_frag_fwd(DEPTH) * 64;
@@ -1002,6 +1004,7 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
                                                       const uint4* __restrict__ img, int depth, int ks0,
                                                       const float* __restrict__ skip_in, const float* __restrict__ raw_in = nullptr)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = THREADS / 64;
     constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);        // largest stage (layer 0 has ks0 <= 5 k-steps)
     constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;      // uint4 per thread per stage
@@ -1243,6 +1246,7 @@ template <int WIDTH, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
                                                          const uint4* __restrict__ img_bwd)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, THREADS = WAVES * 64;
     constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);
     constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;
@@ -1454,6 +1458,7 @@ __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __rest
                                                            const WgradTile* __restrict__ tiles, int n_tiles,
                                                            float* __restrict__ slabs, uint32_t n_params)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t k0 = blockIdx.x * WGRAD_CHUNK;
@@ -1491,6 +1496,7 @@ __global__ __launch_bounds__(256) void k_reduce_grads(const float* __restrict__ 
                                                      float* __restrict__ grad, const float* __restrict__ loss_part,
                                                      uint32_t n_loss, float* __restrict__ loss)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     __shared__ float part[4][64];
     __shared__ float red[256];
     const uint32_t p = threadIdx.x & 63u, g = threadIdx.x >> 6;
@@ -1594,6 +1600,7 @@ __global__ __launch_bounds__(256) void k_opt_pack(float* __restrict__ w, float* 
                                                  AdamArgs a, PackDst d, const float* __restrict__ loss, uint32_t loss_seq,
                                                  unsigned long long* __restrict__ loss_cell)
 {
+    NRC_RAISE_WAVE_PRIORITY();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && loss_cell != nullptr) {
         const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, loss[0]) | ((unsigned long long)loss_seq << 32);
@@ -1735,12 +1742,12 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     for (uint32_t i = 0; i < n_grid; i++) w[n_mlp_ + i] = rng.nextf() * 2e-4f - 1e-4f;
 
     const size_t pb = (size_t)n_params_ * sizeof(float);
-    NRC_HIP(hipMalloc(&d_w_, pb));
-    NRC_HIP(hipMalloc(&d_ema_, pb));
-    NRC_HIP(hipMalloc(&d_m_, pb));
-    NRC_HIP(hipMalloc(&d_v_, pb));
+    dev_alloc(&d_w_, pb, "d_w_");
+    dev_alloc(&d_ema_, pb, "d_ema_");
+    dev_alloc(&d_m_, pb, "d_m_");
+    dev_alloc(&d_v_, pb, "d_v_");
     // gradient vector and the {loss, pad} cell share one allocation so that the multi-GPU driver all-reduces both at once
-    NRC_HIP(hipMalloc(&d_grad_, pb + 4 * sizeof(float)));
+    dev_alloc(&d_grad_, pb + 4 * sizeof(float), "d_grad_");
     d_loss_ = d_grad_ + n_params_;
     NRC_HIP(hipMemcpy(d_w_, w.data(), pb, hipMemcpyHostToDevice));
     NRC_HIP(hipMemcpy(d_ema_, w.data(), pb, hipMemcpyHostToDevice));
@@ -1785,8 +1792,8 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
             }
         }
     }
-    NRC_HIP(hipMalloc(&d_src_fwd_, sf.size() * 4));
-    NRC_HIP(hipMalloc(&d_src_bwd_, sb.size() * 4));
+    dev_alloc(&d_src_fwd_, sf.size() * 4, "d_src_fwd_");
+    dev_alloc(&d_src_bwd_, sb.size() * 4, "d_src_bwd_");
     NRC_HIP(hipMemcpy(d_src_fwd_, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
     // Generic models with the Frequency(12) + OneBlob(4) input (configs[4]'s 8x128): EMA inference encodes inside k_infer_gen as
     // k_infer does, so its image takes layer 0's inputs in that encoder's order (fmap80); training keeps k_encode's natural order
@@ -1800,12 +1807,12 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
                     for (int s = 0; s < ks0; s++)
                         if (32 * mt + (lane & 31) < W)
                             si[slot(mt * ks0 + s, lane, j)] = (int32_t)(layers_[0].off + (32 * mt + (lane & 31)) * E + fmap80(s, lane >> 5, j));
-        NRC_HIP(hipMalloc(&d_src_inf_, si.size() * 4));
+        dev_alloc(&d_src_inf_, si.size() * 4, "d_src_inf_");
         NRC_HIP(hipMemcpy(d_src_inf_, si.data(), si.size() * 4, hipMemcpyHostToDevice));
     }
     NRC_HIP(hipMemcpy(d_src_bwd_, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
     for (auto& p : d_pk_infer_) {
-        NRC_HIP(hipMalloc(&p, sf.size() * 2));
+        dev_alloc(&p, sf.size() * 2, "p");
         NRC_HIP(hipMemset(p, 0, sf.size() * 2));      // k_opt_pack never writes the padding slots
     }
     // inverse maps for the one-launch optimizer step (k_opt_pack): parameter -> its slot in each image
@@ -1825,16 +1832,16 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         if (fused_opt_) invert(si_host.data(), si_host.size(), dst.data() + n_mlp_);
         if (fused_opt_) invert(sb.data(), sb.size(), dst.data() + 2 * (size_t)n_mlp_);
         if (fused_opt_) {
-            NRC_HIP(hipMalloc(&d_dst_, dst.size() * 4));
+            dev_alloc(&d_dst_, dst.size() * 4, "d_dst_");
             NRC_HIP(hipMemcpy(d_dst_, dst.data(), dst.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    NRC_HIP(hipMalloc(&d_pk_fwd_, sf.size() * 2));
-    NRC_HIP(hipMalloc(&d_pk_bwd_, sb.size() * 2));
+    dev_alloc(&d_pk_fwd_, sf.size() * 2, "d_pk_fwd_");
+    dev_alloc(&d_pk_bwd_, sb.size() * 2, "d_pk_bwd_");
     if (hash_) {
-        NRC_HIP(hipMalloc(&d_t16_train_, (size_t)n_grid_entries_ * 4));
-        for (auto& p : d_t16_ema_) NRC_HIP(hipMalloc(&p, (size_t)n_grid_entries_ * 4));
-        NRC_HIP(hipMalloc(&d_grad16_, (size_t)n_grid_entries_ * 4));
+        dev_alloc(&d_t16_train_, (size_t)n_grid_entries_ * 4, "d_t16_train_");
+        for (auto& p : d_t16_ema_) dev_alloc(&p, (size_t)n_grid_entries_ * 4, "p");
+        dev_alloc(&d_grad16_, (size_t)n_grid_entries_ * 4, "d_grad16_");
     }
     repack(nullptr);
     NRC_HIP(hipStreamSynchronize(nullptr));
@@ -1842,13 +1849,13 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
 
 Mlp::~Mlp()
 {
-    if (d_src_inf_ != d_src_fwd_ && d_src_inf_) (void)hipFree(d_src_inf_);
-    if (d_dst_) (void)hipFree(d_dst_);
+    if (d_src_inf_ != d_src_fwd_ && d_src_inf_) dev_free(d_src_inf_);
+    if (d_dst_) dev_free(d_dst_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_[0], d_feat_[1], d_t16_train_,
                     d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p);
 }
 
 float* Mlp::buffer(int which)
@@ -1934,10 +1941,10 @@ void Mlp::ensure_features(uint32_t n, int slot)
     if (n <= feat_n_[slot]) return;
     if (d_feat_[slot]) {
         NRC_HIP(hipDeviceSynchronize());      // a kernel on another stream may still read the old buffer
-        (void)hipFree(d_feat_[slot]);
+        dev_free(d_feat_[slot]);
     }
     d_feat_[slot] = nullptr;
-    NRC_HIP(hipMalloc(&d_feat_[slot], (size_t)n * enc_dims_ * 2));
+    dev_alloc(&d_feat_[slot], (size_t)n * enc_dims_ * 2, "d_feat_[slot]");
     feat_n_[slot] = n;
 }
 
@@ -2036,7 +2043,7 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
     if (abl == 4) {
         static unsigned long long* d_st = nullptr;
         constexpr int SLOTS = 16;
-        if (!d_st) NRC_HIP(hipMalloc(&d_st, (size_t)SLOTS * 4 * 2048 * sizeof(unsigned long long)));
+        if (!d_st) dev_alloc(&d_st, (size_t)SLOTS * 4 * 2048 * sizeof(unsigned long long), "d_st");
         static int count = 0;
         const int slot = count % SLOTS;
         hipLaunchKernelGGL((k_infer<6, 512, 2, 4>), dim3(blocks), dim3(512), lds, s, d_in, d_out, n, img, d_st + (size_t)slot * 4 * 2048);
@@ -2090,23 +2097,23 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
 void Mlp::ensure_train_workspace(uint32_t n)
 {
     if (n <= ws_n_) return;
-    if (d_acts_) (void)hipFree(d_acts_);
-    if (d_deltas_) (void)hipFree(d_deltas_);
-    if (d_slabs_) (void)hipFree(d_slabs_);
-    if (d_loss_part_) (void)hipFree(d_loss_part_);
+    if (d_acts_) dev_free(d_acts_);
+    if (d_deltas_) dev_free(d_deltas_);
+    if (d_slabs_) dev_free(d_slabs_);
+    if (d_loss_part_) dev_free(d_loss_part_);
     d_acts_ = d_deltas_ = nullptr;
     d_slabs_ = d_loss_part_ = nullptr;
     const size_t rows_a = enc_dims_ + (size_t)depth_ * kw_, rows_d = (size_t)depth_ * kw_ + 8;
-    NRC_HIP(hipMalloc(&d_acts_, rows_a * n * 2));
-    NRC_HIP(hipMalloc(&d_deltas_, rows_d * n * 2));
+    dev_alloc(&d_acts_, rows_a * n * 2, "d_acts_");
+    dev_alloc(&d_deltas_, rows_d * n * 2, "d_deltas_");
     NRC_HIP(hipMemset(d_deltas_, 0, rows_d * n * 2));
-    NRC_HIP(hipMalloc(&d_slabs_, (size_t)ceil_div(n, WGRAD_CHUNK) * n_mlp_ * 4));
+    dev_alloc(&d_slabs_, (size_t)ceil_div(n, WGRAD_CHUNK) * n_mlp_ * 4, "d_slabs_");
     if (hash_) {
-        if (d_denc_) (void)hipFree(d_denc_);
+        if (d_denc_) dev_free(d_denc_);
         d_denc_ = nullptr;
-        NRC_HIP(hipMalloc(&d_denc_, (size_t)n * 32 * 2));
+        dev_alloc(&d_denc_, (size_t)n * 32 * 2, "d_denc_");
     }
-    NRC_HIP(hipMalloc(&d_loss_part_, (size_t)(n / 32) * 4));
+    dev_alloc(&d_loss_part_, (size_t)(n / 32) * 4, "d_loss_part_");
     ws_n_ = n;
     if (!d_tiles_) {
         std::vector<WgradTile> tiles;
@@ -2128,7 +2135,7 @@ void Mlp::ensure_train_workspace(uint32_t n)
                 }
         }
         n_wgrad_tiles_ = (int)tiles.size();
-        NRC_HIP(hipMalloc(&d_tiles_, tiles.size() * sizeof(WgradTile)));
+        dev_alloc(&d_tiles_, tiles.size() * sizeof(WgradTile), "d_tiles_");
         NRC_HIP(hipMemcpy(d_tiles_, tiles.data(), tiles.size() * sizeof(WgradTile), hipMemcpyHostToDevice));
     }
 }

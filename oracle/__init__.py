@@ -40,6 +40,9 @@ def build(native=False, out_dir=None):
     """Compile the oracle with g++ (recipe = oracle/Makefile). Returns the .so path."""
     out_dir = out_dir or os.path.join(_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
+    if os.environ.get("NRC_ORACLE_ASAN") == "1":      # tests/test_oracle_asan.py: the -fsanitize=address,undefined build (make asan)
+        subprocess.check_call(["make", "-C", _DIR, "asan"], stdout=subprocess.DEVNULL)
+        return os.path.join(_DIR, "_build", "libnrc_oracle_asan.so")
     name = "libnrc_oracle_native.so" if native else "libnrc_oracle.so"
     so = os.path.join(out_dir, name)
     src = os.path.join(_DIR, "nrc_oracle.cpp")

@@ -68,3 +68,25 @@ def test_headers_compile_standalone():
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", inc,
                            os.path.join(root, "tests", "cpp", "header_check.cpp")])
 
+
+
+def test_camera_kernels_use_no_scratch():
+    """k_gen_rays / k_mc_render / k_prep_train must not spill: the one value k_gen_rays used to spill (8 bytes per lane of scratch) came
+    back stale in lanes 48..63 when high-priority waves of other queues were co-resident -- the cause of both non-determinism events
+    of round 2.  Compiles the device code of nrc_integrator.hip with the Makefile's flags and reads the
+    kernels' metadata."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc", "nrc_integrator.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "integ.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                               "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text):
+        if any(k in m.group(1) for k in ("k_gen_rays", "k_mc_render", "k_prep_train")):
+            seen += 1
+            assert int(m.group(2)) == 0, (m.group(1), m.group(2))
+    assert seen >= 5          # k_gen_rays<0/1>, k_mc_render<0/1>, k_prep_train
