@@ -301,6 +301,11 @@ int nrc_mc_renderer_destroy(nrc_mc_renderer_t* r);
 int nrc_compare_images(const float* d_ref_rgba, const float* d_own_rgba, uint32_t w, uint32_t h, void* stream,
                        float result5[5]);
 
+/* device-resident RGBA32F image [h][w] for nrc_compare_images: a copy of host_rgba (NULL: zeros) -- the reference image that
+ * Reference::GenRefImages loads from reference/<scene>/0.exr into a VkImage (src/Reference.cpp:608-660) */
+int nrc_image_create(uint32_t w, uint32_t h, const float* host_rgba, float** d_out);
+int nrc_image_destroy(float* d_image);
+
 /* diagnostics (environment, read when the library first allocates): NRC_POISON_ALLOC=1 fills every device allocation with 0xFF
  * bytes at creation; NRC_GUARD_ALLOC=1 puts 4 KiB canaries around every allocation.  nrc_debug_check_guards returns -1 when the
  * guard mode is off, otherwise the number of allocations whose canaries were overwritten (0 = clean) and, in message, the first. */

@@ -6,7 +6,9 @@
 //   en::NrcHpmRenderer        include/engine/graphics/renderer/NrcHpmRenderer.hpp:16-41
 //   en::McHpmRenderer         include/engine/graphics/renderer/McHpmRenderer.hpp:16-31
 //   en::Camera                include/engine/graphics/Camera.hpp:18-60, src/Camera.cpp:164-174   (values only, no Vulkan)
-//   en::HpmScene              include/engine/HpmScene.hpp:12-43, src/HpmScene.cpp:24-76          (values only, no Vulkan)
+//   en::HpmScene              include/engine/HpmScene.hpp:12-43, src/HpmScene.cpp:24-76          (values only, no Vulkan; loads the
+//                             cloud itself with the dependency-free VDB reader of nrc_vdb.hpp, src/Texture3D.cpp:12-82)
+//   en::Reference             include/engine/graphics/Reference.hpp:14-39, src/Reference.cpp:9-145,443-455,566-660
 // with the Vulkan/CUDA-interop types replaced: VkQueue -> hipStream_t (as void*), the two cudaExternalSemaphore_t of
 // Init() -> two hipEvent_t (as void*; the overload without them relies on stream order), VkImage/VkImageView -> device
 // pointer to the RGBA32F framebuffer, glm::vec3 -> en::vec3.
@@ -15,12 +17,16 @@
 // which must outlive it; Destroy() is explicit and idempotent, destructors call it.
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <filesystem>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "nrc_exr.hpp"
 #include "nrc_hpm.h"
+#include "nrc_vdb.hpp"
 
 namespace en {
 
@@ -210,19 +216,17 @@ public:
              uint32_t envWidth = 0, uint32_t envHeight = 0)
         : m_ID(appConfig.scene.id), m_Dynamic(appConfig.scene.dynamic)
     {
-        m_Scene.density = density; m_Scene.nx = nx; m_Scene.ny = ny; m_Scene.nz = nz;
-        m_Scene.size[0] = m_Scene.size[1] = m_Scene.size[2] = 0.0f;      // normalize(extent) * 107.5, src/NrcHpmRenderer.cu:910-912
-        m_Scene.density_factor = appConfig.scene.density;
-        m_Scene.g = 0.8f;
-        m_Scene.dir_light_strength = appConfig.scene.dirLightStrength;
-        m_Scene.point_light_pos[0] = m_Scene.point_light_pos[1] = m_Scene.point_light_pos[2] = 0.0f;
-        m_Scene.point_light_color[0] = m_Scene.point_light_color[1] = m_Scene.point_light_color[2] = 1.0f;
-        m_Scene.point_light_strength = appConfig.scene.pointLightStrength;
-        m_Scene.env_strength = appConfig.scene.hdrEnvMapStrength;
-        if (envRgba) { m_Scene.env = envRgba; m_Scene.env_w = envWidth; m_Scene.env_h = envHeight; }
-        else { m_Scene.env = m_BlackEnv; m_Scene.env_w = 1; m_Scene.env_h = 1; }
-        SetDirLightAngles(-1.57f, 0.0f);
+        SetUp(appConfig, density, nx, ny, nz, envRgba, envWidth, envHeight);
     }
+    // HpmScene(appConfig), src/HpmScene.cpp:24-55: the scene loads its density volume itself -- vk::Texture3D::FromVDB on
+    // "data/volume/wdas_cloud_quarter.vdb" (:44) -- here with the reader of nrc_vdb.hpp; the environment map is the reference's:
+    // whatever file it names, every texel ends up 1.0 (quirk Q9, src/read_file.cpp:129-130), an empty path gives one black texel
+    explicit HpmScene(const AppConfig& appConfig, const std::string& vdbPath = "data/volume/wdas_cloud_quarter.vdb")
+        : m_ID(appConfig.scene.id), m_Dynamic(appConfig.scene.dynamic), m_Volume(ReadVdb(vdbPath))
+    {
+        SetUp(appConfig, m_Volume.density.data(), m_Volume.nx, m_Volume.ny, m_Volume.nz, appConfig.scene.hdrEnvMapPath.empty() ? nullptr : m_WhiteEnv, 1, 1);
+    }
+    const VdbVolume& Volume() const { return m_Volume; }
     HpmScene(const HpmScene&) = delete;
     HpmScene& operator=(const HpmScene&) = delete;
     // HpmScene::Update(renderImgui, deltaTime), src/HpmScene.cpp:56-76: only a dynamic scene 3 moves (azimuth += dt / 2,
@@ -248,10 +252,28 @@ public:
     nrc_scene& Scene() { return m_Scene; }
 
 private:
+    void SetUp(const AppConfig& appConfig, const uint8_t* density, uint32_t nx, uint32_t ny, uint32_t nz, const float* envRgba, uint32_t envWidth,
+               uint32_t envHeight)
+    {
+        m_Scene.density = density; m_Scene.nx = nx; m_Scene.ny = ny; m_Scene.nz = nz;
+        m_Scene.size[0] = m_Scene.size[1] = m_Scene.size[2] = 0.0f;      // normalize(extent) * 107.5, src/NrcHpmRenderer.cu:910-912
+        m_Scene.density_factor = appConfig.scene.density;
+        m_Scene.g = 0.8f;
+        m_Scene.dir_light_strength = appConfig.scene.dirLightStrength;
+        m_Scene.point_light_pos[0] = m_Scene.point_light_pos[1] = m_Scene.point_light_pos[2] = 0.0f;
+        m_Scene.point_light_color[0] = m_Scene.point_light_color[1] = m_Scene.point_light_color[2] = 1.0f;
+        m_Scene.point_light_strength = appConfig.scene.pointLightStrength;
+        m_Scene.env_strength = appConfig.scene.hdrEnvMapStrength;
+        if (envRgba) { m_Scene.env = envRgba; m_Scene.env_w = envWidth; m_Scene.env_h = envHeight; }
+        else { m_Scene.env = m_BlackEnv; m_Scene.env_w = 1; m_Scene.env_h = 1; }
+        SetDirLightAngles(-1.57f, 0.0f);
+    }
     uint32_t m_ID;
     bool m_Dynamic;
     float m_Zenith = -1.57f, m_Azimuth = 0.0f;
     float m_BlackEnv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float m_WhiteEnv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    VdbVolume m_Volume;
     nrc_scene m_Scene{};
 };
 
@@ -386,6 +408,93 @@ public:
 
 private:
     nrc_mc_renderer_t* h_ = nullptr;
+};
+
+// en::Reference (src/Reference.cpp): the converged ground-truth image of a scene, seen from a fixed reference camera, and the
+// comparison of a renderer's frame with it -- Result{mse, refMean, ownMean, ownVar, validPixelCount} by the three passes of
+// data/shader/ref/{cmp1,norm,cmp2}.comp (here nrc_compare_images: deterministic fp64 tree sums).  The constructor does what
+// CreateRefCameras / GenRefImages do (:443-455, :566-660): the camera of :447-454; if <referenceRoot><scene id>/ does not exist,
+// an McHpmRenderer with PATH_LENGTH 64 blends `generateFrames` (8192) frames from that camera and exports 0.exr there; then
+// 0.exr is loaded (it must have the render size) and uploaded.  (The reference's "#if __cplusplus >= 201703L" around the
+// generation is inverted -- a C++17 build only warns and then fails to load the image; the intended behaviour is implemented.)
+class Reference {
+public:
+    struct Result {
+        float mse = 0.0f;                  // MSE of "not reference" to reference
+        float refMean = 0.0f;              // mean of the reference image
+        float ownMean = 0.0f;              // mean of the "not reference" image
+        float ownVar = 0.0f;               // variance of the "not reference" image
+        uint32_t validPixelCount = 0;      // pixels whose reference alpha is not 0
+        float GetBias() const { return ownMean - refMean; }                 // src/Reference.cpp:9-27
+        float GetRelBias() const { return GetBias() / refMean; }
+        float GetRelVar() const { return ownVar / refMean; }
+        float GetCV() const { return std::sqrt(ownVar) / ownMean; }
+    };
+
+    Reference(uint32_t width, uint32_t height, const AppConfig& appConfig, const HpmScene& scene, void* queue,
+              const std::string& referenceRoot = "reference/", uint32_t generateFrames = 8192)
+        : m_Width(width), m_Height(height), m_Queue(queue),
+          m_RefCamera(vec3(64.0f, 0.0f, 0.0f), vec3(-1.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), static_cast<float>(width) / static_cast<float>(height),
+                      radians(60.0f), 0.1f, 100.0f)
+    {
+        const std::string dir = referenceRoot + std::to_string(appConfig.scene.id) + "/";
+        const std::string path = dir + "0.exr";
+        if (!std::filesystem::is_directory(dir)) {
+            std::printf("Reference folder for scene %u was not found. Creating reference images\n", appConfig.scene.id);
+            McHpmRenderer refRenderer(width, height, 64, true, &m_RefCamera, scene, queue);
+            std::filesystem::create_directories(dir);
+            for (uint32_t frame = 0; frame < generateFrames; frame++) refRenderer.Render(queue);
+            refRenderer.ExportOutputImageToFile(queue, path);
+            refRenderer.Destroy();
+        }
+        uint32_t w = 0, h = 0;
+        const std::vector<float> rgba = LoadExrRGBA(path, &w, &h);
+        if (w != width || h != height) throw std::runtime_error("SkyRenderer ERROR: " + path + " has wrong resolution");
+        nrc_check(nrc_image_create(width, height, rgba.data(), &m_RefImage));
+    }
+    ~Reference() { Destroy(); }
+    Reference(const Reference&) = delete;
+    Reference& operator=(const Reference&) = delete;
+
+    // src/Reference.cpp:72-107: the renderer looks from the reference camera, renders one frame without training, is compared,
+    // and gets its camera back
+    Result CompareNrc(NrcHpmRenderer& renderer, const Camera* oldCamera, void* queue)
+    {
+        renderer.SetCamera(queue, &m_RefCamera);
+        renderer.Render(queue, false);
+        const Result result = Compare(renderer.GetImage());
+        renderer.SetCamera(queue, oldCamera);
+        return result;
+    }
+    Result CompareMc(McHpmRenderer& renderer, const Camera* oldCamera, void* queue)      // :109-145
+    {
+        renderer.SetCamera(queue, &m_RefCamera);
+        renderer.Render(queue);
+        const Result result = Compare(renderer.GetImage());
+        renderer.SetCamera(queue, oldCamera);
+        return result;
+    }
+    void Destroy()
+    {
+        if (m_RefImage) { nrc_image_destroy(m_RefImage); m_RefImage = nullptr; }
+    }
+    const float* GetRefImage() const { return m_RefImage; }      // device, RGBA32F [height][width]
+    const Camera* GetRefCamera() const { return &m_RefCamera; }
+
+private:
+    Result Compare(const float* dOwnImage)
+    {
+        float r[5];
+        nrc_check(nrc_compare_images(m_RefImage, dOwnImage, m_Width, m_Height, m_Queue, r));
+        Result result;
+        result.mse = r[0]; result.refMean = r[1]; result.ownMean = r[2]; result.ownVar = r[3]; result.validPixelCount = (uint32_t)r[4];
+        std::printf("MSE: %f | rBias: %f | rVar: %f\n", result.mse, result.GetRelBias(), result.GetRelVar());      // Log::Info, :99-103
+        return result;
+    }
+    uint32_t m_Width, m_Height;
+    void* m_Queue;
+    Camera m_RefCamera;
+    float* m_RefImage = nullptr;
 };
 
 }  // namespace en

@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
     "nrc_mc_renderer_set_frame_random", "nrc_mc_renderer_framebuffer", "nrc_mc_renderer_export_exr",
     "nrc_mc_renderer_frame_time_ms", "nrc_mc_renderer_count_fetches", "nrc_mc_renderer_destroy",
-    "nrc_compare_images", "nrc_test_math", "nrc_test_rng", "nrc_debug_check_guards",
+    "nrc_compare_images", "nrc_test_math", "nrc_test_rng", "nrc_debug_check_guards", "nrc_image_create", "nrc_image_destroy",
 ]
 
 _lib = None

@@ -1739,6 +1739,23 @@ int nrc_compare_images(const float* d_ref, const float* d_own, uint32_t w, uint3
     });
 }
 
+int nrc_image_create(uint32_t w, uint32_t h, const float* host_rgba, float** d_out)
+{
+    NRC_REQUIRE(d_out); NRC_REQUIRE(w > 0 && h > 0);
+    return guarded([&] {
+        float* d = nullptr;
+        nrc::dev_alloc(&d, (size_t)w * h * 16, "image");
+        if (host_rgba) NRC_HIP(hipMemcpy(d, host_rgba, (size_t)w * h * 16, hipMemcpyHostToDevice));
+        else NRC_HIP(hipMemset(d, 0, (size_t)w * h * 16));
+        *d_out = d;
+    });
+}
+int nrc_image_destroy(float* d_image)
+{
+    if (!d_image) return NRC_OK;
+    return guarded([&] { nrc::dev_free(d_image); });
+}
+
 int nrc_debug_check_guards(char* message, size_t message_bytes)
 {
     // NRC_GUARD_ALLOC=1: number of allocations (live ones checked now + freed ones found damaged) whose canaries were overwritten

@@ -60,10 +60,12 @@ struct Pcg32 {
 
 }  // namespace nrc
 
-// DIAGNOSTIC build only (-DNRC_DIAG_SETPRIO, tests/cpp/stress_main.cpp): the side-stream kernels raise their waves' issue priority.
-// Round 2 saw wrong lanes in co-resident k_gen_rays waves with this in place; never defined in the product.
+// DIAGNOSTIC builds only (-DNRC_DIAG_SETPRIO=<mask>, tests/cpp/stress_main.cpp): side-stream kernels raise their waves' issue
+// priority -- bit 0 the inference / training kernels (nrc_mlp.hip), bit 1 k_composite, bit 2 the train-ray kernels (k_train_scan,
+// k_prep_train, k_ring_push).  With it, co-resident k_gen_rays waves misbehave a few per cent of the time;
+// never defined in the product.
 #ifdef NRC_DIAG_SETPRIO
-#define NRC_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#define NRC_RAISE_WAVE_PRIORITY(bit) do { if ((NRC_DIAG_SETPRIO) & (bit)) __builtin_amdgcn_s_setprio(3); } while (0)
 #else
-#define NRC_RAISE_WAVE_PRIORITY() do { } while (0)
+#define NRC_RAISE_WAVE_PRIORITY(bit) do { } while (0)
 #endif

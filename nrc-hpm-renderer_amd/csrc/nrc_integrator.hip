@@ -1125,6 +1125,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
     float factor = 1.0f;
     bool did_scatter = false, walking = entered;
+#ifdef NRC_DIAG_LASTDIR
+    // diagnostic build (tests/cpp/stress_main.cpp): RNG state and a hash of the incoming direction in front of the path's last
+    // new_ray_dir, stored in the w components of the vertex images
+    float dbg_rng_in = 0.0f, dbg_dir_in = 0.0f;
+#endif
     for (int i = 0;; i++) {
         if (__ballot(walking) == 0ull) break;
         bool vexit = false;
@@ -1137,6 +1142,10 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         const V3 ts = trace_scene<true>(c, cur, dir, walking);
         if (walking) {
             light = add(light, mul(ts, factor));
+#ifdef NRC_DIAG_LASTDIR
+            dbg_rng_in = c.rng;
+            dbg_dir_in = nrc_u2f((nrc_f2u(dir.x) * 3u) ^ (nrc_f2u(dir.y) * 5u) ^ (nrc_f2u(dir.z) * 7u));
+#endif
             dir = new_ray_dir(c, dir, true);
             if ((uint32_t)i >= primary_ray_length) {
                 if (c.rand(1.0f) >= primary_ray_prob || i == 128) walking = false;
@@ -1156,8 +1165,13 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 on_grid = (qx * tg.x_dist == lx) & (qy * tg.y_dist == y) & (qx < tg.tw) & (qy < tg.th);
             }
             if (on_grid) {
+#ifdef NRC_DIAG_LASTDIR
+                origin[pix] = make_float4(cur.x, cur.y, cur.z, dbg_rng_in);
+                dirs[pix] = make_float4(dir.x, dir.y, dir.z, dbg_dir_in);
+#else
                 origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
                 dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+#endif
             }
             if (did_scatter) {
                 nrc_query(sc, cur, dir, q);
@@ -1337,7 +1351,7 @@ __global__ __launch_bounds__(256) void k_tile_mask(const float* __restrict__ box
 __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, const float* __restrict__ info,
                                                     uint32_t* __restrict__ ring, uint32_t* __restrict__ scratch)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(4);
     __shared__ uint32_t wsum[16];
     const uint32_t T = tg.tw * tg.th;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1402,7 +1416,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
                                                    const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
                                                    float* __restrict__ train_target)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(4);
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1472,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
 __global__ void k_ring_push(DevFrame fr, TrainGrid tg, const float4* __restrict__ origin, const float4* __restrict__ dirs,
                             uint32_t* __restrict__ ring, const uint32_t* __restrict__ scratch)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(4);
     const uint32_t T = tg.tw * tg.th;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (tg.ring_size == 0) return;
@@ -1498,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nr
                                                   const float4* __restrict__ primary, const float* __restrict__ info,
                                                   const float* __restrict__ infer_out, float4* __restrict__ out_rgba)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(2);
     uint32_t lx, y;
     if (!pixel_of_thread(fr, &lx, &y)) return;
     const size_t pix = (size_t)y * fr.w + lx, lin = (size_t)lx * fr.h + y;

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
                                                   int skip_zero = 0)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     unsigned long long t0 = 0, r0 = 0;
@@ -544,7 +544,7 @@ template <int DEPTH, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const uint4* __restrict__ img_fwd,
                                                           const uint4* __restrict__ img_bwd)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* lw = reinterpret_cast<uint4*>(smem);
     uint4* lb = lw + n_frag_fwd(DEPTH) * 64;
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
                                                       const uint4* __restrict__ img, int depth, int ks0,
                                                       const float* __restrict__ skip_in, const float* __restrict__ raw_in = nullptr)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = THREADS / 64;
     constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);        // largest stage (layer 0 has ks0 <= 5 k-steps)
     constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;      // uint4 per thread per stage
@@ -1246,7 +1246,7 @@ template <int WIDTH, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const uint4* __restrict__ img_fwd,
                                                          const uint4* __restrict__ img_bwd)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, THREADS = WAVES * 64;
     constexpr int STAGE_FRAGS = MTG * (KSG > 5 ? KSG : 5);
     constexpr int PF = (STAGE_FRAGS * 64 + THREADS - 1) / THREADS;
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __rest
                                                            const WgradTile* __restrict__ tiles, int n_tiles,
                                                            float* __restrict__ slabs, uint32_t n_params)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t k0 = blockIdx.x * WGRAD_CHUNK;
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_reduce_grads(const float* __restrict__ 
                                                      float* __restrict__ grad, const float* __restrict__ loss_part,
                                                      uint32_t n_loss, float* __restrict__ loss)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     __shared__ float part[4][64];
     __shared__ float red[256];
     const uint32_t p = threadIdx.x & 63u, g = threadIdx.x >> 6;
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_opt_pack(float* __restrict__ w, float* 
                                                  AdamArgs a, PackDst d, const float* __restrict__ loss, uint32_t loss_seq,
                                                  unsigned long long* __restrict__ loss_cell)
 {
-    NRC_RAISE_WAVE_PRIORITY();
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && loss_cell != nullptr) {
         const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, loss[0]) | ((unsigned long long)loss_seq << 32);

@@ -4,7 +4,10 @@
 // GetLoss() poll per frame, IsBlending(), GetImage().  tests/test_gpu_cpp_dropin.py feeds it a volume, and compares what it
 // writes with the same frames rendered through the Python mirror.
 //
-//   dropin_main <scene.bin> <out.bin> <frames> <17 positional AppConfig arguments>
+//   dropin_main <scene.bin> <out.bin> <frames> <17 positional AppConfig arguments> [reference root directory]
+// With the optional last argument the program also does what src/main.cu:140-150 does in benchmark mode: en::Reference (ground truth
+// generated on first use, 16 blended frames here instead of 8192, exported as <root>/<scene>/0.exr and loaded back), CompareNrc and
+// CompareMc with their Result{mse, refMean, ownMean, ownVar, validPixelCount} / GetRelBias() / GetCV(); appended to out.bin.
 //
 // scene.bin: u32 width,height,nx,ny,nz; f32 env rgba (1x1); f32 frame_random[frames][4]; u8 density[nx*ny*nz]
 // out.bin:   f32 loss; f32 inv_proj_view[16], cam_pos[3] (what en::Camera computed); f32 dir_light_dir[3]; f32 image[h][w][4]
@@ -26,10 +29,11 @@ static void rd(FILE* f, T* p, size_t n)
 int main(int argc, char** argv)
 {
     try {
-        if (argc != 4 + 17) throw std::runtime_error("usage: dropin_main scene.bin out.bin frames <17 AppConfig args>");
+        if (argc != 4 + 17 && argc != 5 + 17) throw std::runtime_error("usage: dropin_main scene.bin out.bin frames <17 AppConfig args> [reference root]");
         const int frames = std::atoi(argv[3]);
+        const char* refRoot = argc == 5 + 17 ? argv[4 + 17] : nullptr;
         std::vector<char*> cfg_argv{argv[0]};
-        for (int i = 4; i < argc; i++) cfg_argv.push_back(argv[i]);
+        for (int i = 4; i < 4 + 17; i++) cfg_argv.push_back(argv[i]);
         en::AppConfig appConfig(cfg_argv);
 
         FILE* f = std::fopen(argv[1], "rb");
@@ -85,6 +89,28 @@ int main(int argc, char** argv)
         std::fwrite(camera.Matrices()->pos, sizeof(float), 3, o);
         std::fwrite(hpmScene.Scene().dir_light_dir, sizeof(float), 3, o);
         std::fwrite(image.data(), sizeof(float), image.size(), o);
+        if (refRoot) {
+            // src/main.cu:140-150 (Benchmark): one NRC frame and one MC frame from the reference camera against the ground truth
+            en::Reference reference(W, H, appConfig, hpmScene, nullptr, refRoot, 16);                // generates <root>/<id>/0.exr
+            const en::Reference::Result nrcResult = reference.CompareNrc(nrcHpmRenderer, &camera, nullptr);
+            en::McHpmRenderer mcHpmRenderer(W, H, 32, true, &camera, hpmScene);                      // src/main.cu:212
+            const en::Reference::Result mcResult = reference.CompareMc(mcHpmRenderer, &camera, nullptr);
+            en::Reference again(W, H, appConfig, hpmScene, nullptr, refRoot, 1u << 30);               // the folder exists: loaded, not rendered
+            const en::Reference::Result mcAgain = again.CompareMc(mcHpmRenderer, &camera, nullptr);
+            for (const en::Reference::Result* r : {&nrcResult, &mcResult, &mcAgain}) {
+                const float v[8] = {r->mse, r->refMean, r->ownMean, r->ownVar, (float)r->validPixelCount, r->GetRelBias(), r->GetCV(), r->GetRelVar()};
+                std::fwrite(v, sizeof(float), 8, o);
+            }
+            std::vector<float> own((size_t)W * H * 4), ref((size_t)W * H * 4);
+            if (hipMemcpy(own.data(), mcHpmRenderer.GetImage(), own.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(ref.data(), again.GetRefImage(), ref.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                throw std::runtime_error("hipMemcpy failed");
+            std::fwrite(ref.data(), sizeof(float), ref.size(), o);
+            std::fwrite(own.data(), sizeof(float), own.size(), o);
+            mcHpmRenderer.Destroy();
+            again.Destroy();
+            reference.Destroy();
+        }
         std::fclose(o);
         std::printf("frames %d loss %.9g frame %.3f ms name %s\n", frames, loss, nrcHpmRenderer.GetFrameTimeMS(), appConfig.GetName().c_str());
         // explicit Destroy() in the reference's order (src/main.cu:401-412); destructors are idempotent

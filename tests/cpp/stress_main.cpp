@@ -179,6 +179,7 @@ static Snapshot render(const Setup& su, const nrc_config& cfg, uint32_t gw, uint
     nrc_renderer_t* r = nullptr;
     en::nrc_check(nrc_cache_create(&cfg, &c));
     en::nrc_check(nrc_renderer_create(lw, gh, 1, camera.Matrices(), &cfg, &su.scene, c, tile, nullptr, &r));
+    if (g_keep_sets) en::nrc_check(nrc_renderer_set_full_vertex_images(r, 1));      // (diagnostic builds put their probes into the w components)
     for (uint32_t f = 0; f < su.frames; f++) {
         en::nrc_check(nrc_renderer_set_frame_random(r, &su.randoms[(size_t)f * 4]));
         en::nrc_check(nrc_renderer_render(r, train ? 1 : 0));        // no host synchronisation between frames
@@ -190,7 +191,7 @@ static Snapshot render(const Setup& su, const nrc_config& cfg, uint32_t gw, uint
     HIPCHK(hipMemcpy(s.image.data(), d_img, s.image.size() * 4, hipMemcpyDeviceToHost));
     if (g_keep_sets)
         for (int k = 0; k < 4; k++)
-            for (int b : {0, 1, 4}) {
+            for (int b : {0, 1, 4, 2, 3}) {
                 size_t bytes = 0;
                 void* p = nrc_renderer_buffer(r, b + 16 * (k + 1), &bytes);
                 s.sets[k].push_back(download(p, bytes));
@@ -311,6 +312,14 @@ int main(int argc, char** argv)
                             const float* qt = (const float*)&parts[r].sets[k][2][((size_t)lx * GH + y) * 20];
                             const float* qw = (const float*)&whole.sets[k][2][((size_t)x * GH + y) * 20];
                             const bool dp = std::memcmp(pt, pw, 16) != 0, di = std::memcmp(it, iw, 4) != 0, dq = std::memcmp(qt, qw, 20) != 0;
+                            const float* ot = (const float*)&parts[r].sets[k][3][((size_t)y * lw + lx) * 16];
+                            const float* ow = (const float*)&whole.sets[k][3][((size_t)y * GW + x) * 16];
+                            const float* dt = (const float*)&parts[r].sets[k][4][((size_t)y * lw + lx) * 16];
+                            const float* dw = (const float*)&whole.sets[k][4][((size_t)y * GW + x) * 16];
+                            if (dp || di || dq)
+                                std::printf("   px (%u, %u) set %d: vertex pos %s, final dir %s, [diag build: rng before the last new_ray_dir %s (%.9g | %.9g), incoming dir hash %s]; final dir tiles %.9g %.9g %.9g whole %.9g %.9g %.9g\n",
+                                            x, y, k, std::memcmp(ot, ow, 12) ? "DIFF" : "same", std::memcmp(dt, dw, 12) ? "DIFF" : "same", std::memcmp(ot + 3, ow + 3, 4) ? "DIFF" : "same", ot[3], ow[3],
+                                            std::memcmp(dt + 3, dw + 3, 4) ? "DIFF" : "same", dt[0], dt[1], dt[2], dw[0], dw[1], dw[2]);
                             if (dp || di || dq)
                                 std::printf("   px (%u, %u) set %d: primary %s info %s query %s | tiles prim %.9g %.9g %.9g %.9g info %g q %.9g %.9g %.9g %.9g %.9g | whole prim %.9g %.9g %.9g %.9g info %g q %.9g %.9g %.9g %.9g %.9g\n",
                                             x, y, k, dp ? "DIFF" : "same", di ? "DIFF" : "same", dq ? "DIFF" : "same", pt[0], pt[1], pt[2], pt[3], it[0], qt[0], qt[1], qt[2], qt[3], qt[4],

@@ -28,12 +28,30 @@ def test_cpp_host_program_matches_python_mirror(api, sc, torch_gpu, tmp_path):
         f.write(np.asarray(scene["env"], np.float32).reshape(-1)[:4].tobytes())
         f.write(np.asarray(frs, np.float32).tobytes())
         f.write(np.ascontiguousarray(scene["density"], np.uint8).tobytes())
-    r = subprocess.run([exe, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(frames)] + ARGS,
-                       capture_output=True, text=True, timeout=120)
+    ref_root = str(tmp_path / "reference") + "/"
+    r = subprocess.run([exe, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(frames)] + ARGS + [ref_root],
+                       capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr
     assert "name RelativeL2Luminance_Adam_0.010000_0.990000_3_0_64_6_14_10_1_4_1.000000_1_1_0.000000_32" in r.stdout
     raw = np.fromfile(tmp_path / "out.bin", np.float32)
-    loss_cpp, cam_cpp, light_cpp, img_cpp = raw[0], raw[1:20], raw[20:23], raw[23:].reshape(H, W, 4)
+    n_img = H * W * 4
+    loss_cpp, cam_cpp, light_cpp, img_cpp = raw[0], raw[1:20], raw[20:23], raw[23:23 + n_img].reshape(H, W, 4)
+    # ---- en::Reference (src/Reference.cpp): ground truth generated on first use and exported, loaded back through the C++ EXR
+    # reader, CompareNrc / CompareMc and the Result helpers; checked against the Python reader and CompareImages
+    tail = raw[23 + n_img:]
+    res = tail[:24].reshape(3, 8)
+    ref_cpp, own_cpp = tail[24:24 + n_img].reshape(H, W, 4), tail[24 + n_img:24 + 2 * n_img].reshape(H, W, 4)
+    assert "Reference folder for scene 4 was not found. Creating reference images" in r.stdout and r.stdout.count("MSE: ") == 3
+    from nrc_hpm_renderer_amd import io_exr
+    exr = io_exr.read_exr(os.path.join(ref_root, "4", "0.exr"))
+    assert np.array_equal(exr.view(np.uint32), ref_cpp.view(np.uint32))          # C++ reader == Python reader == what was exported
+    assert (ref_cpp[..., 3] > 0).mean() > 0.05 and np.isfinite(ref_cpp).all()
+    got = api.CompareImages(torch_gpu.from_numpy(ref_cpp.copy()).cuda(), torch_gpu.from_numpy(own_cpp.copy()).cuda())
+    mse, ref_mean, own_mean, own_var, valid, rel_bias, cv, rel_var = res[2]
+    assert (mse, ref_mean, own_mean, own_var, valid) == tuple(np.float32(got[k]) for k in ("mse", "ref_mean", "own_mean", "own_var", "valid"))
+    assert valid == (ref_cpp[..., 3] != 0).sum()
+    assert rel_bias == np.float32((own_mean - ref_mean) / ref_mean) and cv == np.float32(np.sqrt(own_var) / own_mean) and rel_var == np.float32(own_var / ref_mean)
+    assert 0 < res[0][0] < 10 and 0 < res[1][0] < 10 and abs(res[1][5]) < 0.5      # one noisy frame against 16 blended ones
     # en::Camera (glm's fp32 perspective * lookAt, cofactor inverse) agrees with the Python mirror's float64 construction to
     # fp32 rounding; en::HpmScene places the directional light like scene.dir_light_dir().  The frames are then compared bit for
     # bit for the camera the C++ program actually used.
