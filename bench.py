@@ -243,11 +243,13 @@ class Job:
         self.ri = 0
 
     def step(self):
+        """one spp-sample frame: spp x NrcHpmRenderer::Render(queue, train), enqueued by ONE call into the library
+        (nrc_renderer_render_frames: the loop of src/main.cu:287 on the library's side of the binding)"""
         self.ren.SetBlend(True)            # progressive blend restarts: sub-frame i has blendFactor 1/(i+1)
-        for _ in range(self.args.spp):
-            self.ren.SetFrameRandom(self.randoms[self.ri % len(self.randoms)])
-            self.ri += 1
-            self.ren.Render(None, bool(self.args.train))
+        n = len(self.randoms)
+        rows = [(self.ri + k) % n for k in range(self.args.spp)]
+        self.ri += self.args.spp
+        self.ren.RenderFrames(self.randoms[rows], bool(self.args.train))
 
     def barrier(self):
         if self.use_dist:
@@ -336,9 +338,8 @@ def main():
     # the critical path only if this approaches the GPU's frame time
     ren.SetBlend(True)
     t_h = time.perf_counter()
-    for _ in range(8):
-        ren.SetFrameRandom(job.randoms[0])
-        ren.Render(None, bool(args.train))
+    for _ in range(2):
+        ren.RenderFrames(job.randoms[:4], bool(args.train))
     host_enqueue_ms = (time.perf_counter() - t_h) / 8 * 1e3
     torch.cuda.synchronize()
     ren.StageStats(reset=True)

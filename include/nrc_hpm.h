@@ -202,6 +202,9 @@ int nrc_renderer_create(uint32_t width, uint32_t height, int blend, const nrc_ca
                         nrc_renderer_t** out);
 /* NrcHpmRenderer::Render(VkQueue, bool train) (src/NrcHpmRenderer.cu:299-353) */
 int nrc_renderer_render(nrc_renderer_t* r, int train);
+/* n_frames consecutive Render(queue, train) calls enqueued by ONE call (the host loop of src/main.cu:287 without a trip through the
+ * binding per frame); frame_randoms: n_frames x 4 floats, frame f's UniformData.random (NULL: the renderer draws them, as Render does) */
+int nrc_renderer_render_frames(nrc_renderer_t* r, uint32_t n_frames, const float* frame_randoms, int train);
 /* NrcHpmRenderer::SetCamera / SetBlend (src/NrcHpmRenderer.cu:561-610) */
 int nrc_renderer_set_camera(nrc_renderer_t* r, const nrc_camera* camera);
 int nrc_renderer_set_blend(nrc_renderer_t* r, int blend);
@@ -262,11 +265,25 @@ int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on);
  * with and without.  tile_order copies the permutation in use (n = nrc_renderer_tile_order(r, NULL, 0) entries) to the host. */
 int nrc_renderer_set_cost_order(nrc_renderer_t* r, int on);
 size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t capacity);
+/* Hot tiles (on by default): a pixel whose RNG state can run into DeltaTrack's cap of 128 collisions inside a tile the empty-space
+ * mask rejects (see set_empty_skip) is ONE lane that walks for ~0.12 ms; started where the launch order has its (empty) tile --
+ * at the very end -- it ends the launch that much later (one frame in four on the bench view: mean 0.213 -> 0.232 ms).  A 3-us
+ * kernel finds such pixels for the NEXT frame's random numbers (drawn one frame early, same sequence; or the ones render_frames
+ * was given) at the end of the train-ray stream's work, and gen_rays starts up to 8 of their tiles first.  Scheduling only: every
+ * tile is traced exactly once either way.  hot_tiles copies the last frame's list -- 8 entries (ty << 16 | tx) and their count --
+ * and returns 1 when the list had been computed one frame ahead, 0 when in front of gen_rays (first frame, pinned random numbers,
+ * another camera), -1 when the frame used none, -2 on error. */
+int nrc_renderer_set_hot_tiles(nrc_renderer_t* r, int on);
+int nrc_renderer_hot_tiles(nrc_renderer_t* r, uint32_t* host_out9);
 /* The NRC vertex images (buffers 2 and 3: nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) are read back only at the pixels of
  * the train grid (prep_train_rays.comp:113-118), so by default gen_rays stores them only there; on != 0 makes it store every
  * pixel that entered the volume, as the reference's images hold (tests, debugging).  vertex_image_bytes: what one frame stores. */
 int nrc_renderer_set_full_vertex_images(nrc_renderer_t* r, int on);
 size_t nrc_renderer_vertex_image_bytes(nrc_renderer_t* r);
+/* per-stage timing events (the reference's eight timestamp queries, src/NrcHpmRenderer.cu:495-530) of train-ray generation,
+ * training, inference and compositing: on by default; off = four timed event records fewer per frame, frame_time_ms / stage_stats
+ * then report gen_rays only */
+int nrc_renderer_set_stage_events(nrc_renderer_t* r, int on);
 /* density look-ups executed by gen_rays (measurement: algorithmic bytes of the integrator).
  * Returns the count accumulated so far in *out (may be NULL), then enables/disables + zeroes the device counter. */
 int nrc_renderer_count_fetches(nrc_renderer_t* r, int enable, unsigned long long* out);

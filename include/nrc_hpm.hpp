@@ -350,6 +350,11 @@ public:
     NrcHpmRenderer& operator=(const NrcHpmRenderer&) = delete;
 
     void Render(void* /*queue: the stream given at construction*/, bool train) { nrc_check(nrc_renderer_render(h_, train ? 1 : 0)); }
+    // nFrames consecutive Render(queue, train) calls, enqueued by one call; frameRandoms: nFrames x 4 floats or nullptr
+    void RenderFrames(void* /*queue*/, uint32_t nFrames, const float* frameRandoms, bool train)
+    {
+        nrc_check(nrc_renderer_render_frames(h_, nFrames, frameRandoms, train ? 1 : 0));
+    }
     void Destroy()
     {
         if (h_) { nrc_renderer_destroy(h_); h_ = nullptr; }

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
     "nrc_cache_get_loss_blocking", "nrc_cache_get_loss_async", "nrc_cache_comm_info", "nrc_cache_comm_time_exchange", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
-    "nrc_renderer_set_cost_order", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order",
+    "nrc_renderer_set_cost_order", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order", "nrc_renderer_set_hot_tiles", "nrc_renderer_hot_tiles",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "nrc_cache_grid_grad_pack", "nrc_cache_grid_grad_apply",
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
     "nrc_cache_get_step", "nrc_cache_set_step",
-    "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
+    "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_render_frames", "nrc_renderer_set_stage_events", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
     "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_framebuffer_on",
     "nrc_renderer_export_exr",
@@ -439,6 +439,16 @@ class NrcHpmRenderer:
     def Render(self, queue=None, train=False):
         _check(self.L.nrc_renderer_render(self.h, C.c_int(int(bool(train)))))
 
+    def RenderFrames(self, frameRandoms, train=False):
+        """len(frameRandoms) consecutive Render(queue, train) calls enqueued by one call into the library; frameRandoms: [n][4]"""
+        r = np.ascontiguousarray(frameRandoms, np.float32).reshape(-1, 4)
+        if not hasattr(self.L, "nrc_renderer_render_frames"):      # an older build loaded through NRC_HPM_LIB (A/B tooling)
+            for row in r:
+                self.SetFrameRandom(row)
+                self.Render(None, train)
+            return
+        _check(self.L.nrc_renderer_render_frames(self.h, C.c_uint32(r.shape[0]), r.ctypes.data_as(C.c_void_p), C.c_int(int(bool(train)))))
+
     def SetCamera(self, queue, camera):
         cam = make_c_camera(camera)
         _check(self.L.nrc_renderer_set_camera(self.h, C.byref(cam)))
@@ -497,6 +507,10 @@ class NrcHpmRenderer:
     def IsBlending(self):
         return bool(self.L.nrc_renderer_is_blending(self.h))
 
+    def SetStageEvents(self, on=True):
+        """per-stage timing events (EvaluateTimestampQueries / StageStats) of every stage (default) or of gen_rays only"""
+        _check(self.L.nrc_renderer_set_stage_events(self.h, C.c_int(int(on))))
+
     def SetEmptySkip(self, on=True):
         """exact empty-space early-out of camera rays (default on); off = every ray is traced"""
         _check(self.L.nrc_renderer_set_empty_skip(self.h, C.c_int(int(on))))
@@ -504,6 +518,22 @@ class NrcHpmRenderer:
     def SetCostOrder(self, on=True):
         """costliest-first launch order of gen_rays' tiles from earlier frames' per-tile times (default on); frames do not change"""
         _check(self.L.nrc_renderer_set_cost_order(self.h, C.c_int(int(on))))
+
+    def SetHotTiles(self, on=True):
+        """start the tiles with a pixel in a capped RNG state first (default on); frames do not change"""
+        _check(self.L.nrc_renderer_set_hot_tiles(self.h, C.c_int(int(on))))
+
+    def HotTiles(self):
+        """(tiles [(tx, ty), ...] gen_rays started first in the last frame, total count found, computed one frame ahead?) or None"""
+        import numpy as np
+        out = np.zeros(9, np.uint32)
+        rc = self.L.nrc_renderer_hot_tiles(self.h, out.ctypes.data_as(C.c_void_p))
+        if rc == -2:
+            raise RuntimeError(self.L.nrc_last_error().decode() or "nrc_renderer_hot_tiles failed")
+        if rc < 0:
+            return None
+        n = int(out[8])
+        return [(int(t & 0xffff), int(t >> 16)) for t in out[:min(n, 8)]], n, rc == 1
 
     def TileOrder(self):
         """the tile permutation the next frame launches in (numpy uint32)"""

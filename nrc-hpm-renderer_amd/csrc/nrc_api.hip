@@ -506,7 +506,8 @@ struct SceneDev {
         auto cells = [&](uint32_t n) { return (n + (1u << sh) - 1u) >> sh; };
         while ((uint64_t)cells(s.nx) * cells(s.ny) * cells(s.nz) > (uint64_t)kOccMaxWords * 32u) sh++;
         const uint32_t gx = cells(s.nx), gy = cells(s.ny), gz = cells(s.nz);
-        std::vector<uint32_t> bits(((size_t)gx * gy * gz + 31) / 32, 0u);
+        // (a multiple of four words: k_gen_rays copies the table in 16-byte pieces)
+        std::vector<uint32_t> bits((((size_t)gx * gy * gz + 31) / 32 + 3) & ~(size_t)3, 0u);
         for (uint32_t z = 0; z < s.nz; z++)
             for (uint32_t y = 0; y < s.ny; y++) {
                 const uint8_t* row = s.density + ((size_t)z * s.ny + y) * s.nx;
@@ -735,8 +736,8 @@ static void write_exr(const std::string& path, const std::vector<float>& rgba, u
 }
 
 // ---------------------------------------------------------------------------------------------------- empty-space skip
-// DevFrame::flight_table: one table per device for the life of the process (32 MB, a function of the hash RNG alone), built by
-// the first renderer that applies a tile mask
+// the free-flight table: one per device for the life of the process (32 MB, a function of the hash RNG alone), built by the first
+// renderer that applies a tile mask; renderers read it only when their mask is (re)built (launch_flight_select)
 static const float* flight_table()
 {
     static std::mutex mu;
@@ -759,14 +760,25 @@ static const float* flight_table()
 // a segment between two points the sphere tracing of find_entry_exit stops at (within 0.125 of the box) is at most the box
 // diagonal + 0.25 long; 0.2 % on top covers the rounding of the walk's and the table's fp32 sums.  Past ~100 most RNG states can
 // reach the cap (the 128 flights cover 128 +- 11 on average) and the mask would be rejected tile after tile: it is not built.
-static bool skip_setup(const DevScene& d, DevFrame* fr)
+// flight_bits / d_scratch9: per-renderer buffers (1 MB, 36 bytes).  Ends with a 36-byte read-back on `s` (a host wait: the
+// mask is rebuilt only when the camera or the medium changes).
+static bool skip_setup(const DevScene& d, DevFrame* fr, uint32_t* d_flight_bits, uint32_t* d_scratch9, hipStream_t s)
 {
     const double diag = std::sqrt((double)d.size[0] * d.size[0] + (double)d.size[1] * d.size[1] + (double)d.size[2] * d.size[2]);
     const double lambda = (double)d.density_factor * (diag + 0.5) * 1.002;
-    fr->flight_table = nullptr;
-    fr->skip_lambda = (float)lambda;
+    fr->flight_mode = 0; fr->flight_n = 0; fr->flight_bits = nullptr;
     if (!(lambda <= 100.0)) return false;
-    fr->flight_table = flight_table();
+    launch_flight_select(flight_table(), (float)lambda, d_scratch9, d_flight_bits, s);
+    uint32_t h[1 + kFlightListMax];
+    NRC_HIP(hipMemcpyAsync(h, d_scratch9, sizeof(h), hipMemcpyDeviceToHost, s));
+    NRC_HIP(hipStreamSynchronize(s));
+    if (h[0] <= kFlightListMax) {
+        fr->flight_mode = 1; fr->flight_n = h[0];
+        for (uint32_t k = 0; k < kFlightListMax; k++) fr->flight_list[k] = k < h[0] ? h[1 + k] : 0xffffffffu;
+    } else {
+        fr->flight_mode = 2; fr->flight_n = h[0];
+        fr->flight_bits = d_flight_bits;
+    }
     return true;
 }
 
@@ -808,6 +820,11 @@ public:
         alloc(&d_scratch_, (2 * T + 4) * 4);
         alloc(&d_fetch_, 8);
         alloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4);
+        alloc(&d_flight_bits_, (size_t)kFlightStates / 8 + 8);
+        alloc(&d_flight_sel_, (1 + kFlightListMax) * 4);
+        for (auto& h : d_hot_) { alloc(&h, 64); NRC_HIP(hipMemset(h, 0, 64)); }
+        for (auto& e : ev_hot_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hot_promote_ = getenv("NRC_NO_HOT_TILES") == nullptr;
         // costliest-first launch order of gen_rays' tiles: costs of frame N order frame N + 2 (sorted on stream D beside frame N + 1)
         n_slots_ = camera_slots(w, h);
         alloc(&d_tile_cost_, (size_t)n_slots_ * 4);
@@ -861,6 +878,7 @@ public:
         for (auto& e : ev_comp_done_) if (e) (void)hipEventDestroy(e);
         if (ev_consumer_) (void)hipEventDestroy(ev_consumer_);
         if (ev_order_done_) (void)hipEventDestroy(ev_order_done_);
+        for (auto& e : ev_hot_) if (e) (void)hipEventDestroy(e);
         cache_.forget(this);
     }
 
@@ -877,8 +895,10 @@ public:
         }
         hipEvent_t* ev_ = ev_pool_[ev_used_++].data();
         const float blend_factor = 1.0f / (float)blend_index_;
+        // (the random numbers of an unpinned frame may have been drawn one frame early, for the hot-tile list: same sequence)
         if (have_pinned_random_) { std::memcpy(frame_.random, pinned_random_, 16); have_pinned_random_ = false; }
-        else { std::uniform_real_distribution<float> u(0.0f, 1.0f); for (float& r : frame_.random) r = u(rng_); }
+        else if (have_next_random_) { std::memcpy(frame_.random, next_random_, 16); have_next_random_ = false; }
+        else draw_random(frame_.random);
         if (blend_) blend_index_++;
         // Frame graph on four streams, pipelined across frames (no host sync anywhere):
         //   A: [wait composite(N-4), train rays(N-4)] gen_rays(N)
@@ -920,6 +940,23 @@ public:
         // the first samples of a view replace the costs (a cold first launch, another camera); later ones keep a decaying maximum
         frame_.tile_cost_keep = order_fresh_ > 0 ? 0u : order_keep_;
         if (sample_cost && order_fresh_ > 0) order_fresh_--;
+        // Hot tiles (DevFrame::hot_tiles): the list for this frame's random numbers was computed at the end of the previous
+        // frame's work on stream D (below); when it was not -- first frame, pinned random numbers, another mask -- it is computed
+        // here, in front of gen_rays.
+        frame_.hot_tiles = nullptr;
+        const int hb = (int)(frame_index_ & 1u);
+        const bool promote = hot_promote_ && frame_.tile_mask != nullptr && frame_.flight_mode == 1u && frame_.flight_n > 0;
+        if (promote) {
+            if (hot_ready_[hb] && D != A) NRC_HIP(hipStreamWaitEvent(A, ev_hot_[hb], 0));
+            last_hot_predicted_ = hot_ready_[hb] && hot_epoch_[hb] == mask_epoch_ && std::memcmp(hot_random_[hb], frame_.random, 16) == 0;
+            if (!last_hot_predicted_) {
+                NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_[hb] + kHotTilesMax, 0, 4, A));
+                launch_hot_tiles(frame_, (uint32_t*)d_hot_[hb], A);
+            }
+            frame_.hot_tiles = (const uint32_t*)d_hot_[hb];
+        }
+        hot_ready_[hb] = false;
+        last_hot_ = promote ? hb : -1;
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
@@ -930,7 +967,7 @@ public:
         // the reference records prep_train_rays into every frame's pre-CUDA command buffer (:2039-2040), trained or not
         launch_prep_train(scene_.d, frame_, tg_, (const float*)d_info_, (const float*)d_origin_, (const float*)d_dir_,
                           (uint32_t*)d_ring_, (uint32_t*)d_scratch_, (float*)d_train_in_, (float*)d_train_target_, D);
-        NRC_HIP(hipEventRecord(ev_[2], D));
+        if (stage_events_) NRC_HIP(hipEventRecord(ev_[2], D));
         NRC_HIP(hipEventRecord(ev_prep_done_[gp], D));
         if (B != D) NRC_HIP(hipStreamWaitEvent(B, ev_prep_done_[gp], 0));
         if (sample_cost) {      // order buffer cur^1: its last reader is a gen_rays before this one on A
@@ -938,6 +975,21 @@ public:
             NRC_HIP(hipEventRecord(ev_order_done_, D));
             order_pending_ = true;
             order_pending_frame_ = frame_index_;
+        }
+        if (promote) {      // the next frame's list (buffer hb^1: its last reader is the gen_rays before this frame's, D is behind this frame's)
+            // the next frame's random numbers: announced by the caller (render_frames), or drawn now instead of then
+            const float* nr = next_random_;
+            if (have_hint_) nr = hint_random_;
+            else if (!have_next_random_) { draw_random(next_random_); have_next_random_ = true; }
+            have_hint_ = false;
+            DevFrame nf = frame_;
+            std::memcpy(nf.random, nr, 16);
+            NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_[hb ^ 1] + kHotTilesMax, 0, 4, D));
+            launch_hot_tiles(nf, (uint32_t*)d_hot_[hb ^ 1], D);
+            NRC_HIP(hipEventRecord(ev_hot_[hb ^ 1], D));
+            hot_ready_[hb ^ 1] = true;
+            hot_epoch_[hb ^ 1] = mask_epoch_;
+            std::memcpy(hot_random_[hb ^ 1], nr, 16);
         }
         if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
@@ -947,11 +999,11 @@ public:
                     (float*)d_train_target_);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
         cache_.infer_all(nullptr, Cs, !dense_infer_);
-        NRC_HIP(hipEventRecord(ev_[3], Cs));
+        if (stage_events_) NRC_HIP(hipEventRecord(ev_[3], Cs));
         NRC_HIP(hipEventRecord(ev_infer_done_[pp], Cs));
         if (train) cache_.train_all(B, (B != Cs && frame_index_ > 0) ? ev_infer_done_[pp ^ 1] : nullptr,
                                     B != Cs ? ev_infer_done_[pp] : nullptr);
-        NRC_HIP(hipEventRecord(ev_[5], B));
+        if (stage_events_) NRC_HIP(hipEventRecord(ev_[5], B));
         NRC_HIP(hipEventRecord(ev_train_done_[pp], B));
         // the framebuffer is ONE image that compositing blends in place: a consumer stream that was handed the previous frame
         // (framebuffer_on) and announced the end of its read (release_frame) holds this frame's compositing back until then
@@ -961,7 +1013,7 @@ public:
         }
         launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
                          (const float*)d_infer_out_, (float*)d_out_, Cs);
-        NRC_HIP(hipEventRecord(ev_[4], Cs));
+        if (stage_events_) NRC_HIP(hipEventRecord(ev_[4], Cs));
         NRC_HIP(hipEventRecord(ev_comp_done_[gp], Cs));
         frame_index_++;
         timed_ = true;
@@ -981,9 +1033,10 @@ public:
     {
         if (!mask_dirty_) return;
         mask_dirty_ = false;
+        mask_epoch_++;
         DevProjView pv;
         frame_.tile_mask = nullptr;
-        if (!empty_skip_ || !forward_transform(nrc_cam_, &pv) || !skip_setup(scene_.d, &frame_)) return;
+        if (!empty_skip_ || !forward_transform(nrc_cam_, &pv) || !skip_setup(scene_.d, &frame_, (uint32_t*)d_flight_bits_, (uint32_t*)d_flight_sel_, A)) return;
         launch_tile_mask((const float*)scene_.d_boxes, scene_.n_boxes, pv, frame_, (uint32_t*)d_tile_mask_, A);
         frame_.tile_mask = (const uint32_t*)d_tile_mask_;
     }
@@ -998,6 +1051,23 @@ public:
     {
         sync();
         cost_order_ = on;
+    }
+    void set_hot_tiles(bool on)
+    {
+        sync();
+        hot_promote_ = on;
+    }
+    // the random numbers of the frame after the next one to be rendered (render_frames knows them): the hot-tile list is computed
+    // for these instead of numbers drawn ahead
+    void hint_next_random(const float* r) { std::memcpy(hint_random_, r, 16); have_hint_ = true; }
+    // the hot-tile list of the last frame: kHotTilesMax entries + count; returns 1 when it was computed one frame ahead, 0 when in
+    // front of gen_rays, -1 when the frame had none
+    int hot_tiles(uint32_t* out9)
+    {
+        sync();
+        if (last_hot_ < 0) return -1;
+        NRC_HIP(hipMemcpy(out9, d_hot_[last_hot_], (kHotTilesMax + 1) * 4, hipMemcpyDeviceToHost));
+        return last_hot_predicted_ ? 1 : 0;
     }
     // the permutation the next frame launches its tiles in (after the pending sort, if one is due)
     size_t tile_order(uint32_t* host_out, size_t capacity)
@@ -1027,6 +1097,9 @@ public:
         }
     }
     void set_blend(bool b) { blend_ = b; blend_index_ = 1; }      // :606-610
+    // the timing events of train-ray generation, training, inference and compositing (four timed hipEventRecord per frame, the
+    // reference's timestamp queries :495-515) can be switched off; gen_rays stays bracketed
+    void set_stage_events(bool on) { sync(); stage_events_ = on; ev_used_ = 0; timed_ = false; }
     void set_scene_params(const nrc_scene& s) { scene_.set_params(s); mask_dirty_ = true; }      // density_factor enters skip_lambda
     void set_show_nrc(bool s) { show_nrc_ = s ? 1u : 0u; }
     void set_frame_random(const float* r) { std::memcpy(pinned_random_, r, 16); have_pinned_random_ = true; }
@@ -1048,10 +1121,10 @@ public:
     {
         const size_t n = ev_used_;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (n > 0) { NRC_HIP(hipEventSynchronize(ev_pool_[n - 1][4])); NRC_HIP(hipEventSynchronize(ev_pool_[n - 1][5])); }
+        if (n > 0) sync();
         for (size_t f = 0; f < n; f++) {
             float st[8];
-            stage_times(ev_pool_[f].data(), st);
+            stage_times(ev_pool_[f].data(), st, stage_events_);
             for (int k = 0; k < 8; k++) acc[k] += st[k];
         }
         if (avg8) for (int k = 0; k < 8; k++) avg8[k] = n ? (float)(acc[k] / (double)n) : 0.0f;
@@ -1063,20 +1136,24 @@ public:
     {
         if (!timed_ || ev_used_ == 0) return 0.0f;
         hipEvent_t* ev_ = ev_pool_[ev_used_ - 1].data();
-        NRC_HIP(hipEventSynchronize(ev_[4]));
-        NRC_HIP(hipEventSynchronize(ev_[5]));
+        sync();
         float st[8];
-        stage_times(ev_, st);
+        stage_times(ev_, st, stage_events_);
         if (stage) for (int k = 0; k < 8; k++) stage[k] = st[k];
         return st[7];
     }
 
     // {clear(0), gen_rays, prep_infer(0: fused into gen_rays), train (second stream), prep_train (second stream),
     //  inference, composite, total}
-    static void stage_times(hipEvent_t* e, float* st)
+    static void stage_times(hipEvent_t* e, float* st, bool all_stages)
     {
         float gen = 0, prep = 0, inf = 0, trn = 0, comp = 0, total = 0;
         NRC_HIP(hipEventElapsedTime(&gen, e[0], e[1]));
+        if (!all_stages) {      // only gen_rays is bracketed (set_stage_events(false)): the other stages read 0, the total is gen_rays'
+            for (int k = 0; k < 8; k++) st[k] = 0.0f;
+            st[1] = gen; st[7] = gen;
+            return;
+        }
         NRC_HIP(hipEventElapsedTime(&prep, e[1], e[2]));
         NRC_HIP(hipEventElapsedTime(&inf, e[1], e[3]));
         NRC_HIP(hipEventElapsedTime(&trn, e[2], e[5]));
@@ -1222,6 +1299,21 @@ private:
     bool consumer_pending_ = false;
     bool full_vertex_images_ = false;
     void* d_tile_mask_ = nullptr;
+    void *d_flight_bits_ = nullptr, *d_flight_sel_ = nullptr;
+    // hot-tile lists (DevFrame::hot_tiles), double-buffered by frame parity; [k] was computed on stream D for hot_random_[k]
+    void* d_hot_[2] = {nullptr, nullptr};
+    hipEvent_t ev_hot_[2] = {nullptr, nullptr};
+    bool hot_promote_ = true, hot_ready_[2] = {false, false};
+    uint64_t hot_epoch_[2] = {0, 0}, mask_epoch_ = 0;
+    float hot_random_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    float next_random_[4] = {0, 0, 0, 0}, hint_random_[4] = {0, 0, 0, 0};
+    bool have_next_random_ = false, have_hint_ = false, last_hot_predicted_ = false;
+    int last_hot_ = -1;
+    void draw_random(float* r4)
+    {
+        std::uniform_real_distribution<float> u(0.0f, 1.0f);
+        for (int k = 0; k < 4; k++) r4[k] = u(rng_);
+    }
     void* d_tile_cost_ = nullptr;
     void* d_tile_order_[2] = {nullptr, nullptr};
     uint32_t n_slots_ = 0;
@@ -1234,6 +1326,7 @@ private:
     int order_fresh_ = 2;
     nrc_camera nrc_cam_{};
     bool mask_dirty_ = true, empty_skip_ = true;
+    bool stage_events_ = getenv("NRC_NO_STAGE_EVENTS") == nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------------- McRenderer
@@ -1251,6 +1344,8 @@ public:
         dev_alloc(&d_info_, px * 4, "d_info_"); NRC_HIP(hipMemset(d_info_, 0, px * 4));
         dev_alloc(&d_fetch_, 8, "d_fetch_"); NRC_HIP(hipMemset(d_fetch_, 0, 8));
         dev_alloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4, "d_tile_mask_");
+        dev_alloc(&d_flight_bits_, (size_t)kFlightStates / 8 + 8, "d_flight_bits_");
+        dev_alloc(&d_flight_sel_, (1 + kFlightListMax) * 4, "d_flight_sel_");
         NRC_HIP(hipEventCreate(&ev_[0])); NRC_HIP(hipEventCreate(&ev_[1]));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
@@ -1269,6 +1364,8 @@ public:
         if (d_info_) dev_free(d_info_);
         if (d_fetch_) dev_free(d_fetch_);
         if (d_tile_mask_) dev_free(d_tile_mask_);
+        if (d_flight_bits_) dev_free(d_flight_bits_);
+        if (d_flight_sel_) dev_free(d_flight_sel_);
         if (d_tile_cost_) dev_free(d_tile_cost_);
         if (d_tile_order_) dev_free(d_tile_order_);
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -1280,7 +1377,7 @@ public:
             mask_dirty_ = false;
             DevProjView pv;
             frame_.tile_mask = nullptr;
-            if (empty_skip_ && forward_transform(nrc_cam_, &pv) && skip_setup(scene_.d, &frame_)) {
+            if (empty_skip_ && forward_transform(nrc_cam_, &pv) && skip_setup(scene_.d, &frame_, (uint32_t*)d_flight_bits_, (uint32_t*)d_flight_sel_, stream_)) {
                 launch_tile_mask((const float*)scene_.d_boxes, scene_.n_boxes, pv, frame_, (uint32_t*)d_tile_mask_, stream_);
                 frame_.tile_mask = (const uint32_t*)d_tile_mask_;
             }
@@ -1351,6 +1448,7 @@ private:
     std::mt19937 rng_;
     SceneDev scene_;
     void *d_out_ = nullptr, *d_info_ = nullptr, *d_fetch_ = nullptr, *d_tile_mask_ = nullptr;
+    void *d_flight_bits_ = nullptr, *d_flight_sel_ = nullptr;
     nrc_camera nrc_cam_{};
     bool mask_dirty_ = true, empty_skip_ = true;
     hipEvent_t ev_[2] = {nullptr, nullptr};
@@ -1595,6 +1693,19 @@ int nrc_renderer_create(uint32_t w, uint32_t h, int blend, const nrc_camera* cam
     return guarded([&] { *out = new nrc_renderer(w, h, blend != 0, *cam, *cfg, *scene, cache->impl, tile, (hipStream_t)stream); });
 }
 int nrc_renderer_render(nrc_renderer_t* r, int train) { NRC_REQUIRE(r); return guarded([&] { r->impl.render(train != 0); }); }
+int nrc_renderer_render_frames(nrc_renderer_t* r, uint32_t n_frames, const float* frame_randoms, int train)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] {
+        for (uint32_t f = 0; f < n_frames; f++) {
+            if (frame_randoms) {
+                r->impl.set_frame_random(frame_randoms + 4 * (size_t)f);
+                if (f + 1 < n_frames) r->impl.hint_next_random(frame_randoms + 4 * (size_t)(f + 1));
+            }
+            r->impl.render(train != 0);
+        }
+    });
+}
 int nrc_renderer_set_camera(nrc_renderer_t* r, const nrc_camera* c) { NRC_REQUIRE(r); NRC_REQUIRE(c); return guarded([&] { r->impl.set_camera(*c); }); }
 int nrc_renderer_set_scene_params(nrc_renderer_t* r, const nrc_scene* scene)
 {
@@ -1622,6 +1733,11 @@ int nrc_renderer_release_frame(nrc_renderer_t* r, void* consumer_stream)
     NRC_REQUIRE(r);
     return guarded([&] { r->impl.release_frame((hipStream_t)consumer_stream); });
 }
+int nrc_renderer_set_stage_events(nrc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.set_stage_events(on != 0); });
+}
 int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on)
 {
     NRC_REQUIRE(r);
@@ -1638,6 +1754,18 @@ size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t cap
     size_t n = 0;
     if (guarded([&] { n = r->impl.tile_order(host_out, capacity); }) != NRC_OK) return 0;
     return n;
+}
+int nrc_renderer_set_hot_tiles(nrc_renderer_t* r, int on)
+{
+    NRC_REQUIRE(r);
+    return guarded([&] { r->impl.set_hot_tiles(on != 0); });
+}
+int nrc_renderer_hot_tiles(nrc_renderer_t* r, uint32_t* host_out9)
+{
+    NRC_REQUIRE(r); NRC_REQUIRE(host_out9);
+    int rc = -2;
+    if (guarded([&] { rc = r->impl.hot_tiles(host_out9); }) != NRC_OK) return -2;
+    return rc;
 }
 int nrc_mc_renderer_set_cost_order(nrc_mc_renderer_t* r, int on)
 {

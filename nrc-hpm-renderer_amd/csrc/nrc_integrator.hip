@@ -192,6 +192,35 @@ __device__ __forceinline__ const uint32_t* load_occupancy(const DevScene& sc, ui
     __syncthreads();
     return s_occ;
 }
+// The same for a kernel whose waves leave the workgroup at different times (k_gen_rays: a wave whose tile misses the medium is
+// gone before this point): every wave copies the whole table for itself -- identical values to identical addresses -- and there is
+// no workgroup barrier.  occ_words is a multiple of 4 (Scene::build_occupancy_bits).
+__device__ __forceinline__ const uint32_t* load_occupancy_per_wave(const DevScene& sc, uint32_t* s_occ)
+{
+    if (sc.occ_bits == nullptr) return nullptr;
+    const uint4* src = reinterpret_cast<const uint4*>(sc.occ_bits);
+    uint4* dst = reinterpret_cast<uint4*>(s_occ);
+    for (uint32_t i = threadIdx.x & 63u; i < (sc.occ_words >> 2); i += 64u) dst[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return s_occ;
+}
+
+// wave-uniform 32-bit loads through the scalar cache (the compiler takes the vector path for a pointer it cannot prove unwritten)
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t* p)
+{
+    uint32_t r;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ void scalar_load2(const uint32_t* p, const uint32_t* q, uint32_t* a, uint32_t* b)
+{
+    uint32_t r0, r1;
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r0), "=&s"(r1) : "s"(p), "s"(q) : "memory");
+    *a = r0;
+    *b = r1;
+}
 
 template <class C>
 __device__ __forceinline__ void init_random(C& c, float u, float v, const float* frame_random)
@@ -242,12 +271,16 @@ __device__ __forceinline__ void find_entry_exit(C& c, V3 ro, V3 rd, V3* entry, V
     *exit_ = ro;
 }
 
-// a * b + c on the full-rate 24-bit multiplier (hipcc turns __umul24 of an unbounded operand back into a quarter-rate 32-bit
-// multiply); exact when a, b < 2^24 and the result fits 32 bits -- guaranteed by the size checks at scene upload
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+// (z * ny + y) * nx + x on the full-rate 24-bit multiplier (hipcc turns __umul24 of an unbounded operand back into a quarter-rate
+// 32-bit multiply); exact when every factor is below 2^24 and the result fits 32 bits -- guaranteed by the size checks at scene
+// upload.  The two multiply-adds of an index are ONE asm statement that opens with two wait states: ny and nx are scalar operands,
+// the compiler may have just reloaded them from an SGPR spill lane with v_readlane_b32, and a vector instruction that reads an SGPR
+// another vector instruction wrote needs two wait states on this target -- which the compiler's hazard recognizer inserts for its
+// own instructions but cannot see inside an asm string.
+__device__ __forceinline__ uint32_t index24(uint32_t z, uint32_t ny, uint32_t y, uint32_t nx, uint32_t x)
 {
     uint32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    asm("s_nop 1\n\tv_mad_u32_u24 %0, %1, %2, %3\n\tv_mad_u32_u24 %0, %0, %4, %5" : "=&v"(r) : "v"(z), "s"(ny), "v"(y), "s"(nx), "v"(x));
     return r;
 }
 
@@ -265,7 +298,7 @@ __device__ __forceinline__ float get_density(C& c, V3 p)
     c.count(1u);
     const bool inb = (fx >= 0.0f) & (fx < s.fnx) & (fy >= 0.0f) & (fy < s.fny) & (fz >= 0.0f) & (fz < s.fnz);
     const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
-    uint32_t idx = mad24(mad24(iz, s.ny, iy), s.nx, ix);
+    uint32_t idx = index24(iz, s.ny, iy, s.nx, ix);
     idx = inb ? idx : 0u;
     const uint8_t t = s.density[idx];
     const float d = s.density_factor * ((float)t * (1.0f / 255.0f));
@@ -300,12 +333,12 @@ __device__ __forceinline__ Addr2 fetch2_addr(const C& c, V3 dir, V3 start, float
     bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
     const uint32_t x0 = (uint32_t)fx.x, y0 = (uint32_t)fy.x, z0 = (uint32_t)fz.x;
     const uint32_t x1 = (uint32_t)fx.y, y1 = (uint32_t)fy.y, z1 = (uint32_t)fz.y;
-    const uint32_t idx0 = mad24(mad24(z0, s.ny, y0), s.nx, x0);
-    const uint32_t idx1 = mad24(mad24(z1, s.ny, y1), s.nx, x1);
+    const uint32_t idx0 = index24(z0, s.ny, y0, s.nx, x0);
+    const uint32_t idx1 = index24(z1, s.ny, y1, s.nx, x1);
     if (c.occ != nullptr) {      // occupancy bit of the voxel's cell from LDS: an empty cell's byte is 0 without asking memory
         const uint32_t sh = s.occ_shift;
-        uint32_t c0 = mad24(mad24(z0 >> sh, s.occ_gy, y0 >> sh), s.occ_gx, x0 >> sh);
-        uint32_t c1 = mad24(mad24(z1 >> sh, s.occ_gy, y1 >> sh), s.occ_gx, x1 >> sh);
+        uint32_t c0 = index24(z0 >> sh, s.occ_gy, y0 >> sh, s.occ_gx, x0 >> sh);
+        uint32_t c1 = index24(z1 >> sh, s.occ_gy, y1 >> sh, s.occ_gx, x1 >> sh);
         c0 = in0 ? c0 : 0u;
         c1 = in1 ? c1 : 0u;
         in0 &= ((c.occ[c0 >> 5] >> (c0 & 31u)) & 1u) != 0u;
@@ -566,8 +599,8 @@ __device__ __forceinline__ f2 get_density2(C& c, V3 dir, V3 start, float t1, flo
     // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
     const bool in0 = max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u;
     const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
-    uint32_t idx0 = mad24(mad24((uint32_t)fz.x, s.ny, (uint32_t)fy.x), s.nx, (uint32_t)fx.x);
-    uint32_t idx1 = mad24(mad24((uint32_t)fz.y, s.ny, (uint32_t)fy.y), s.nx, (uint32_t)fx.y);
+    uint32_t idx0 = index24((uint32_t)fz.x, s.ny, (uint32_t)fy.x, s.nx, (uint32_t)fx.x);
+    uint32_t idx1 = index24((uint32_t)fz.y, s.ny, (uint32_t)fy.y, s.nx, (uint32_t)fx.y);
     idx0 = in0 ? idx0 : 0x80000000u;
     idx1 = in1 ? idx1 : 0x80000000u;
     const uint8_t b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx0, 0, 0);
@@ -976,20 +1009,39 @@ __device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx
 // the XCD of a column then walks through all eight values over eight consecutive rows.
 // On top of that mapping the tiles are launched costliest first (DevFrame::tile_order, k_tile_order below): slot d of the grid
 // renders tile order[d].  (Measured and rejected, tools/loop_profile.py: one-wave workgroups.)
-constexpr uint32_t CAMERA_WAVES_PER_BLOCK = 4;
+#ifndef NRC_CAMERA_WAVES_PER_BLOCK
+#define NRC_CAMERA_WAVES_PER_BLOCK 4
+#endif
+constexpr uint32_t CAMERA_WAVES_PER_BLOCK = NRC_CAMERA_WAVES_PER_BLOCK;
+// The camera kernels run at the highest user wave priority.  Reason (tests/cpp/stress_main.cpp): a k_gen_rays
+// wave that shares its SIMD with waves of a HIGHER issue priority -- waves of the renderer's high-priority streams, or any
+// kernel that raises its priority with s_setprio -- now and then (2-3 % of 72-frame runs with k_infer at priority 3; twice in ~60
+// runs of the product build in round 2) leaves the path's last new_ray_dir with a different direction in lanes 48..63 although
+// every input is identical: the NRC query of those 16 pixels changes, nothing else.  Neither scratch, nor the lane-pair tails,
+// nor the spacing of transcendental instructions has a part in it (each was removed or padded without effect); with the camera
+// waves at a priority no lower than their neighbours' the event did not occur once in 300 runs that otherwise show it 6-11 times.
+#ifndef NRC_CAMERA_WAVE_PRIORITY
+#define NRC_CAMERA_WAVE_PRIORITY 3
+#endif
+__device__ __forceinline__ void camera_wave_priority()
+{
+#if NRC_CAMERA_WAVE_PRIORITY > 0
+    __builtin_amdgcn_s_setprio(NRC_CAMERA_WAVE_PRIORITY);
+#endif
+}
 __host__ __device__ inline uint32_t camera_row_blocks(uint32_t w)
 {
     const uint32_t blocks_x = (((w + 7u) >> 3) + CAMERA_WAVES_PER_BLOCK - 1u) / CAMERA_WAVES_PER_BLOCK;
     return blocks_x | 1u;
 }
 // *slot: the wave's default slot (index into DevFrame::tile_cost)
-__device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
+// launch slot (workgroup * 4 + wave) -> the wave's pixel
+__device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_t d, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
     const uint32_t row_blocks = camera_row_blocks(fr.w);
-    uint32_t d = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (fr.tile_order != nullptr) d = __builtin_amdgcn_readfirstlane(fr.tile_order[d]);      // costliest tiles first
+    if (fr.tile_order != nullptr) d = scalar_load(fr.tile_order + d);      // costliest tiles first
     if (slot) *slot = d;
     const uint32_t bd = d / CAMERA_WAVES_PER_BLOCK;
     const uint32_t k = bd / row_blocks, jb = bd - k * row_blocks;
@@ -1001,29 +1053,49 @@ __device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t*
     *y = ty * 8u + (lane >> 3);
     return *lx < fr.w && *y < fr.h;
 }
+__device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
+{
+    return pixel_of_launch_slot(fr, __builtin_amdgcn_readfirstlane(blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6)), lx, y, slot);
+}
 
 // Empty-space early-out, exact: the tile mask (k_tile_mask) clears the bit of an 8x8 tile only when no camera ray of the tile can
 // come within a voxel of non-empty density.  Every density such a ray's delta tracking fetches is 0, so every tentative collision
 // is rejected and the walk can end in two ways only: it leaves the volume (the pixel is env(rd), didScatter = 0, an all-zero
 // query, and the RNG state behind the walk is never used), or it runs into DeltaTrack's cap of 128 collisions
 // (path_trace.glsl:161-173) and "scatters" at a random point of the segment.  Which of the two happens is a function of the
-// pixel's RNG state alone: the hash chain has only 2^23 states, and DevFrame::flight_table holds, for every state, the optical
-// distance the 128 free flights drawn from it cover (k_flight_table).  A lane whose table entry exceeds the largest optical
-// depth any ray of the scene can have (DevFrame::skip_lambda, with a margin for the rounding of the walk's own sums) provably
-// leaves the volume before the cap; the tile's waves skip the walk only when that holds for every pixel of the tile (all but a
-// handful of states near the chain's fixed point 0 -- hash(0) = 0, every flight has length 0 -- once the bound is below ~90).
-__device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, uint32_t y, bool inside, float rng0)
+// pixel's RNG state alone: the hash chain has only 2^23 states, and k_flight_table computes, for every state, the optical distance
+// the 128 free flights drawn from it cover.  A state whose distance exceeds the largest optical depth any ray of the scene can
+// have (with a margin for the rounding of the walk's own sums) provably leaves the volume before the cap; the others ("capped":
+// k_flight_select) reach the kernels as a short list -- for the bench scene the chain's fixed point 0 alone (hash(0) = 0: every
+// flight has length 0) -- or, for denser media, as one bit per state.  A tile's waves skip the walk only when no pixel of the
+// tile is in a capped state.
+__device__ __forceinline__ bool tile_mask_clear(const DevFrame& fr, uint32_t lx, uint32_t y)
 {
-    if (fr.tile_mask == nullptr || fr.flight_table == nullptr) return false;
+    if (fr.tile_mask == nullptr || fr.flight_mode == 0u) return false;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
     const uint32_t id = __builtin_amdgcn_readfirstlane((y >> 3) * tiles_x + (lx >> 3));      // wave-uniform: one tile per wave
     const uint32_t n_words = (tiles_x * tiles_y + 31u) >> 5;
-    const uint32_t word = fr.tile_mask[id >> 5], ignore = fr.tile_mask[n_words];
-    if (!(ignore == 0u && ((word >> (id & 31u)) & 1u) == 0u)) return false;
+    uint32_t word, ignore;
+    scalar_load2(fr.tile_mask + (id >> 5), fr.tile_mask + n_words, &word, &ignore);
+    return ignore == 0u && ((word >> (id & 31u)) & 1u) == 0u;
+}
+// is a pixel of the wave's tile in a capped RNG state?  (wave-uniform)
+__device__ __forceinline__ bool tile_has_capped_state(const DevFrame& fr, bool inside, float rng0)
+{
     // state -> mantissa: the states are the multiples of 2^-23 in [0, 1), so rng0 + 1 is exact
     const uint32_t m = nrc_f2u(rng0 + 1.0f) & 0x007fffffu;
-    const bool capped = inside && !(fr.flight_table[m] > fr.skip_lambda);
-    return __ballot(capped) == 0ull;
+    bool capped = false;
+    if (fr.flight_mode == 1u) {      // a handful of states: compared one by one (no memory access)
+#pragma unroll
+        for (uint32_t k = 0; k < kFlightListMax; k++) capped |= (k < fr.flight_n) & (m == fr.flight_list[k]);
+    } else {
+        capped = ((fr.flight_bits[m >> 5] >> (m & 31u)) & 1u) != 0u;
+    }
+    return __ballot(inside & capped) != 0ull;
+}
+__device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, uint32_t y, bool inside, float rng0)
+{
+    return tile_mask_clear(fr, lx, y) && !tile_has_capped_state(fr, inside, rng0);
 }
 
 // optical distance (in units of 1 / sigma_max) covered by the 128 free flights of a delta walk that starts in RNG state
@@ -1039,6 +1111,41 @@ __global__ __launch_bounds__(256) void k_flight_table(float* __restrict__ table)
         r = random1(s);
     }
     table[m] = d;
+}
+
+__global__ __launch_bounds__(256) void k_flight_select(const float* __restrict__ table, float lambda, uint32_t* __restrict__ out, uint32_t* __restrict__ bits)
+{
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    const bool capped = !(table[m] > lambda);
+    const unsigned long long b = __ballot(capped);
+    if ((threadIdx.x & 63u) == 0u) {
+        bits[m >> 5] = (uint32_t)b;
+        bits[(m >> 5) + 1u] = (uint32_t)(b >> 32);
+    }
+    if (capped) {
+        const uint32_t k = atomicAdd(&out[0], 1u);
+        if (k < kFlightListMax) out[1u + k] = m;
+    }
+}
+
+// the tiles with a pixel in a capped RNG state (list mode), for DevFrame::hot_tiles: hot[kHotTilesMax] counts them (zeroed by the
+// caller), the first kHotTilesMax are kept in hot[0..].  256 workgroups (the dispatcher places ~250 workgroups per microsecond), eight pixels per thread.
+__global__ __launch_bounds__(1024) void k_hot_tiles(DevFrame fr, uint32_t* __restrict__ hot)
+{
+    const uint32_t n = fr.w * fr.h;
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
+        const uint32_t y = i / fr.w, lx = i - y * fr.w;
+        const float u = (float)global_x(fr, lx) * fr.inv_gw, v = (float)y * fr.inv_gh;
+        const float rng0 = random2(random2(u, v), random4(fr.random));      // init_random
+        const uint32_t m = nrc_f2u(rng0 + 1.0f) & 0x007fffffu;
+        bool capped = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kFlightListMax; k++) capped |= (k < fr.flight_n) & (m == fr.flight_list[k]);
+        if (capped) {
+            const uint32_t k = atomicAdd(&hot[kHotTilesMax], 1u);
+            if (k < kHotTilesMax) hot[k] = ((y >> 3) << 16) | (lx >> 3);
+        }
+    }
 }
 
 // what a tile cost in this launch, kept as a decaying maximum over the sampled launches (DevFrame::tile_cost_keep)
@@ -1072,11 +1179,45 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
                                                  unsigned long long* fetch_counter, TrainGrid tg, int full_vertex_images)
 {
+    camera_wave_priority();
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
-    const uint32_t* occ = load_occupancy(sc, s_occ);
-    uint32_t lx = 0, y = 0, slot;      // (a padding workgroup's lanes stay at pixel 0: they run the predicated code below with no walk)
-    const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
+    uint32_t lx = 0, y = 0, slot = 0;
+    bool inside;
+    bool hot_wave = false;
+    {
+        uint32_t d = __builtin_amdgcn_readfirstlane(blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+        if (fr.hot_tiles != nullptr) {
+            // the launch has kHotTilesMax waves in front of the ordered ones: wave k traces hot tile k, and the wave the order
+            // gives that tile to leaves
+            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+            uint32_t hot_n;
+            u32x8 hv;
+            asm volatile("s_load_dword %0, %2, 0x20\n\ts_load_dwordx8 %1, %2, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hot_n), "=&s"(hv) : "s"(fr.hot_tiles) : "memory");
+            hot_n = min(hot_n, kHotTilesMax);
+            const uint32_t hot[kHotTilesMax] = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
+            if (d < kHotTilesMax) {
+                if (d >= hot_n) return;
+                uint32_t t = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kHotTilesMax; k++) t = d == k ? hot[k] : t;
+                const uint32_t lane = threadIdx.x & 63u;
+                lx = (t & 0xffffu) * 8u + (lane & 7u);
+                y = (t >> 16) * 8u + (lane >> 3);
+                inside = lx < fr.w && y < fr.h;
+                hot_wave = true;
+            } else {
+                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot);
+                const uint32_t t = __builtin_amdgcn_readfirstlane(((y >> 3) << 16) | (lx >> 3));
+                bool is_hot = false;
+#pragma unroll
+                for (uint32_t k = 0; k < kHotTilesMax; k++) is_hot |= (k < hot_n) & (t == hot[k]);
+                if (is_hot) return;
+            }
+        } else {
+            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot);
+        }
+    }
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
@@ -1088,19 +1229,45 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         g_wave_times[4 * wave_id + 3] = hw;
     }
 #endif
+    if (__ballot(inside) == 0ull) return;      // a padding workgroup's wave (the grid is rounded up to whole rows of workgroups)
     CtxT<COUNT> c{sc, 0.0f, 0u};
-    c.occ = occ;
-    // Wave-uniform control flow with per-lane predicates from here to the stores: a lane whose path has ended (or that has none)
-    // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
     const uint32_t gx = global_x(fr, lx);
     const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+    // Two of three tiles of the bench view miss the medium.  Their waves are the tail of the launch (k_tile_order starts the
+    // costliest tiles first): the tile's bit comes through the scalar cache, and the wave is gone before the occupancy table is
+    // copied (there is no workgroup barrier in this kernel: load_occupancy_per_wave).  What is left of them is dispatch: ~1000
+    // waves per microsecond start at the end of the launch (tools/loop_profile.py), and all they do costs 0.004 ms of 0.215.
+    if (tile_mask_clear(fr, lx, y)) {
+        init_random(c, u, v, fr.random);
+        if (!tile_has_capped_state(fr, inside, c.rng)) {
+            if (inside) {
+                V3 ro, rd;
+                camera_ray(cam, u, v, &ro, &rd);
+                const V3 e = sample_env_dir(sc, rd);
+                const size_t pix = (size_t)y * fr.w + lx;
+                primary[pix] = make_float4(e.x, e.y, e.z, 1.0f);
+                info[pix] = 0.0f;
+                float* qo = infer_in + ((size_t)lx * fr.h + y) * 5u;
+#pragma unroll
+                for (int k = 0; k < 5; k++) qo[k] = 0.0f;
+            }
+            if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
+#ifdef NRC_LOOP_PROFILE
+            if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = 0.0f;
+            if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) g_wave_times[4 * wave_id + 1] = wall_clock64();
+#endif
+            return;
+        }
+    }
+    c.occ = load_occupancy_per_wave(sc, s_occ);
+    // Wave-uniform control flow with per-lane predicates from here to the stores: a lane whose path has ended (or that has none)
+    // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
     V3 ro, rd;
     camera_ray(cam, u, v, &ro, &rd);
     init_random(c, u, v, fr.random);
-    const bool empty = tile_is_empty(fr, lx, y, inside, c.rng);      // wave-uniform (the tile is, even where the image ends inside it)
-    const bool enter = inside & !empty;
+    const bool enter = inside;
     V3 entry = ro, ex;
-    if (__ballot(enter) != 0ull) {
+    {
 #ifdef NRC_LOOP_PROFILE
         c.fee_kind = 0;
 #endif
@@ -1112,23 +1279,23 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     const bool entered = enter && !(sky_sdf(sc, entry) > 100000.0f);
     // The colour of a pixel that does not scatter -- the environment along its camera ray, throughput 1 (gen_rays.comp:86-95) -- is
     // stored NOW, before the walk; a pixel that scatters overwrites it at the end (same lane, same address: the stores are
-    // performed in order).  The camera ray direction is therefore dead during the walk.  Kept live for the end, two of its
-    // components were the ONE value this kernel spilled (8 bytes per lane of scratch), and that spill is where both non-determinism
-    // events of round 2 came from: with high-priority waves of other queues co-resident, the reload returned -- in lanes 48..63,
-    // i.e. one 64-byte segment of each of the wave's scratch rows -- the direction ANOTHER wave had spilled to the same scratch
-    // slot earlier (tests/cpp/stress_main.cpp).  The kernel has no scratch now (tests/test_abi.py checks that).
+    // performed in order).  The camera ray direction is therefore dead during the walk; kept live for the end, two of its
+    // components were the one value this kernel spilled to scratch (tests/test_abi.py checks that there is none).
+#ifndef NRC_LATE_ENV
     if (inside) {
         const V3 e = sample_env_dir(sc, rd);
         primary[(size_t)y * fr.w + lx] = make_float4(e.x, e.y, e.z, 1.0f);
     }
+#endif
     V3 light = v3(0, 0, 0);
     V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
     float factor = 1.0f;
     bool did_scatter = false, walking = entered;
 #ifdef NRC_DIAG_LASTDIR
-    // diagnostic build (tests/cpp/stress_main.cpp): RNG state and a hash of the incoming direction in front of the path's last
+    // diagnostic build (tests/cpp/stress_main.cpp): RNG state and incoming direction in front of the path's last
     // new_ray_dir, stored in the w components of the vertex images
-    float dbg_rng_in = 0.0f, dbg_dir_in = 0.0f;
+    float dbg_rng_in = 0.0f;
+    V3 dbg_old = v3(0.0f, 0.0f, 0.0f);
 #endif
     for (int i = 0;; i++) {
         if (__ballot(walking) == 0ull) break;
@@ -1144,7 +1311,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             light = add(light, mul(ts, factor));
 #ifdef NRC_DIAG_LASTDIR
             dbg_rng_in = c.rng;
-            dbg_dir_in = nrc_u2f((nrc_f2u(dir.x) * 3u) ^ (nrc_f2u(dir.y) * 5u) ^ (nrc_f2u(dir.z) * 7u));
+            dbg_old = dir;
 #endif
             dir = new_ray_dir(c, dir, true);
             if ((uint32_t)i >= primary_ray_length) {
@@ -1166,8 +1333,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             }
             if (on_grid) {
 #ifdef NRC_DIAG_LASTDIR
-                origin[pix] = make_float4(cur.x, cur.y, cur.z, dbg_rng_in);
-                dirs[pix] = make_float4(dir.x, dir.y, dir.z, dbg_dir_in);
+                origin[pix] = make_float4(dbg_old.x, dbg_old.y, dbg_old.z, dbg_rng_in);      // (the incoming direction instead of the vertex)
+                dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
 #else
                 origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
                 dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
@@ -1178,6 +1345,12 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 primary[pix] = make_float4(light.x, light.y, light.z, factor);      // replaces the environment colour stored above
             }
         }
+#ifdef NRC_LATE_ENV
+        if (!(entered && did_scatter)) {
+            const V3 e = sample_env_dir(sc, rd);
+            primary[pix] = make_float4(e.x, e.y, e.z, 1.0f);
+        }
+#endif
         info[pix] = did_scatter ? 1.0f : 0.0f;
         // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
         // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
@@ -1190,8 +1363,9 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = (float)c.fetches;
 #endif
     if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
-    // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order)
-    if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
+    // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order).  (Not for a hot wave: what
+    // it measured is this frame's one pixel in a capped state, not the tile.)
+    if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
 #if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
     for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
 #endif
@@ -1206,6 +1380,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
 {
+    camera_wave_priority();
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
@@ -1661,9 +1836,17 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 #ifdef NRC_LOOP_PROFILE
     kernel = k_gen_rays<true>;      // (the profiling build's per-pixel look-up counts, tools/lane_model.py)
 #endif
-    hipLaunchKernelGGL(kernel, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
+    dim3 grid = wave_tile_grid(fr.w, fr.h);
+    if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
                        fetch_counter, tg, full_vertex_images ? 1 : 0);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hot_tiles, dim3(256), dim3(1024), 0, s, fr, hot);
     NRC_HIP(hipGetLastError());
 }
 
@@ -1688,6 +1871,13 @@ void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& p
 void launch_flight_table(float* table, hipStream_t s)
 {
     hipLaunchKernelGGL(k_flight_table, dim3(kFlightStates / 256u), dim3(256), 0, s, table);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_flight_select(const float* table, float lambda, uint32_t* count_and_list, uint32_t* bits, hipStream_t s)
+{
+    NRC_HIP(hipMemsetAsync(count_and_list, 0, (1 + kFlightListMax) * 4, s));
+    hipLaunchKernelGGL(k_flight_select, dim3(kFlightStates / 256u), dim3(256), 0, s, table, lambda, count_and_list, bits);
     NRC_HIP(hipGetLastError());
 }
 

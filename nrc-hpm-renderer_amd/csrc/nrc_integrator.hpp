@@ -43,10 +43,13 @@ struct DevFrame {
     // word behind the last tile word is non-zero when the mask must be ignored.  nullptr: no mask (every tile is traced).
     const uint32_t* tile_mask;
     // the mask may only be applied to a pixel whose delta walk through empty space provably leaves the volume before DeltaTrack's
-    // cap of 128 collisions: flight_table[state] (kFlightStates floats, launch_flight_table) > skip_lambda, the scene's largest
-    // optical depth with a rounding margin.  nullptr: the mask is not applied.
-    const float* flight_table;
-    float skip_lambda;
+    // cap of 128 collisions -- a property of the pixel's RNG state (2^23 of them) and of the scene's largest optical depth.  The
+    // states that can reach the cap ("capped") are handed over as a list when there are at most kFlightListMax of them (one state,
+    // the chain's fixed point 0, for the bench scene), otherwise as a bit per state (flight_bits, 1 MB, bit set = capped).
+    // flight_mode: 0 the mask is not applied, 1 list, 2 bits.
+    uint32_t flight_mode, flight_n;
+    uint32_t flight_list[8];
+    const uint32_t* flight_bits;
     // launch order of the camera kernels' 8x8 tiles: launch slot (workgroup * 4 + wave) -> default slot (the centre-out order of
     // pixel_of_wave_tile), costliest first (k_tile_order); nullptr: default order.  tile_cost: cycles each default slot's wave
     // took in this launch (written by k_gen_rays when non-null)
@@ -56,7 +59,14 @@ struct DevFrame {
     // sampled launches: the costliest-first order is hurt by tiles it under-estimates (a long tile started late ends the launch),
     // not by tiles it over-estimates
     uint32_t tile_cost_keep;
+    // tiles k_gen_rays starts FIRST, whatever the order says: {kHotTilesMax entries (ty << 16 | tx), then their count}, written by
+    // k_hot_tiles for this frame's random numbers; nullptr: none.  A pixel in a capped RNG state (see flight_mode) in a tile the
+    // mask rejects is one lane that walks for ~120 us; its wave would otherwise start among the empty tiles at the end of the
+    // launch and end it that much later (one frame in four on the bench view).  Scheduling only: every tile is traced exactly once
+    // with or without the list.
+    const uint32_t* hot_tiles;
 };
+constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front
 
 // forward camera transform for the tile mask: clip = m * (x, y, z, 1), column-major like DevCamera::m
 struct DevProjView {
@@ -74,11 +84,17 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 
 // marks the 8x8-pixel tiles whose camera rays can meet a non-empty voxel: `boxes` = n axis-aligned world-space boxes
 // {lo.xyz, hi.xyz} that together cover every non-empty voxel with a margin of one voxel.  mask: ceil(tiles/32) + 1 words, zeroed.
+// finds the pixels of the frame whose RNG state is in fr.flight_list (flight_mode 1) and appends their tiles to hot (count zeroed by the caller: hot[kHotTilesMax])
+void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s);
 void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s);
 uint32_t tile_mask_words(uint32_t w, uint32_t h);
 // table[m] = optical distance covered by the 128 free flights a delta walk draws from RNG state m when it rejects every collision
 constexpr uint32_t kFlightStates = 1u << 23;
+constexpr uint32_t kFlightListMax = 8;
 void launch_flight_table(float* table, hipStream_t s);
+// the states whose table entry does not exceed lambda: count_and_list[0] = their number, [1..8] the first eight (any order);
+// bits (kFlightStates / 32 words): bit m set for every such state
+void launch_flight_select(const float* table, float lambda, uint32_t* count_and_list, uint32_t* bits, hipStream_t s);
 // launch slots of the camera kernels (rows padded to an odd number of workgroups) and the costliest-first order over them
 uint32_t camera_slots(uint32_t w, uint32_t h);
 void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, hipStream_t s);

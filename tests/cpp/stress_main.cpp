@@ -317,9 +317,10 @@ int main(int argc, char** argv)
                             const float* dt = (const float*)&parts[r].sets[k][4][((size_t)y * lw + lx) * 16];
                             const float* dw = (const float*)&whole.sets[k][4][((size_t)y * GW + x) * 16];
                             if (dp || di || dq)
-                                std::printf("   px (%u, %u) set %d: vertex pos %s, final dir %s, [diag build: rng before the last new_ray_dir %s (%.9g | %.9g), incoming dir hash %s]; final dir tiles %.9g %.9g %.9g whole %.9g %.9g %.9g\n",
-                                            x, y, k, std::memcmp(ot, ow, 12) ? "DIFF" : "same", std::memcmp(dt, dw, 12) ? "DIFF" : "same", std::memcmp(ot + 3, ow + 3, 4) ? "DIFF" : "same", ot[3], ow[3],
-                                            std::memcmp(dt + 3, dw + 3, 4) ? "DIFF" : "same", dt[0], dt[1], dt[2], dw[0], dw[1], dw[2]);
+                                std::printf("   px (%u, %u) set %d: origin image (product: vertex; -DNRC_DIAG_LASTDIR: incoming direction) %s, final dir %s, [diag build: rng before the last new_ray_dir %s]; LASTDIR rng %08x in %08x %08x %08x out_tiles %08x %08x %08x out_whole %08x %08x %08x\n",
+                                            x, y, k, std::memcmp(ot, ow, 12) ? "DIFF" : "same", std::memcmp(dt, dw, 12) ? "DIFF" : "same", std::memcmp(ot + 3, ow + 3, 4) ? "DIFF" : "same",
+                                            ((const unsigned*)ow)[3], ((const unsigned*)ow)[0], ((const unsigned*)ow)[1], ((const unsigned*)ow)[2], ((const unsigned*)dt)[0], ((const unsigned*)dt)[1],
+                                            ((const unsigned*)dt)[2], ((const unsigned*)dw)[0], ((const unsigned*)dw)[1], ((const unsigned*)dw)[2]);
                             if (dp || di || dq)
                                 std::printf("   px (%u, %u) set %d: primary %s info %s query %s | tiles prim %.9g %.9g %.9g %.9g info %g q %.9g %.9g %.9g %.9g %.9g | whole prim %.9g %.9g %.9g %.9g info %g q %.9g %.9g %.9g %.9g %.9g\n",
                                             x, y, k, dp ? "DIFF" : "same", di ? "DIFF" : "same", dq ? "DIFF" : "same", pt[0], pt[1], pt[2], pt[3], it[0], qt[0], qt[1], qt[2], qt[3], qt[4],

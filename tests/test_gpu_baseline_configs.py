@@ -161,21 +161,8 @@ def test_c4_eight_tiles_equal_the_whole_4k_frame_at_8spp(api, sc, torch_gpu):
         parts.append(img)
     got = parallel.gather_columns(parts, GW)
     assert np.isfinite(whole).all() and (whole[..., 3] == 1.0).all()
-    bad = (got.view(np.uint32) != whole.view(np.uint32)).any(-1)
-    if bad.any():
-        # Seen twice in ~60 runs, both times in the first GPU process of a fresh box: 3 pixels of the first tile off by 1e-4
-        # relative (fp16-noise size, in the NRC term), not reproducible by rendering again.  Cause not found.
-        # Say which side moved, and hold the line at: nothing but such noise, and a second rendering of both sides agrees.
-        import warnings
-        ys, xs = np.nonzero(bad)
-        whole2, _ = frames(GW, None)
-        parts2 = [frames(parallel.local_width(r, WORLD, GW), parallel.column_tile(r, WORLD, GW, GH))[0] for r in range(WORLD)]
-        got2 = parallel.gather_columns(parts2, GW)
-        msg = ("%d pixels differed between the tiles and the whole frame (rows %d..%d, columns %d..%d, tiles %s); first: tiles %s whole %s; "
-               "second whole == first whole: %s, second tiles == first tiles: %s"
-               % (bad.sum(), ys.min(), ys.max(), xs.min(), xs.max(), sorted(set(int(x) for x in xs % 8)), got[ys[0], xs[0]], whole[ys[0], xs[0]],
-                  np.array_equal(whole2, whole), np.array_equal(got2, got)))
-        warnings.warn(msg)
-        assert bad.sum() <= 16 and np.abs(got - whole).max() <= 1e-3 * np.abs(whole).max(), msg
-        assert np.array_equal(got2.view(np.uint32), whole2.view(np.uint32)), msg
+    # bit for bit.  (Round 2 saw 3 pixels differ twice in ~60 runs and loosened this assertion; the cause is found -- a k_gen_rays wave
+    # sharing its SIMD with waves of a higher issue priority could leave new_ray_dir with a different direction in lanes 48..63 --
+    # and the camera kernels now run at a wave priority no lower than any neighbour's: DESIGN.md section 7, tests/test_gpu_stress.py.)
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
     assert whole[..., :3].std() > 0.01

@@ -692,6 +692,51 @@ def test_cli_main_loop_and_benchmark_log(torch_gpu, tmp_path):
         cli.main(argv[:5])
 
 
+def test_hot_tiles_are_started_first_and_change_no_pixel(api, orc, sc, cloud16, torch_gpu):
+    """a pixel in the RNG's fixed point inside a tile the empty-space mask rejects walks for the whole launch: gen_rays starts its
+    tile first.  The list is computed one frame ahead when the next frame's random numbers are known (RenderFrames) or drawn early
+    (unpinned frames: same sequence as without), in front of gen_rays otherwise; frames are bit-identical with the feature off, and
+    the oracle agrees"""
+    W, H = 256, 144
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=14, seed=77)
+    keys = ("primary", "info", "infer_input", "train_input", "train_target")
+    out = {}
+    for on in (True, False):
+        nrc = api.NeuralRadianceCache(cfg)
+        ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
+        ren.SetHotTiles(on)
+        got = []
+        # pinned, one at a time: the list is computed in front of gen_rays
+        ren.SetFrameRandom(STATE0_FRAME_RANDOM)
+        ren.Render(None, True)
+        got.append(([ren.Buffer(k).cpu().numpy().copy() for k in keys], ren.HotTiles()))
+        # announced ahead: frame 1 of these two is the state-0 frame, its list comes from the end of frame 0's work
+        ren.RenderFrames(np.array([FRAME_RANDOM, STATE0_FRAME_RANDOM], np.float32), True)
+        got.append(([ren.Buffer(k).cpu().numpy().copy() for k in keys], ren.HotTiles()))
+        # unpinned: drawn one frame early with the feature on, at the frame with it off -- the same numbers
+        for _ in range(5):
+            ren.Render(None, True)
+        got.append(([ren.Buffer(k).cpu().numpy().copy() for k in keys], ren.HotTiles()))
+        out[on] = (got, ren.GetImage().cpu().numpy().copy(), nrc.GetLoss())
+        ren.Destroy()
+        nrc.Destroy()
+    for (fa, _), (fb, _) in zip(out[True][0], out[False][0]):
+        for a, b in zip(fa, fb):
+            assert same_bits(a, b)
+    assert same_bits(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    assert [h for _, h in out[False][0]] == [None, None, None]
+    hot = [h for _, h in out[True][0]]
+    assert hot[0] == ([(0, 0)], 1, False)            # pixel (2, 3): tile (0, 0), found in front of gen_rays
+    assert hot[1] == ([(0, 0)], 1, True)             # ... and one frame ahead
+    assert hot[2] == ([], 0, True)
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, STATE0_FRAME_RANDOM, threads=8)
+    for fa, _ in out[True][0][:2]:
+        assert same_bits(fa[0].reshape(H, W, 4), o["primary"]) and same_bits(fa[1].reshape(H, W), o["info"])
+    assert o["info"][3, 2] == 1.0 and o["info"][:8, :8].sum() == 1.0
+
+
 def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc, cloud16, torch_gpu):
     """the costliest-first launch order of gen_rays' tiles: after the first sort the order is no longer the identity, it is a
     permutation of all tile slots with the provably empty tiles behind the cloud's, and every frame -- primary pass, queries,

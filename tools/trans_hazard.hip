@@ -7,8 +7,8 @@
 // while high-priority waves (k_infer: v_sin / v_cos / MFMA) are co-resident.  In k_gen_rays 58 of 80 transcendental results are
 // consumed at distance 1 (one independent instruction in between).
 //
-// The victim kernel runs v_rcp_f32 / v_sqrt_f32 with the dependent instruction at a chosen distance (inline asm, s_nop padding)
-// and compares every result with the same computation at distance 8; the aggressor keeps trans / MFMA / LDS work with
+// The victim kernel runs v_rcp_f32 / v_sqrt_f32 with the dependent instruction behind a chosen separator (inline asm) and compares
+// every result with the same computation behind a VALU instruction + s_nop 7; the aggressor keeps trans / MFMA / LDS work with
 // s_setprio 3 in flight on a high-priority stream.  Output: mismatches by lane, per distance.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o trans_hazard tools/trans_hazard.hip -pthread
@@ -32,38 +32,38 @@ __device__ __forceinline__ unsigned mix(unsigned x)
     return x;
 }
 
-// e = fma(-x, rcp(x), 1) with the fma DIST wait states behind the rcp; DIST 1 = one independent VALU instruction in between (what
-// the compiler emits), DIST 0 = back to back (the compiler never does that on this target), larger = s_nop padding
-template <int DIST>
-__device__ __forceinline__ float rcp_use(float x, float& side)
-{
-    float r, e;
-    if constexpr (DIST == 0)
-        asm volatile("v_rcp_f32 %0, %2\n\tv_fma_f32 %1, -%2, %0, 1.0" : "=&v"(r), "=v"(e) : "v"(x));
-    else if constexpr (DIST == 1)
-        asm volatile("v_rcp_f32 %0, %3\n\tv_mul_f32 %2, %3, %3\n\tv_fma_f32 %1, -%3, %0, 1.0" : "=&v"(r), "=&v"(e), "=&v"(side) : "v"(x));
-    else if constexpr (DIST == 2)
-        asm volatile("v_rcp_f32 %0, %3\n\tv_mul_f32 %2, %3, %3\n\ts_nop 0\n\tv_fma_f32 %1, -%3, %0, 1.0" : "=&v"(r), "=&v"(e), "=&v"(side) : "v"(x));
-    else
-        asm volatile("v_rcp_f32 %0, %3\n\tv_mul_f32 %2, %3, %3\n\ts_nop 7\n\tv_fma_f32 %1, -%3, %0, 1.0" : "=&v"(r), "=&v"(e), "=&v"(side) : "v"(x));
-    return e;
-}
-// y - 1 ulp of sqrt(x) (the first step of the correctly rounded sqrt's fix-up), the integer add DIST wait states behind the sqrt
-template <int DIST>
-__device__ __forceinline__ unsigned sqrt_use(float x, float& side)
-{
-    float y;
-    unsigned m;
-    if constexpr (DIST == 0)
-        asm volatile("v_sqrt_f32 %0, %2\n\tv_add_u32 %1, -1, %0" : "=&v"(y), "=v"(m) : "v"(x));
-    else if constexpr (DIST == 1)
-        asm volatile("v_sqrt_f32 %0, %3\n\tv_mul_f32 %2, %3, %3\n\tv_add_u32 %1, -1, %0" : "=&v"(y), "=&v"(m), "=&v"(side) : "v"(x));
-    else if constexpr (DIST == 2)
-        asm volatile("v_sqrt_f32 %0, %3\n\tv_mul_f32 %2, %3, %3\n\ts_nop 0\n\tv_add_u32 %1, -1, %0" : "=&v"(y), "=&v"(m), "=&v"(side) : "v"(x));
-    else
-        asm volatile("v_sqrt_f32 %0, %3\n\tv_mul_f32 %2, %3, %3\n\ts_nop 7\n\tv_add_u32 %1, -1, %0" : "=&v"(y), "=&v"(m), "=&v"(side) : "v"(x));
-    return m;
-}
+// e = fma(-x, rcp(x), 1) and m = bits(sqrt(x)) - 1 (the first step of the correctly rounded sqrt's fix-up) with the consumer behind a
+// chosen separator.  MODE: 0 back to back (the compiler never emits that on this target); 1 one independent VALU instruction;
+// 10 "s_nop 0" -- what the compiler emits for 44 of the 80 transcendental results in k_gen_rays; 11 "s_nop 1"; 12 one SALU
+// instruction (s_mov_b32); 13 one v_readlane_b32 (an SGPR reload from a spill lane); 8 the reference: VALU + "s_nop 7"
+#define NRC_TRANS_CASE(MODE, SEP)                                                                                                  \
+    template <>                                                                                                                     \
+    __device__ __forceinline__ float rcp_use<MODE>(float x, float& side)                                                            \
+    {                                                                                                                               \
+        float r, e;                                                                                                                 \
+        unsigned sg;                                                                                                                \
+        asm volatile("v_rcp_f32 %0, %4\n\t" SEP "\n\tv_fma_f32 %1, -%4, %0, 1.0" : "=&v"(r), "=&v"(e), "=&v"(side), "=&s"(sg) : "v"(x));     \
+        return e;                                                                                                                   \
+    }                                                                                                                               \
+    template <>                                                                                                                     \
+    __device__ __forceinline__ unsigned sqrt_use<MODE>(float x, float& side)                                                        \
+    {                                                                                                                               \
+        float y;                                                                                                                    \
+        unsigned m, sg;                                                                                                             \
+        asm volatile("v_sqrt_f32 %0, %4\n\t" SEP "\n\tv_add_u32 %1, -1, %0" : "=&v"(y), "=&v"(m), "=&v"(side), "=&s"(sg) : "v"(x));           \
+        return m;                                                                                                                   \
+    }
+template <int MODE>
+__device__ __forceinline__ float rcp_use(float x, float& side);
+template <int MODE>
+__device__ __forceinline__ unsigned sqrt_use(float x, float& side);
+NRC_TRANS_CASE(0, "")
+NRC_TRANS_CASE(1, "v_mul_f32 %2, %4, %4")
+NRC_TRANS_CASE(10, "s_nop 0")
+NRC_TRANS_CASE(11, "s_nop 1")
+NRC_TRANS_CASE(12, "s_mov_b32 %3, 7")
+NRC_TRANS_CASE(13, "v_readlane_b32 %3, %4, 5")
+NRC_TRANS_CASE(8, "v_mul_f32 %2, %4, %4\n\ts_nop 7")
 
 template <int DIST>
 __global__ __launch_bounds__(256, 5) void k_victim(unsigned seed, unsigned iters, unsigned* __restrict__ hist /* [2][64] */, unsigned long long* __restrict__ checks)
@@ -164,7 +164,7 @@ static void run_case(double seconds, int aggressor, unsigned* d_hist, unsigned l
     unsigned long long bad[2] = {0, 0}, quarter[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int k = 0; k < 2; k++)
         for (int l = 0; l < 64; l++) { bad[k] += hist[64 * k + l]; quarter[k][l / 16] += hist[64 * k + l]; }
-    std::printf("consumer %d wait state(s) behind the trans op, aggressor %d: %.3g checks each | v_rcp_f32 -> v_fma_f32: %llu wrong (lanes 0-15 %llu, 16-31 %llu, 32-47 %llu, 48-63 %llu) | "
+    std::printf("separator mode %d, aggressor %d: %.3g checks each | v_rcp_f32 -> v_fma_f32: %llu wrong (lanes 0-15 %llu, 16-31 %llu, 32-47 %llu, 48-63 %llu) | "
                 "v_sqrt_f32 -> v_add_u32: %llu wrong (%llu, %llu, %llu, %llu)\n",
                 DIST, aggressor, (double)checks, bad[0], quarter[0][0], quarter[0][1], quarter[0][2], quarter[0][3], bad[1], quarter[1][0], quarter[1][1], quarter[1][2], quarter[1][3]);
 }
@@ -180,10 +180,13 @@ int main(int argc, char** argv)
     CHK(hipMalloc(&d_hist, 128 * 4));
     CHK(hipMalloc(&d_checks, 8));
     CHK(hipMalloc(&d_sink, 64));
+    std::printf("separator modes: 0 none, 1 one VALU instruction, 10 s_nop 0 (the compiler's usual choice), 11 s_nop 1, 12 one SALU instruction, 13 one v_readlane_b32\n");
     run_case<0>(seconds, 0, d_hist, d_checks, d_sink);
-    run_case<0>(seconds, aggressor, d_hist, d_checks, d_sink);
-    run_case<1>(seconds, 0, d_hist, d_checks, d_sink);
+    run_case<10>(seconds, 0, d_hist, d_checks, d_sink);
+    run_case<10>(seconds, aggressor, d_hist, d_checks, d_sink);
+    run_case<12>(seconds, aggressor, d_hist, d_checks, d_sink);
+    run_case<13>(seconds, aggressor, d_hist, d_checks, d_sink);
+    run_case<11>(seconds, aggressor, d_hist, d_checks, d_sink);
     run_case<1>(seconds, aggressor, d_hist, d_checks, d_sink);
-    run_case<2>(seconds, aggressor, d_hist, d_checks, d_sink);
     return 0;
 }
