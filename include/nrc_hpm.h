@@ -269,7 +269,7 @@ size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t cap
  * mask rejects (see set_empty_skip) is ONE lane that walks for ~0.12 ms; started where the launch order has its (empty) tile --
  * at the very end -- it ends the launch that much later (one frame in four on the bench view: mean 0.213 -> 0.232 ms).  A 3-us
  * kernel finds such pixels for the NEXT frame's random numbers (drawn one frame early, same sequence; or the ones render_frames
- * was given) at the end of the train-ray stream's work, and gen_rays starts up to 8 of their tiles first.  Scheduling only: every
+ * was given) on the train-ray stream beside the current gen_rays, and the next gen_rays starts up to 8 of their tiles first.  Scheduling only: every
  * tile is traced exactly once either way.  hot_tiles copies the last frame's list -- 8 entries (ty << 16 | tx) and their count --
  * and returns 1 when the list had been computed one frame ahead, 0 when in front of gen_rays (first frame, pinned random numbers,
  * another camera), -1 when the frame used none, -2 on error. */

@@ -940,8 +940,8 @@ public:
         // the first samples of a view replace the costs (a cold first launch, another camera); later ones keep a decaying maximum
         frame_.tile_cost_keep = order_fresh_ > 0 ? 0u : order_keep_;
         if (sample_cost && order_fresh_ > 0) order_fresh_--;
-        // Hot tiles (DevFrame::hot_tiles): the list for this frame's random numbers was computed at the end of the previous
-        // frame's work on stream D (below); when it was not -- first frame, pinned random numbers, another mask -- it is computed
+        // Hot tiles (DevFrame::hot_tiles): the list for this frame's random numbers was computed on stream D beside the previous
+        // frame's gen_rays (below); when it was not -- first frame, pinned random numbers, another mask -- it is computed
         // here, in front of gen_rays.
         frame_.hot_tiles = nullptr;
         const int hb = (int)(frame_index_ & 1u);
@@ -957,6 +957,24 @@ public:
         }
         hot_ready_[hb] = false;
         last_hot_ = promote ? hb : -1;
+        // The next frame's list goes to stream D FIRST, in front of D's wait for this frame's gen_rays: it then runs beside this
+        // gen_rays (behind it, the next gen_rays would wait for this frame's train rays and the frames would serialise).  Buffer
+        // hb^1: its last reader is the gen_rays before this frame's, which D's work for that frame waited for.
+        if (promote) {
+            // the next frame's random numbers: announced by the caller (render_frames), or drawn now instead of then
+            const float* nr = next_random_;
+            if (have_hint_) nr = hint_random_;
+            else if (!have_next_random_) { draw_random(next_random_); have_next_random_ = true; }
+            have_hint_ = false;
+            DevFrame nf = frame_;
+            std::memcpy(nf.random, nr, 16);
+            NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_[hb ^ 1] + kHotTilesMax, 0, 4, D));
+            launch_hot_tiles(nf, (uint32_t*)d_hot_[hb ^ 1], D);
+            NRC_HIP(hipEventRecord(ev_hot_[hb ^ 1], D));
+            hot_ready_[hb ^ 1] = true;
+            hot_epoch_[hb ^ 1] = mask_epoch_;
+            std::memcpy(hot_random_[hb ^ 1], nr, 16);
+        }
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
@@ -975,21 +993,6 @@ public:
             NRC_HIP(hipEventRecord(ev_order_done_, D));
             order_pending_ = true;
             order_pending_frame_ = frame_index_;
-        }
-        if (promote) {      // the next frame's list (buffer hb^1: its last reader is the gen_rays before this frame's, D is behind this frame's)
-            // the next frame's random numbers: announced by the caller (render_frames), or drawn now instead of then
-            const float* nr = next_random_;
-            if (have_hint_) nr = hint_random_;
-            else if (!have_next_random_) { draw_random(next_random_); have_next_random_ = true; }
-            have_hint_ = false;
-            DevFrame nf = frame_;
-            std::memcpy(nf.random, nr, 16);
-            NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_[hb ^ 1] + kHotTilesMax, 0, 4, D));
-            launch_hot_tiles(nf, (uint32_t*)d_hot_[hb ^ 1], D);
-            NRC_HIP(hipEventRecord(ev_hot_[hb ^ 1], D));
-            hot_ready_[hb ^ 1] = true;
-            hot_epoch_[hb ^ 1] = mask_epoch_;
-            std::memcpy(hot_random_[hb ^ 1], nr, 16);
         }
         if (B != Cs && frame_index_ > 0) NRC_HIP(hipStreamWaitEvent(Cs, ev_train_done_[pp ^ 1], 0));   // weights of frame N-1
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the

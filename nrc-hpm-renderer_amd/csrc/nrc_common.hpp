@@ -60,12 +60,21 @@ struct Pcg32 {
 
 }  // namespace nrc
 
-// DIAGNOSTIC builds only (-DNRC_DIAG_SETPRIO=<mask>, tests/cpp/stress_main.cpp): side-stream kernels raise their waves' issue
-// priority -- bit 0 the inference / training kernels (nrc_mlp.hip), bit 1 k_composite, bit 2 the train-ray kernels (k_train_scan,
-// k_prep_train, k_ring_push).  With it, co-resident k_gen_rays waves misbehave a few per cent of the time;
-// never defined in the product.
-#ifdef NRC_DIAG_SETPRIO
-#define NRC_RAISE_WAVE_PRIORITY(bit) do { if ((NRC_DIAG_SETPRIO) & (bit)) __builtin_amdgcn_s_setprio(3); } while (0)
-#else
-#define NRC_RAISE_WAVE_PRIORITY(bit) do { } while (0)
+// Every kernel of the library that can share a SIMD with k_gen_rays raises its waves to the SAME user wave priority, the highest
+// (s_setprio 3).  Reason (tests/cpp/stress_main.cpp): a k_gen_rays wave that shares its SIMD with waves of a
+// HIGHER issue priority now and then -- 2-3 % of 72-frame runs when the inference kernel alone is raised; twice in ~60 runs of
+// round 2's build, whose streams differed in queue priority only -- leaves the path's last new_ray_dir with a different direction
+// in lanes 48..63 although every input is identical: the NRC query of those 16 pixels changes, nothing else.  Neither scratch, nor
+// the lane-pair tails, nor the spacing of transcendental instructions has a part in it (each was removed or padded without
+// effect).  With every kernel at one priority the event did not occur in 300 runs that otherwise show it 6-11 times; raising the
+// camera kernels ALONE does the same but starves the side streams (frame 0.279 -> 0.298 ms).  One common level costs nothing
+// against none.
+//   bit: 1 inference / training kernels (nrc_mlp.hip), 2 k_composite, 4 train-ray kernels, 8 camera kernels, 16 helpers
+//   -DNRC_DIAG_LOWPRIO=<mask>: DIAGNOSTIC builds leave those groups at the default priority 0 (8 = the configuration that fails)
+#ifndef NRC_WAVE_PRIORITY
+#define NRC_WAVE_PRIORITY 3
 #endif
+#ifndef NRC_DIAG_LOWPRIO
+#define NRC_DIAG_LOWPRIO 0
+#endif
+#define NRC_RAISE_WAVE_PRIORITY(bit) do { if (!((NRC_DIAG_LOWPRIO) & (bit))) __builtin_amdgcn_s_setprio(NRC_WAVE_PRIORITY); } while (0)

@@ -1013,22 +1013,8 @@ __device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx
 #define NRC_CAMERA_WAVES_PER_BLOCK 4
 #endif
 constexpr uint32_t CAMERA_WAVES_PER_BLOCK = NRC_CAMERA_WAVES_PER_BLOCK;
-// The camera kernels run at the highest user wave priority.  Reason (tests/cpp/stress_main.cpp): a k_gen_rays
-// wave that shares its SIMD with waves of a HIGHER issue priority -- waves of the renderer's high-priority streams, or any
-// kernel that raises its priority with s_setprio -- now and then (2-3 % of 72-frame runs with k_infer at priority 3; twice in ~60
-// runs of the product build in round 2) leaves the path's last new_ray_dir with a different direction in lanes 48..63 although
-// every input is identical: the NRC query of those 16 pixels changes, nothing else.  Neither scratch, nor the lane-pair tails,
-// nor the spacing of transcendental instructions has a part in it (each was removed or padded without effect); with the camera
-// waves at a priority no lower than their neighbours' the event did not occur once in 300 runs that otherwise show it 6-11 times.
-#ifndef NRC_CAMERA_WAVE_PRIORITY
-#define NRC_CAMERA_WAVE_PRIORITY 3
-#endif
-__device__ __forceinline__ void camera_wave_priority()
-{
-#if NRC_CAMERA_WAVE_PRIORITY > 0
-    __builtin_amdgcn_s_setprio(NRC_CAMERA_WAVE_PRIORITY);
-#endif
-}
+// (wave priority of the camera kernels: NRC_RAISE_WAVE_PRIORITY in nrc_common.hpp)
+__device__ __forceinline__ void camera_wave_priority() { NRC_RAISE_WAVE_PRIORITY(8); }
 __host__ __device__ inline uint32_t camera_row_blocks(uint32_t w)
 {
     const uint32_t blocks_x = (((w + 7u) >> 3) + CAMERA_WAVES_PER_BLOCK - 1u) / CAMERA_WAVES_PER_BLOCK;
@@ -1115,6 +1101,7 @@ __global__ __launch_bounds__(256) void k_flight_table(float* __restrict__ table)
 
 __global__ __launch_bounds__(256) void k_flight_select(const float* __restrict__ table, float lambda, uint32_t* __restrict__ out, uint32_t* __restrict__ bits)
 {
+    NRC_RAISE_WAVE_PRIORITY(16);
     const uint32_t m = blockIdx.x * 256u + threadIdx.x;
     const bool capped = !(table[m] > lambda);
     const unsigned long long b = __ballot(capped);
@@ -1132,6 +1119,7 @@ __global__ __launch_bounds__(256) void k_flight_select(const float* __restrict__
 // caller), the first kHotTilesMax are kept in hot[0..].  256 workgroups (the dispatcher places ~250 workgroups per microsecond), eight pixels per thread.
 __global__ __launch_bounds__(1024) void k_hot_tiles(DevFrame fr, uint32_t* __restrict__ hot)
 {
+    NRC_RAISE_WAVE_PRIORITY(16);
     const uint32_t n = fr.w * fr.h;
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
         const uint32_t y = i / fr.w, lx = i - y * fr.w;
@@ -1442,6 +1430,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
 // cost classes of 512 cycles, one workgroup, order within a class arbitrary -- any permutation gives the same frame.
 __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order)
 {
+    NRC_RAISE_WAVE_PRIORITY(16);
     __shared__ uint32_t hist[1024];
     const uint32_t tid = threadIdx.x;
     hist[tid] = 0u;
@@ -1476,6 +1465,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_tile_mask(const float* __restrict__ boxes, uint32_t n_boxes, DevProjView pv, DevFrame fr,
                                                   uint32_t* __restrict__ mask)
 {
+    NRC_RAISE_WAVE_PRIORITY(16);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_boxes) return;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;

@@ -666,6 +666,7 @@ __device__ __forceinline__ void oneblob4(float xd, float (&out)[4]) { oneblob4_b
 template <int POS, int DIR>
 __global__ __launch_bounds__(256) void k_encode(const float* __restrict__ in, half_t* __restrict__ feat, uint32_t n, int skip_zero)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int NP = POS == 3 ? 72 : (POS == 1 ? 3 : 36);
     constexpr int ND = DIR == 1 ? 2 : 8;
     constexpr int E16 = (NP + ND + 15) / 16 * 16;
@@ -779,6 +780,7 @@ template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ in, const uint32_t* __restrict__ table16,
                                                     half_t* __restrict__ feat, uint32_t n, HashLevels lv, int skip_zero)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int ND = DIR == 1 ? 2 : 8, E16 = 48;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
@@ -832,6 +834,7 @@ template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict__ in, const uint32_t* __restrict__ table16,
                                                        uint32_t* __restrict__ feat_lm, uint32_t n, HashLevels lv, int skip_zero)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int ND = DIR == 1 ? 2 : 8;
     const uint32_t sample = blockIdx.x * 256u + threadIdx.x, slot = blockIdx.y;
     if (sample >= n) return;
@@ -878,6 +881,7 @@ __global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict_
 __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
                                                       uint32_t* __restrict__ grad16, uint32_t n, HashLevels lv)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
     if (sample >= n) return;
@@ -898,6 +902,7 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
 
 __global__ void k_grid_grad_f32(const uint32_t* __restrict__ grad16, float* __restrict__ grad, uint32_t n_entries)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     const half2v h = __builtin_bit_cast(half2v, grad16[i]);
@@ -915,6 +920,7 @@ __global__ void k_grid_grad_f32(const uint32_t* __restrict__ grad16, float* __re
 __global__ __launch_bounds__(256) void k_grid_pack(const uint32_t* __restrict__ grad16, uint32_t n_entries,
                                                   uint32_t* __restrict__ list, uint32_t cap)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t e0 = wave * 1024u;
     uint32_t w[16], cnt = 0;
@@ -957,6 +963,7 @@ __global__ __launch_bounds__(256) void k_grid_pack(const uint32_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_grid_apply(const uint32_t* __restrict__ list, uint32_t cap, float* __restrict__ grad,
                                                    uint32_t n_entries)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= min(list[0], cap)) return;
     const uint32_t e = list[2u + 2u * i];
@@ -971,6 +978,7 @@ __global__ __launch_bounds__(256) void k_grid_apply(const uint32_t* __restrict__
 __global__ void k_pack_grid(const float* __restrict__ w, const float* __restrict__ ema, uint32_t* __restrict__ t_train,
                             uint32_t* __restrict__ t_ema, uint32_t n_entries)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     float2v a = {w[2 * (size_t)i], w[2 * (size_t)i + 1]}, b = {ema[2 * (size_t)i], ema[2 * (size_t)i + 1]};
@@ -1570,6 +1578,7 @@ __device__ __forceinline__ void sgd_ema_update(uint32_t i, float* __restrict__ w
 __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
                            float* __restrict__ v, const float* __restrict__ grad, uint32_t n, uint32_t n_matrix, AdamArgs a)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float wn, en;
@@ -1579,6 +1588,7 @@ __global__ void k_adam_ema(float* __restrict__ w, float* __restrict__ ema, float
 __global__ void k_sgd_ema(float* __restrict__ w, float* __restrict__ ema, const float* __restrict__ grad, uint32_t n, float lr,
                           AdamArgs a)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float wn, en;
@@ -1626,6 +1636,7 @@ __global__ __launch_bounds__(256) void k_grid_opt(float* __restrict__ w, float* 
                                                  const uint32_t* __restrict__ grad16, uint32_t n_matrix, uint32_t n_entries, float lr,
                                                  AdamArgs a, uint32_t* __restrict__ t_train, uint32_t* __restrict__ t_ema)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= n_entries) return;
     const uint32_t i0 = n_matrix + 2u * e;
@@ -1653,6 +1664,7 @@ __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ em
                        const int32_t* __restrict__ src_inf, uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd,
                        half_t* __restrict__ pk_infer, half_t* __restrict__ pk_fwd, half_t* __restrict__ pk_bwd)
 {
+    NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_fwd) {
         const int32_t s = src_fwd[i], si = src_inf[i];      // the EMA (inference) image may order layer 0's inputs differently

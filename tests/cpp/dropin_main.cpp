@@ -96,7 +96,15 @@ int main(int argc, char** argv)
             en::McHpmRenderer mcHpmRenderer(W, H, 32, true, &camera, hpmScene);                      // src/main.cu:212
             const en::Reference::Result mcResult = reference.CompareMc(mcHpmRenderer, &camera, nullptr);
             en::Reference again(W, H, appConfig, hpmScene, nullptr, refRoot, 1u << 30);               // the folder exists: loaded, not rendered
+            // (pinned random numbers: CompareMc ends with SetCamera(oldCamera), which clears the accumulation image, so the frame
+            // it compared is rendered once more below for the dump)
+            const float pin[4] = {0.6180339887f, 0.4142135623f, 0.7320508075f, 0.2360679775f};
+            en::nrc_check(nrc_mc_renderer_set_frame_random(mcHpmRenderer.Handle(), pin));
             const en::Reference::Result mcAgain = again.CompareMc(mcHpmRenderer, &camera, nullptr);
+            mcHpmRenderer.SetCamera(nullptr, again.GetRefCamera());
+            en::nrc_check(nrc_mc_renderer_set_frame_random(mcHpmRenderer.Handle(), pin));
+            mcHpmRenderer.Render(nullptr);
+            if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
             for (const en::Reference::Result* r : {&nrcResult, &mcResult, &mcAgain}) {
                 const float v[8] = {r->mse, r->refMean, r->ownMean, r->ownVar, (float)r->validPixelCount, r->GetRelBias(), r->GetCV(), r->GetRelVar()};
                 std::fwrite(v, sizeof(float), 8, o);

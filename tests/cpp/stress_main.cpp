@@ -11,7 +11,7 @@
 //
 //   stress_main <mode: tiles|pipe|both> <iters> <perturb: 0|1|2> [width height frames]
 // Linked against libnrc_hpm.so (rpath); tools/stress.sh runs it >= 100 times in fresh processes under the environment variants
-// NRC_POISON_ALLOC=1, NRC_GUARD_ALLOC=1, GPU_MAX_HW_QUEUES=2/4/8 and against the diagnostic -DNRC_DIAG_SETPRIO build.
+// NRC_POISON_ALLOC=1, NRC_GUARD_ALLOC=1, GPU_MAX_HW_QUEUES=2/4/8 and against the diagnostic -DNRC_DIAG_LOWPRIO=8 build (camera kernels at wave priority 0 beside raised neighbours).
 #include <hip/hip_runtime.h>
 
 #include <atomic>

@@ -10,5 +10,5 @@ for E in "$@"; do
   python3 -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print('%-40s %7.1f Msamples/s frame %.4f' % (sys.argv[2] or '(default)', d['value'], d['ms_per_frame']), {k: round(v,3) for k,v in d['stage_ms'].items()})" $OUT/env_$i.json "$E"
+print('%-40s %7.1f Msamples/s frame %.4f host %.3f' % (sys.argv[2] or '(default)', d['value'], d['ms_per_frame'], d.get('host_enqueue_ms_per_frame', -1)), {k: round(v,3) for k,v in d['stage_ms'].items()})" $OUT/env_$i.json "$E"
 done

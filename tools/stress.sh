@@ -10,7 +10,7 @@ BIN=tests/cpp/_build
 if [ "${1:-}" = "build" ]; then
     mkdir -p $BIN
     make -C nrc-hpm-renderer_amd/csrc ARCH=gfx950 || exit 1
-    make -C nrc-hpm-renderer_amd/csrc ARCH=gfx950 OUT=../lib_prio EXTRA=-DNRC_DIAG_SETPRIO || exit 1
+    make -C nrc-hpm-renderer_amd/csrc ARCH=gfx950 OUT=../lib_prio EXTRA=-DNRC_DIAG_LOWPRIO=8 || exit 1
     for v in "" _prio; do
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O2 -Iinclude tests/cpp/stress_main.cpp -o $BIN/stress_main$v \
             -Lnrc-hpm-renderer_amd/lib$v -lnrc_hpm -pthread "-Wl,-rpath,\$ORIGIN/../../../nrc-hpm-renderer_amd/lib$v" || exit 1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# verification stage: the comparison and the build that reproduced (tiles-vs-whole, -DNRC_DIAG_SETPRIO), many fresh processes
+# verification stage: the comparison and the build that reproduced (tiles-vs-whole, -DNRC_DIAG_LOWPRIO=8: the camera kernels at wave priority 0 beside raised neighbours), many fresh processes
 set -u
 cd "$(dirname "$0")/.."
 N=${1:-150}; OUT=${2:-gpurun_out/stress3}; mkdir -p "$OUT"; : > "$OUT/summary.txt"
