@@ -176,6 +176,7 @@ __global__ void k_publish_loss(const float* __restrict__ d_loss, uint32_t seq, u
 }
 
 // ---------------------------------------------------------------------------------------------------- Cache
+
 class Cache {
     // validated before any size is derived from it: 2 << (log2 - 1) with log2 = 0 would shift by 0xFFFFFFFF
     static const nrc_config& checked(const nrc_config& cfg)
@@ -825,6 +826,7 @@ public:
         for (auto& h : d_hot_) { alloc(&h, 64); NRC_HIP(hipMemset(h, 0, 64)); }
         for (auto& e : ev_hot_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hot_promote_ = getenv("NRC_NO_HOT_TILES") == nullptr;
+        hot_ahead_ = getenv("NRC_HOT_TILES_INLINE") == nullptr;      // diagnostic: always compute the list in front of gen_rays
         // costliest-first launch order of gen_rays' tiles: costs of frame N order frame N + 2 (sorted on stream D beside frame N + 1)
         n_slots_ = camera_slots(w, h);
         alloc(&d_tile_cost_, (size_t)n_slots_ * 4);
@@ -837,6 +839,7 @@ public:
         NRC_HIP(hipEventCreateWithFlags(&ev_order_done_, hipEventDisableTiming));
         cost_order_ = getenv("NRC_NO_COST_ORDER") == nullptr;
         if (const char* e = getenv("NRC_COST_ORDER_EVERY")) order_every_ = (uint64_t)std::max(2, atoi(e));
+        order_neighbours_ = getenv("NRC_COST_ORDER_NEIGHBOURS") != nullptr;
         if (const char* e = getenv("NRC_COST_ORDER_KEEP")) order_keep_ = (uint32_t)std::min(31, std::max(0, atoi(e)));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
@@ -960,7 +963,7 @@ public:
         // The next frame's list goes to stream D FIRST, in front of D's wait for this frame's gen_rays: it then runs beside this
         // gen_rays (behind it, the next gen_rays would wait for this frame's train rays and the frames would serialise).  Buffer
         // hb^1: its last reader is the gen_rays before this frame's, which D's work for that frame waited for.
-        if (promote) {
+        if (promote && hot_ahead_) {
             // the next frame's random numbers: announced by the caller (render_frames), or drawn now instead of then
             const float* nr = next_random_;
             if (have_hint_) nr = hint_random_;
@@ -989,7 +992,7 @@ public:
         NRC_HIP(hipEventRecord(ev_prep_done_[gp], D));
         if (B != D) NRC_HIP(hipStreamWaitEvent(B, ev_prep_done_[gp], 0));
         if (sample_cost) {      // order buffer cur^1: its last reader is a gen_rays before this one on A
-            launch_tile_order((const uint32_t*)d_tile_cost_, n_slots_, (uint32_t*)d_tile_order_[order_cur_ ^ 1], D);
+            launch_tile_order((const uint32_t*)d_tile_cost_, n_slots_, (uint32_t*)d_tile_order_[order_cur_ ^ 1], w_, order_neighbours_, D);
             NRC_HIP(hipEventRecord(ev_order_done_, D));
             order_pending_ = true;
             order_pending_frame_ = frame_index_;
@@ -1306,7 +1309,7 @@ private:
     // hot-tile lists (DevFrame::hot_tiles), double-buffered by frame parity; [k] was computed on stream D for hot_random_[k]
     void* d_hot_[2] = {nullptr, nullptr};
     hipEvent_t ev_hot_[2] = {nullptr, nullptr};
-    bool hot_promote_ = true, hot_ready_[2] = {false, false};
+    bool hot_promote_ = true, hot_ahead_ = true, hot_ready_[2] = {false, false};
     uint64_t hot_epoch_[2] = {0, 0}, mask_epoch_ = 0;
     float hot_random_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     float next_random_[4] = {0, 0, 0, 0}, hint_random_[4] = {0, 0, 0, 0};
@@ -1324,6 +1327,7 @@ private:
     bool cost_order_ = true, order_pending_ = false;
     int order_cur_ = 0;
     uint64_t order_every_ = 4, order_pending_frame_ = 0;
+    bool order_neighbours_ = false;
     bool order_resample_ = false;
     uint32_t order_keep_ = 4;        // DevFrame::tile_cost_keep once the view's first two samples are in
     int order_fresh_ = 2;
@@ -1398,7 +1402,7 @@ public:
         launch_mc_render(scene_.d, cam_, frame_, path_length_, blend_factor, (float*)d_out_, (float*)d_info_,
                          count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
         NRC_HIP(hipEventRecord(ev_[1], stream_));
-        if (sample_cost) launch_tile_order((const uint32_t*)d_tile_cost_, n_slots_, (uint32_t*)d_tile_order_, stream_);
+        if (sample_cost) launch_tile_order((const uint32_t*)d_tile_cost_, n_slots_, (uint32_t*)d_tile_order_, w_, false, stream_);
         frame_index_++;
         timed_ = true;
     }

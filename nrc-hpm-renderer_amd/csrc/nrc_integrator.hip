@@ -1428,15 +1428,32 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
 // launch and a third of its duration is a thinning tail (tools/loop_profile.py).  Tile costs repeat from frame to frame
 // (correlation 0.95), so the waves are launched in order of decreasing cost of an earlier frame: a counting sort over 1024
 // cost classes of 512 cycles, one workgroup, order within a class arbitrary -- any permutation gives the same frame.
-__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order)
+// row_len > 0: a tile is ranked by the largest cost among itself and its four neighbours (row_len = slots per tile row).  What ends
+// a launch is a tile whose cost was under-estimated -- a long walk is a rare event of a pixel, and a tile at the cloud's rim has
+// one in some frames only --, and its neighbours see the same medium: their maximum is the better estimate of what it CAN cost.
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order, uint32_t row_len)
 {
     NRC_RAISE_WAVE_PRIORITY(16);
     __shared__ uint32_t hist[1024];
     const uint32_t tid = threadIdx.x;
     hist[tid] = 0u;
     __syncthreads();
-    auto key_of = [](uint32_t c) { return 1023u - min(c >> 9, 1023u); };      // descending cost
-    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[key_of(cost[i])], 1u);
+    auto key_of = [=](uint32_t i) {
+        uint32_t c = cost[i];
+        if (row_len != 0u) {
+            // slot -> (row k, position in the row); the rows alternate around the middle one (pixel_of_launch_slot): the vertical
+            // neighbours of row k are rows k - 2 and k + 2, and rows 0 and 1 are neighbours of each other
+            const uint32_t k = i / row_len, j = i - k * row_len;
+            if (j > 0u) c = max(c, cost[i - 1u]);
+            if (j + 1u < row_len) c = max(c, cost[i + 1u]);
+            if (i + 2u * row_len < n) c = max(c, cost[i + 2u * row_len]);
+            if (k >= 2u) c = max(c, cost[i - 2u * row_len]);
+            if (k == 0u && i + row_len < n) c = max(c, cost[i + row_len]);
+            if (k == 1u) c = max(c, cost[i - row_len]);
+        }
+        return 1023u - min(c >> 9, 1023u);      // descending cost
+    };
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[key_of(i)], 1u);
     __syncthreads();
     // exclusive prefix sum over the 1024 classes (wave scans + wave totals)
     const uint32_t v = hist[tid];
@@ -1454,7 +1471,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
     __syncthreads();
     hist[tid] = woff + incl - v;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024u) order[atomicAdd(&hist[key_of(cost[i])], 1u)] = i;
+    for (uint32_t i = tid; i < n; i += 1024u) order[atomicAdd(&hist[key_of(i)], 1u)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------ empty-space tile mask
@@ -1842,9 +1859,9 @@ void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s)
 
 uint32_t camera_slots(uint32_t w, uint32_t h) { return camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK * ceil_div(h, 8); }
 
-void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, hipStream_t s)
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order, neighbours ? camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK : 0u);
     NRC_HIP(hipGetLastError());
 }
 

@@ -97,7 +97,7 @@ void launch_flight_table(float* table, hipStream_t s);
 void launch_flight_select(const float* table, float lambda, uint32_t* count_and_list, uint32_t* bits, hipStream_t s);
 // launch slots of the camera kernels (rows padded to an odd number of workgroups) and the costliest-first order over them
 uint32_t camera_slots(uint32_t w, uint32_t h);
-void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, hipStream_t s);
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, hipStream_t s);
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);

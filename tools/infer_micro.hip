@@ -3,6 +3,11 @@
 // image, ReLU + fp16 convert between the layers, optionally FILL extra VALU instructions per MFMA (the encoding's share).
 //   MODE 0: both tiles in the same layer (16 MFMAs, then 64 ReLU/convert instructions)      -- forward_tiles
 //   MODE 1: tiles half a layer apart, ReLU of one tile in the MFMA gaps of the other           -- forward_tiles_skewed
+//   MODE 2: v_mfma_f32_16x16x32_f16 formulation -- four 16-sample tiles per wave iteration, all in the same layer; a layer is 8 weight
+//           fragments (4 row tiles of 16 neurons x 2 k-blocks of 32) x 4 sample tiles = 32 MFMAs of half the size; the accumulators
+//           of row tiles 2kb and 2kb+1 (4 rows per lane each) are ReLU'd / converted into the B operand of k-block kb of the next layer
+//           (k order permuted in the weight image, as kperm does for 32x32x16)      -- VERDICT r02 item 4
+//   MODE 3: the same with the sample tiles in two groups half a layer apart (ReLU of one group in the MFMA shadow of the other)
 //   RELU 0: accumulators are re-used without conversion work (v_mov only where the compiler needs them)
 // Reports the MFMA pipe utilisation at the clock the kernel held (s_memtime / s_memrealtime).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/infer_micro.hip -o tools/_build/infer_micro
@@ -145,6 +150,101 @@ __global__ __launch_bounds__(512, WPS) void k(float* out, int iters, unsigned lo
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+using f32x4 = float __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <int MODE, int RELU, int FILL, int WPS>
+__global__ __launch_bounds__(512, WPS) void k16(float* out, int iters, unsigned long long* clk, int trivial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* lw = (uint4*)smem;
+    for (int i = threadIdx.x; i < NFRAG * 64; i += blockDim.x) {
+        if (trivial) { lw[i] = make_uint4(0x2c002c00u + (i & 0xff), 0xa8002c00u, 0x2c00a800u + 7 * (i & 0xff), 0x24002c00u); continue; }
+        uint32_t w[4];
+        for (int c = 0; c < 4; c++) {
+            uint32_t hsh = (uint32_t)(i * 4 + c) * 2654435761u;
+            hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+            const float lo = ((float)(hsh & 0xffffu) / 65535.0f - 0.5f) * 0.6f, hi = ((float)(hsh >> 16) / 65535.0f - 0.5f) * 0.6f;
+            half2v pk = {(_Float16)lo, (_Float16)hi};
+            w[c] = __builtin_bit_cast(uint32_t, pk);
+        }
+        lw[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    f32x4 acc[4][4];          // [sample tile][row tile of 16 neurons]
+    uint4v b[4][2];           // [sample tile][k-block of 32]
+    float f[4] = {0.1f * lane, 0.2f, 0.3f, 0.4f};
+    for (int t = 0; t < 4; t++) for (int kb = 0; kb < 2; kb++) b[t][kb] = uint4v{0x3c003c00u + lane, 0x38003c00u, 0x3c003800u, 0x34003c00u + t};
+    for (int t = 0; t < 4; t++) for (int m = 0; m < 4; m++) acc[t][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto relu_tile = [&](int t, int m) {      // row tile m of sample tile t -> half of b[t][m >> 1]
+        b[t][m >> 1][2 * (m & 1)] = relu_pk<RELU>(acc[t][m][0], acc[t][m][1]);
+        b[t][m >> 1][2 * (m & 1) + 1] = relu_pk<RELU>(acc[t][m][2], acc[t][m][3]);
+    };
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+        asm volatile("" ::: "memory");
+        if (!trivial) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) { const uint4 v = lw[((it + 2 * t + kb) % NFRAG) * 64 + lane]; b[t][kb] = uint4v{v.x & 0x7fff7fffu, v.y, v.z & 0x7fff7fffu, v.w}; }
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int l = 0; l < LAYERS; l++) {
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const half8 a = ld_frag(lw, 8 * l + 4 * kb + m, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            acc[t][m] = mfma16(a, __builtin_bit_cast(half8, b[t][kb]), kb == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[t][m]);
+                            if (t & 1) filler<FILL>(f);       // FILL per 32x32x16-equivalent = per two of these MFMAs
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) relu_tile(t, m);
+            }
+        } else {
+            // two groups of two sample tiles, half a layer apart: while group g runs a layer's 16 MFMAs, the 16 ReLU/convert pairs of
+            // the other group's previous layer are issued between them
+#pragma unroll
+            for (int l = 0; l < LAYERS; l++) {
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {
+                            const half8 a = ld_frag(lw, 8 * l + 4 * kb + m, lane);
+#pragma unroll
+                            for (int tt = 0; tt < 2; tt++) {
+                                const int t = 2 * g + tt;
+                                acc[t][m] = mfma16(a, __builtin_bit_cast(half8, b[t][kb]), kb == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[t][m]);
+                            }
+                            // other group: its 8 (tile, row tile) conversions spread over this group's 8 fragment steps
+                            const int step = kb * 4 + m, ot = 2 * (g ^ 1) + (step >> 2), om = step & 3;
+                            relu_tile(ot, om);
+                            filler<FILL>(f);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = f[0] + f[1] + f[2] + f[3];
+    for (int t = 0; t < 4; t++) for (int m = 0; m < 4; m++) for (int e = 0; e < 4; e++) s += acc[t][m][e];
+    for (int t = 0; t < 4; t++) for (int q = 0; q < 2; q++) s += (float)(b[t][q][0] & 0xffu);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int MODE, int RELU, int FILL, int WPS>
 void run(const char* name, int blocks_per_cu, int iters, int trivial)
 {
@@ -152,7 +252,7 @@ void run(const char* name, int blocks_per_cu, int iters, int trivial)
     float* out; unsigned long long* clk;
     hipMalloc(&out, (size_t)blocks * threads * 4); hipMalloc(&clk, blocks * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto kern = k<MODE, RELU, FILL, WPS>;
+    auto kern = MODE >= 2 ? k16<MODE, RELU, FILL, WPS> : k<MODE < 2 ? MODE : 0, RELU, FILL, WPS>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG * 1024);
     for (int w = 0; w < 3; w++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), NFRAG * 1024, 0, out, iters, clk, trivial);
     hipEventRecord(e0);
@@ -179,6 +279,11 @@ int main()
         run<0, 1, 3, 1>("same-layer tiles, relu, 3 VALU fill/MFMA", 1, it, trivial);
         run<1, 1, 3, 1>("skewed tiles, relu, 3 VALU fill/MFMA", 1, it, trivial);
         run<1, 1, 3, 4>("skewed tiles, relu, 3 VALU fill/MFMA", 2, it, trivial);
+        run<2, 1, 0, 1>("16x16x32: same-layer tiles, relu", 1, it, trivial);
+        run<3, 1, 0, 1>("16x16x32: skewed groups, relu", 1, it, trivial);
+        run<2, 1, 3, 1>("16x16x32: same-layer, relu, 3 VALU fill", 1, it, trivial);
+        run<3, 1, 3, 1>("16x16x32: skewed groups, relu, 3 VALU fill", 1, it, trivial);
+        run<3, 1, 3, 4>("16x16x32: skewed groups, relu, 3 VALU fill", 2, it, trivial);
     }
     return 0;
 }
