@@ -267,12 +267,13 @@ int nrc_renderer_set_cost_order(nrc_renderer_t* r, int on);
 size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t capacity);
 /* Hot tiles (on by default): a pixel whose RNG state can run into DeltaTrack's cap of 128 collisions inside a tile the empty-space
  * mask rejects (see set_empty_skip) is ONE lane that walks for ~0.12 ms; started where the launch order has its (empty) tile --
- * at the very end -- it ends the launch that much later (one frame in four on the bench view: mean 0.213 -> 0.232 ms).  A 3-us
- * kernel finds such pixels for the NEXT frame's random numbers (drawn one frame early, same sequence; or the ones render_frames
- * was given) on the train-ray stream beside the current gen_rays, and the next gen_rays starts up to 8 of their tiles first.  Scheduling only: every
- * tile is traced exactly once either way.  hot_tiles copies the last frame's list -- 8 entries (ty << 16 | tx) and their count --
- * and returns 1 when the list had been computed one frame ahead, 0 when in front of gen_rays (first frame, pinned random numbers,
- * another camera), -1 when the frame used none, -2 on error. */
+ * at the very end -- it ends the launch that much later (one frame in four on the bench view: mean 0.213 -> 0.232 ms).  Each
+ * gen_rays launch therefore also tests its pixels against the NEXT frame's random numbers (drawn one frame early, same sequence;
+ * or the ones render_frames was given) -- one more hash per pixel, no launch of its own -- and the next launch starts up to 8 of
+ * the tiles found first.  Scheduling only: every tile is traced exactly once either way.  hot_tiles copies the last frame's list
+ * -- 8 entries (ty << 16 | tx) and their count -- and returns 1 when the list had been built by the previous frame's launch, 0
+ * when by a kernel in front of gen_rays (first frame, pinned random numbers, another camera), -1 when the frame used none, -2 on
+ * error. */
 int nrc_renderer_set_hot_tiles(nrc_renderer_t* r, int on);
 int nrc_renderer_hot_tiles(nrc_renderer_t* r, uint32_t* host_out9);
 /* The NRC vertex images (buffers 2 and 3: nrcRayOrigin / nrcRayDir of gen_rays.comp:97-100) are read back only at the pixels of

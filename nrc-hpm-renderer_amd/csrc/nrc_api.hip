@@ -824,7 +824,6 @@ public:
         alloc(&d_flight_bits_, (size_t)kFlightStates / 8 + 8);
         alloc(&d_flight_sel_, (1 + kFlightListMax) * 4);
         for (auto& h : d_hot_) { alloc(&h, 64); NRC_HIP(hipMemset(h, 0, 64)); }
-        for (auto& e : ev_hot_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hot_promote_ = getenv("NRC_NO_HOT_TILES") == nullptr;
         hot_ahead_ = getenv("NRC_HOT_TILES_INLINE") == nullptr;      // diagnostic: always compute the list in front of gen_rays
         // costliest-first launch order of gen_rays' tiles: costs of frame N order frame N + 2 (sorted on stream D beside frame N + 1)
@@ -881,7 +880,6 @@ public:
         for (auto& e : ev_comp_done_) if (e) (void)hipEventDestroy(e);
         if (ev_consumer_) (void)hipEventDestroy(ev_consumer_);
         if (ev_order_done_) (void)hipEventDestroy(ev_order_done_);
-        for (auto& e : ev_hot_) if (e) (void)hipEventDestroy(e);
         cache_.forget(this);
     }
 
@@ -943,41 +941,43 @@ public:
         // the first samples of a view replace the costs (a cold first launch, another camera); later ones keep a decaying maximum
         frame_.tile_cost_keep = order_fresh_ > 0 ? 0u : order_keep_;
         if (sample_cost && order_fresh_ > 0) order_fresh_--;
-        // Hot tiles (DevFrame::hot_tiles): the list for this frame's random numbers was computed on stream D beside the previous
-        // frame's gen_rays (below); when it was not -- first frame, pinned random numbers, another mask -- it is computed
-        // here, in front of gen_rays.
+        // Hot tiles (DevFrame::hot_tiles): the list for this frame's random numbers was built by the previous frame's gen_rays
+        // (DevFrame::hot_next: no launch and no event of its own -- as a kernel on a side stream it cost a cross-stream hand-over
+        // of ~0.01 ms per frame, whichever stream and position); when it was not -- first frame, pinned random numbers, another
+        // mask -- k_hot_tiles computes it here, in front of gen_rays.
         frame_.hot_tiles = nullptr;
-        const int hb = (int)(frame_index_ & 1u);
+        frame_.hot_next = frame_.hot_reset = nullptr;
+        const int hb = (int)(frame_index_ % 3u);
         const bool promote = hot_promote_ && frame_.tile_mask != nullptr && frame_.flight_mode == 1u && frame_.flight_n > 0;
         if (promote) {
-            if (hot_ready_[hb] && D != A) NRC_HIP(hipStreamWaitEvent(A, ev_hot_[hb], 0));
+            if (!hot_chain_) {      // the rotation starts (again): all three lists empty
+                for (auto& h : d_hot_) NRC_HIP(hipMemsetAsync(h, 0, 64, A));
+                for (bool& r : hot_ready_) r = false;
+            }
             last_hot_predicted_ = hot_ready_[hb] && hot_epoch_[hb] == mask_epoch_ && std::memcmp(hot_random_[hb], frame_.random, 16) == 0;
             if (!last_hot_predicted_) {
                 NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_[hb] + kHotTilesMax, 0, 4, A));
                 launch_hot_tiles(frame_, (uint32_t*)d_hot_[hb], A);
             }
             frame_.hot_tiles = (const uint32_t*)d_hot_[hb];
+            hot_ready_[hb] = false;
+            if (hot_ahead_) {
+                // the next frame's random numbers: announced by the caller (render_frames), or drawn now instead of then
+                const float* nr = next_random_;
+                if (have_hint_) nr = hint_random_;
+                else if (!have_next_random_) { draw_random(next_random_); have_next_random_ = true; }
+                const int hn = (hb + 1) % 3;
+                std::memcpy(frame_.random_next, nr, 16);
+                frame_.hot_next = (uint32_t*)d_hot_[hn];
+                frame_.hot_reset = (uint32_t*)d_hot_[(hb + 2) % 3] + kHotTilesMax;
+                hot_ready_[hn] = true;
+                hot_epoch_[hn] = mask_epoch_;
+                std::memcpy(hot_random_[hn], nr, 16);
+            }
         }
-        hot_ready_[hb] = false;
+        have_hint_ = false;
+        hot_chain_ = promote && hot_ahead_;
         last_hot_ = promote ? hb : -1;
-        // The next frame's list goes to stream D FIRST, in front of D's wait for this frame's gen_rays: it then runs beside this
-        // gen_rays (behind it, the next gen_rays would wait for this frame's train rays and the frames would serialise).  Buffer
-        // hb^1: its last reader is the gen_rays before this frame's, which D's work for that frame waited for.
-        if (promote && hot_ahead_) {
-            // the next frame's random numbers: announced by the caller (render_frames), or drawn now instead of then
-            const float* nr = next_random_;
-            if (have_hint_) nr = hint_random_;
-            else if (!have_next_random_) { draw_random(next_random_); have_next_random_ = true; }
-            have_hint_ = false;
-            DevFrame nf = frame_;
-            std::memcpy(nf.random, nr, 16);
-            NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_[hb ^ 1] + kHotTilesMax, 0, 4, D));
-            launch_hot_tiles(nf, (uint32_t*)d_hot_[hb ^ 1], D);
-            NRC_HIP(hipEventRecord(ev_hot_[hb ^ 1], D));
-            hot_ready_[hb ^ 1] = true;
-            hot_epoch_[hb ^ 1] = mask_epoch_;
-            std::memcpy(hot_random_[hb ^ 1], nr, 16);
-        }
         NRC_HIP(hipEventRecord(ev_[0], A));
         launch_gen_rays(scene_.d, cam_, frame_, cfg_.primary_ray_length, cfg_.primary_ray_prob, (float*)d_primary_,
                         (float*)d_info_, (float*)d_origin_, (float*)d_dir_, (float*)d_infer_in_,
@@ -1306,12 +1306,12 @@ private:
     bool full_vertex_images_ = false;
     void* d_tile_mask_ = nullptr;
     void *d_flight_bits_ = nullptr, *d_flight_sel_ = nullptr;
-    // hot-tile lists (DevFrame::hot_tiles), double-buffered by frame parity; [k] was computed on stream D for hot_random_[k]
-    void* d_hot_[2] = {nullptr, nullptr};
-    hipEvent_t ev_hot_[2] = {nullptr, nullptr};
-    bool hot_promote_ = true, hot_ahead_ = true, hot_ready_[2] = {false, false};
-    uint64_t hot_epoch_[2] = {0, 0}, mask_epoch_ = 0;
-    float hot_random_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // hot-tile lists (DevFrame::hot_tiles), three in rotation (read / appended by the same gen_rays / zeroed for the one after);
+    // [k] was built for the random numbers hot_random_[k]
+    void* d_hot_[3] = {nullptr, nullptr, nullptr};
+    bool hot_promote_ = true, hot_ahead_ = true, hot_chain_ = false, hot_ready_[3] = {false, false, false};
+    uint64_t hot_epoch_[3] = {0, 0, 0}, mask_epoch_ = 0;
+    float hot_random_[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     float next_random_[4] = {0, 0, 0, 0}, hint_random_[4] = {0, 0, 0, 0};
     bool have_next_random_ = false, have_hint_ = false, last_hot_predicted_ = false;
     int last_hot_ = -1;

@@ -1116,12 +1116,15 @@ __global__ __launch_bounds__(256) void k_flight_select(const float* __restrict__
 }
 
 // the tiles with a pixel in a capped RNG state (list mode), for DevFrame::hot_tiles: hot[kHotTilesMax] counts them (zeroed by the
-// caller), the first kHotTilesMax are kept in hot[0..].  256 workgroups (the dispatcher places ~250 workgroups per microsecond), eight pixels per thread.
-__global__ __launch_bounds__(1024) void k_hot_tiles(DevFrame fr, uint32_t* __restrict__ hot)
+// caller), the first kHotTilesMax are kept in hot[0..].  The kernel runs BESIDE k_gen_rays, whose five waves per SIMD leave 32 of
+// a lane's 512 VGPRs and three of eight wave slots: one-wave workgroups of 10 VGPRs start anywhere at once (as 256 workgroups of
+// 1024 threads the kernel waited for gen_rays to thin out and the next gen_rays waited for it: +0.012 ms per frame).  Eight
+// pixels per thread.
+__global__ __launch_bounds__(64) void k_hot_tiles(DevFrame fr, uint32_t* __restrict__ hot)
 {
     NRC_RAISE_WAVE_PRIORITY(16);
     const uint32_t n = fr.w * fr.h;
-    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
+    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
         const uint32_t y = i / fr.w, lx = i - y * fr.w;
         const float u = (float)global_x(fr, lx) * fr.inv_gw, v = (float)y * fr.inv_gh;
         const float rng0 = random2(random2(u, v), random4(fr.random));      // init_random
@@ -1185,6 +1188,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             hot_n = min(hot_n, kHotTilesMax);
             const uint32_t hot[kHotTilesMax] = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
             if (d < kHotTilesMax) {
+                if (d == 0u && fr.hot_reset != nullptr && (threadIdx.x & 63u) == 0u) *fr.hot_reset = 0u;
                 if (d >= hot_n) return;
                 uint32_t t = 0;
 #pragma unroll
@@ -1221,12 +1225,23 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     CtxT<COUNT> c{sc, 0.0f, 0u};
     const uint32_t gx = global_x(fr, lx);
     const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
+    const float seed_uv = random2(u, v);      // the pixel's part of init_random's seed
+    if (fr.hot_next != nullptr) {             // the next frame's hot tiles (DevFrame::hot_next): is a pixel of this tile in a capped state then?
+        const uint32_t m = nrc_f2u(random2(seed_uv, random4(fr.random_next)) + 1.0f) & 0x007fffffu;
+        bool capped = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kFlightListMax; k++) capped |= (k < fr.flight_n) & (m == fr.flight_list[k]);
+        if (__ballot(inside & capped) != 0ull && (threadIdx.x & 63u) == 0u) {
+            const uint32_t k = atomicAdd(&fr.hot_next[kHotTilesMax], 1u);
+            if (k < kHotTilesMax) fr.hot_next[k] = __builtin_amdgcn_readfirstlane(((y >> 3) << 16) | (lx >> 3));
+        }
+    }
     // Two of three tiles of the bench view miss the medium.  Their waves are the tail of the launch (k_tile_order starts the
     // costliest tiles first): the tile's bit comes through the scalar cache, and the wave is gone before the occupancy table is
     // copied (there is no workgroup barrier in this kernel: load_occupancy_per_wave).  What is left of them is dispatch: ~1000
     // waves per microsecond start at the end of the launch (tools/loop_profile.py), and all they do costs 0.004 ms of 0.215.
     if (tile_mask_clear(fr, lx, y)) {
-        init_random(c, u, v, fr.random);
+        c.rng = random2(seed_uv, random4(fr.random));      // init_random
         if (!tile_has_capped_state(fr, inside, c.rng)) {
             if (inside) {
                 V3 ro, rd;
@@ -1252,7 +1267,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
     V3 ro, rd;
     camera_ray(cam, u, v, &ro, &rd);
-    init_random(c, u, v, fr.random);
+    c.rng = random2(seed_uv, random4(fr.random));      // init_random
     const bool enter = inside;
     V3 entry = ro, ex;
     {
@@ -1853,7 +1868,7 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 
 void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_hot_tiles, dim3(256), dim3(1024), 0, s, fr, hot);
+    hipLaunchKernelGGL(k_hot_tiles, dim3(4096), dim3(64), 0, s, fr, hot);
     NRC_HIP(hipGetLastError());
 }
 

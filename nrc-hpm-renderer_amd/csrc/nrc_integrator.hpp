@@ -60,11 +60,17 @@ struct DevFrame {
     // not by tiles it over-estimates
     uint32_t tile_cost_keep;
     // tiles k_gen_rays starts FIRST, whatever the order says: {kHotTilesMax entries (ty << 16 | tx), then their count}, written by
-    // k_hot_tiles for this frame's random numbers; nullptr: none.  A pixel in a capped RNG state (see flight_mode) in a tile the
+    // the previous frame's k_gen_rays (hot_next) or by k_hot_tiles for this frame's random numbers; nullptr: none.  A pixel in a capped RNG state (see flight_mode) in a tile the
     // mask rejects is one lane that walks for ~120 us; its wave would otherwise start among the empty tiles at the end of the
     // launch and end it that much later (one frame in four on the bench view).  Scheduling only: every tile is traced exactly once
     // with or without the list.
     const uint32_t* hot_tiles;
+    // k_gen_rays builds the NEXT frame's list itself: every wave tests its tile's pixels against the next frame's random numbers
+    // (random_next; one more hash per pixel, the pixel's own part of the seed is shared) and appends to hot_next; it also zeroes the
+    // count cell of the list after that one (hot_reset).  Three list buffers rotate; no extra launch, no event.  nullptr: off.
+    uint32_t* hot_next;
+    uint32_t* hot_reset;
+    float random_next[4];
 };
 constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front
 
