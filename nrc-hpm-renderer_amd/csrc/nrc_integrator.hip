@@ -451,6 +451,86 @@ __device__ __forceinline__ void pair_both(float x, float* lo, float* hi)
     *hi = nrc_u2f(r[1]);
 }
 
+// ---- the last walks: 32 lanes per walk ----------------------------------------------------------------------------------------
+// What ends a launch is a wave that still has one or two long walks when its neighbours are done (tools/loop_profile.py): in the
+// pair loop such a walk advances four collisions per round trip to memory.  When at most two walks are left and they still have a
+// long way to go, each gets HALF THE WAVE: the next 32 draws of its hash chain are made by all 32 lanes (the chain is the one serial
+// part; lane j keeps draw j + 1), the 32 free-flight logs, positions, look-ups and transmittance factors are one lane's work each,
+// and the running free-flight position and transmittance product are then replayed in the walk's own order with v_readlane -- bit
+// for bit the sequential walk, 32 collisions per memory round trip.
+// MEASURED AND SWITCHED OFF (round 3): bit-exact at the first attempt (every oracle comparison of tests/test_gpu_integrator.py), but the
+// walks it applies to are too few -- against a build that contains the code and never enters it, entering from 8 / 16 / 32 expected
+// collisions left gains 0.000 / 0.005 / 0.002 ms of 0.251 -- and its presence costs the whole kernel 0.038 ms (0.213 -> 0.251: 62 -> 162
+// SGPR spills and 8 bytes of scratch under the 96-VGPR cap).  -DNRC_WIDE_TAIL=1 builds it.
+#ifndef NRC_WIDE_TAIL
+#define NRC_WIDE_TAIL 0
+#endif
+#ifndef NRC_WIDE_MIN
+#define NRC_WIDE_MIN 8      // expected collisions left (free-flight lengths) from which a walk goes wide
+#endif
+// value of lane i of the lower half on the lower half's lanes, of lane 32 + i on the upper half's (i wave-uniform)
+__device__ __forceinline__ float half_bcast(float x, uint32_t i, bool upper)
+{
+    const float lo = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)i));
+    const float hi = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)(32u + i)));
+    return upper ? hi : lo;
+}
+// ratio walks in (R0, t0, T, tm, nn, st, dr), uniform over each half of the wave (`on`: the half has a walk); runs them to their end.
+// On exit T and rf (the last draw made) are the finished walks' results on every lane of their half.
+template <class C>
+__device__ __forceinline__ void ratio_wide(C& c, bool on, float R0, float t0, float tm, uint32_t nn, V3 st, V3 dr, float inv, float& T, float& rf)
+{
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 31u;
+    const bool upper = (lane & 32u) != 0u;
+    for (;;) {
+        if (__ballot(on) == 0ull) break;
+        // 32 draws of the chain; lane j keeps draw j + 1
+        float R = R0, my_r = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 32u; i++) {
+            R = random1(R);
+            my_r = (i == j) ? R : my_r;
+        }
+        const float l = logf2(f2{1.0f - my_r, 1.0f - my_r}).x;
+        // free-flight positions in the walk's order
+        float t = t0, my_t = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 32u; i++) {
+            t = nrc_fmaf_(-half_bcast(l, i, upper), inv, t);
+            my_t = (i == j) ? t : my_t;
+        }
+        // draw j + 1 is made unless 128 collisions are done; the walk ends on the first draw that is not made or lies beyond the segment
+        const bool made = nn + j + 1u <= 128u;
+        const bool stop = on & (!made | (my_t >= tm));
+        const unsigned long long sm = __ballot(stop);
+        const uint32_t sh = upper ? (uint32_t)(sm >> 32) : (uint32_t)sm;
+        const uint32_t K = !on ? 0u : (sh != 0u ? (uint32_t)__builtin_ctz(sh) : 32u);      // collisions 1..K lie inside the segment
+        const bool inseg = j < K;
+        const Addr2 ad = fetch2_addr(c, dr, st, my_t, my_t, inseg, false);
+        const Fetch2 fa = fetch2_load(c, ad);
+        const float f = nrc_fmaf_(-fetch2_density(c.sc, fa).x, inv, 1.0f);
+        c.count(inseg ? 1u : 0u);
+        // the last draw made (1-based): 32 when the chunk has no stop, K when the cap ended the walk, K + 1 when draw K + 1 lies beyond
+        // the segment; 0: none in this chunk (the cap was reached with the chunk before)
+        const uint32_t last = K == 32u ? 32u : (nn + K + 1u > 128u ? K : K + 1u);
+        const float r_sel = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & 32u) + (last == 0u ? 0u : last - 1u)) * 4u), (int)nrc_f2u(my_r)));
+        rf = (on & (last != 0u)) ? r_sel : rf;
+        // transmittance in the walk's order (a wave-uniform loop: the longer of the two walks' chunks)
+        const uint32_t kmax = max((uint32_t)__builtin_amdgcn_readlane((int)K, 0), (uint32_t)__builtin_amdgcn_readlane((int)K, 32));
+#pragma unroll 4
+        for (uint32_t i = 0; i < 32u; i++) {
+            if (i >= kmax) break;
+            const float fi = half_bcast(f, i, upper);
+            T = (i < K) ? T * fi : T;
+        }
+        // no stop in this chunk: the walk goes on behind draw 32
+        on &= K == 32u;
+        nn += 32u;
+        R0 = R;
+        t0 = t;
+    }
+}
+
 // the surviving walks of a ratio_track loop, two lanes per walk.  On entry: `alive` lanes have a located trip whose base state is
 // (bs, bt) = (chain value before its first draw, free-flight position before it), n collisions done.  On exit: tr / rng of the alive
 // lanes are the finished walks' results.
@@ -482,8 +562,28 @@ __device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool al
     bool act = (lane & 31u) < k;
     float rf = R0;
     for (;;) {
-        if (__ballot(act) == 0ull) break;
-        NRC_PROF_LIVE(1, __ballot(act) & 0xffffffffull);
+        const unsigned long long actm = __ballot(act);
+        if (actm == 0ull) break;
+        NRC_PROF_LIVE(1, actm & 0xffffffffull);
+#if NRC_WIDE_TAIL
+        // one or two walks left with a long way to go (at least eight more collisions expected): half the wave each (ratio_wide)
+        if (__popc((uint32_t)actm) <= 2 && __ballot(act & (tm - t0 >= (float)(NRC_WIDE_MIN) * inv)) != 0ull) {
+            const uint32_t ra = (uint32_t)__builtin_ctz((uint32_t)actm), rb = 31u - (uint32_t)__builtin_clz((uint32_t)actm);
+            auto pick = [&](float x) {
+                const float lo = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)ra));
+                const float hi = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)rb));
+                return is_b ? hi : lo;
+            };
+            float Tw = pick(T), rfw = pick(rf);
+            ratio_wide(c, !is_b | (rb != ra), pick(R0), pick(t0), pick(tm), nrc_f2u(pick(nrc_u2f(nn))), v3(pick(st.x), pick(st.y), pick(st.z)),
+                       v3(pick(dr.x), pick(dr.y), pick(dr.z)), inv, Tw, rfw);
+            const float Ta = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(Tw), 0)), Tb = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(Tw), 32));
+            const float ra_f = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(rfw), 0)), rb_f = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(rfw), 32));
+            if ((lane & 31u) == ra) { T = Ta; rf = ra_f; }
+            if (rb != ra && (lane & 31u) == rb) { T = Tb; rf = rb_f; }
+            break;
+        }
+#endif
         const float R1 = random1(R0), R2 = random1(R1), R3 = random1(R2), R4 = random1(R3);
         const f2 l = logf2(f2{1.0f - (is_b ? R3 : R1), 1.0f - (is_b ? R4 : R2)});
         float l1, l2, l3, l4;
