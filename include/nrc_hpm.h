@@ -244,7 +244,7 @@ int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
  * wait for each other, and do not add up; total = latency of the frame, which exceeds the frame interval. */
 float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
 /* the same stage times averaged over every frame rendered since the last reset (HIP events on the renderer's streams);
- * *frames = number of frames covered */
+ * *frames = number of frames covered.  avg_ms == NULL with reset != 0 only forgets the frames so far, without reading an event */
 int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frames, int reset);
 /* NrcHpmRenderer::Destroy */
 int nrc_renderer_destroy(nrc_renderer_t* r);

@@ -490,6 +490,10 @@ class NrcHpmRenderer:
         d["frames"] = n.value
         return d
 
+    def ResetStageStats(self):
+        """forget the frames rendered so far without reading their events (StageStats(reset=True) reads every one of them first)"""
+        _check(self.L.nrc_renderer_stage_stats(self.h, None, None, C.c_int(1)))
+
     def GetImage(self, stream=None):
         """RGBA32F framebuffer as a torch CUDA tensor view [height, width, 4].  The stream given at construction (default) or
         `stream` (a torch stream / raw handle of the consumer) is ordered behind the frame's compositing."""

@@ -1127,6 +1127,10 @@ public:
     {
         const size_t n = ev_used_;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (avg8 == nullptr) {      // reset only: no event is read (a caller in front of a timed region must not keep the GPU waiting)
+            if (reset) { ev_used_ = 0; timed_ = false; }
+            return (uint32_t)n;
+        }
         if (n > 0) sync();
         for (size_t f = 0; f < n; f++) {
             float st[8];
