@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace nrc {
 
@@ -1004,6 +1005,9 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 #endif
 #ifndef NRC_GEN128_THREADS
 #define NRC_GEN128_THREADS 512
+#endif
+#ifndef NRC_GEN128_WG4_PER_CU
+#define NRC_GEN128_WG4_PER_CU 2      // persistent 4-wave workgroups per CU of the renderer-mode 128-wide inference launch
 #endif
 // ENC80: the input is the raw 5-float query and the Frequency(12) + OneBlob(4) encoding is computed here, k-step by k-step, as
 // k_infer does (no k_encode pass, no 160 B/sample feature buffer); feat is unused, raw_in required, the image is in fmap80 order.
@@ -1990,21 +1994,35 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
             // layer at a time keep the kernel at 134-154 VGPRs without scratch (two tiles per wave spilled 27 VGPRs): a workgroup
             // fits on a CU beside two gen_rays waves per SIMD.  The staged layers come out of the L2 (the 250 KB image is resident
             // there): 1 KB per sample instead of 0.5 KB, still far below what per-tile fragment fetches cost (7.8 KB).
+            // Renderer inference (skip_in: the launch runs BESIDE gen_rays, whose five waves per SIMD leave room for one 168-VGPR wave
+            // per SIMD only after two of them have retired) uses 4-wave workgroups -- one wave per SIMD instead of two: configs[4]'s frame
+            // 0.456 -> 0.439 ms -- although they are 12 % slower on a dense launch (0.54 -> 0.61 ms: half the samples per staged
+            // layer), which keeps the 8-wave form.
             const size_t lds = 2 * 32 * 1024;
-            constexpr int T128 = NRC_GEN128_THREADS;
-            if (!attr_infer_set_) {      // per instance = per device: the attribute belongs to the device's code object
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, false, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, true, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, false, 1, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_infer_set_ = true;
-            }
-            blocks = ceil_div(ceil_div(n, 32), T128 / 64);
-            if (enc80) launch(k_infer_gen<128, T128, false, 1, true>, T128, lds, 2);
-            else if (hash_) launch(k_infer_gen<128, T128, true, 1>, T128, lds, 2);
-            else launch(k_infer_gen<128, T128, false, 1>, T128, lds, 2);
+            auto launch128 = [&](auto threads_c) {
+                constexpr int T128 = decltype(threads_c)::value;
+                bool& attr_set = T128 == 256 ? attr_infer4_set_ : attr_infer_set_;
+                if (!attr_set) {      // per instance = per device: the attribute belongs to the device's code object
+                    NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, false, 1>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, true, 1>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer_gen<128, T128, false, 1, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr_set = true;
+                }
+                blocks = ceil_div(ceil_div(n, 32), T128 / 64);
+                constexpr uint32_t per_cu = T128 == 256 ? NRC_GEN128_WG4_PER_CU : 2;
+                if (enc80) launch(k_infer_gen<128, T128, false, 1, true>, T128, lds, per_cu);
+                else if (hash_) launch(k_infer_gen<128, T128, true, 1>, T128, lds, per_cu);
+                else launch(k_infer_gen<128, T128, false, 1>, T128, lds, per_cu);
+            };
+#ifdef NRC_GEN128_THREADS_FORCED
+            launch128(std::integral_constant<int, NRC_GEN128_THREADS>{});
+#else
+            if (skip_in != nullptr) launch128(std::integral_constant<int, 256>{});
+            else launch128(std::integral_constant<int, 512>{});
+#endif
         }
         NRC_HIP(hipGetLastError());
         return;

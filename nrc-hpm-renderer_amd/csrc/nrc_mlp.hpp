@@ -56,7 +56,7 @@ public:
 private:
     int num_cus();
     int num_cus_ = 0;
-    bool attr_infer_set_ = false, attr_train_set_ = false;     // hipFuncSetAttribute done on this instance's device
+    bool attr_infer_set_ = false, attr_infer4_set_ = false, attr_train_set_ = false;     // hipFuncSetAttribute done on this instance's device
     void ensure_train_workspace(uint32_t n);
     void ensure_features(uint32_t n, int slot);
     void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero);
