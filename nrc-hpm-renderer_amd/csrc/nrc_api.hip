@@ -902,13 +902,13 @@ public:
         else draw_random(frame_.random);
         if (blend_) blend_index_++;
         // Frame graph on four streams, pipelined across frames (no host sync anywhere):
-        //   A: [wait composite(N-4), train rays(N-4)] gen_rays(N)
+        //   A: [wait composite(N-6), train rays(N-6)] gen_rays(N)
         //   D: [wait gen_rays(N), train(N-2)] train-ray generation(N)
         //   B: [wait train rays(N)] backward(N) -> (all-reduce) -> [wait inference(N)] optimizer(N)
         //   C: [wait gen_rays(N), train(N-1)] inference(N) -> composite(N)
         // so frame N's train rays, training and inference all overlap frame N+1's gen_rays (the MFMA kernels and the short
         // latency-bound kernels run beside the VALU-bound integrator); inference(N+1) still sees the weights after frame N's
-        // training (quirk Q13 ordering).  gen_rays' outputs exist in four sets (the chain gen_rays -> train rays -> training
+        // training (quirk Q13 ordering).  gen_rays' outputs exist in six sets (the chain gen_rays -> train rays -> training
         // -> next frame's inference -> compositing spans almost three frame times on one GPU, and the gradient all-reduce of a
         // multi-GPU run sits on it too), the train rays double-buffered.
         // events: 0 frame start, 1 gen_rays done, 2 train rays done (D), 3 inference done, 4 composite done, 5 training done (B)
@@ -1285,7 +1285,7 @@ private:
     size_t ring_entries_ = 0;
     void *d_primary_ = nullptr, *d_info_ = nullptr, *d_origin_ = nullptr, *d_dir_ = nullptr, *d_out_ = nullptr;
 #ifndef NRC_GEN_SETS
-#define NRC_GEN_SETS 4
+#define NRC_GEN_SETS 6      // 4 -> 6: the 6x64 frame 0.2713 -> 0.2682 ms, the HashGrid frame 0.802 -> 0.758 ms (its chain is 3.4 ms long); 8 adds nothing
 #endif
     static constexpr int kGenSets = NRC_GEN_SETS;
     void *d_info2_[kGenSets] = {}, *d_origin2_[kGenSets] = {}, *d_dir2_[kGenSets] = {};
