@@ -1357,6 +1357,9 @@ public:
         dev_alloc(&d_tile_mask_, (size_t)tile_mask_words(w, h) * 4, "d_tile_mask_");
         dev_alloc(&d_flight_bits_, (size_t)kFlightStates / 8 + 8, "d_flight_bits_");
         dev_alloc(&d_flight_sel_, (1 + kFlightListMax) * 4, "d_flight_sel_");
+        dev_alloc(&d_hot_, 64, "d_hot_");
+        NRC_HIP(hipMemset(d_hot_, 0, 64));
+        hot_promote_ = getenv("NRC_NO_HOT_TILES") == nullptr;
         NRC_HIP(hipEventCreate(&ev_[0])); NRC_HIP(hipEventCreate(&ev_[1]));
         nrc_cam_ = cam;
         empty_skip_ = getenv("NRC_NO_EMPTY_SKIP") == nullptr;
@@ -1377,6 +1380,7 @@ public:
         if (d_tile_mask_) dev_free(d_tile_mask_);
         if (d_flight_bits_) dev_free(d_flight_bits_);
         if (d_flight_sel_) dev_free(d_flight_sel_);
+        if (d_hot_) dev_free(d_hot_);
         if (d_tile_cost_) dev_free(d_tile_cost_);
         if (d_tile_order_) dev_free(d_tile_order_);
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -1402,6 +1406,15 @@ public:
         frame_.tile_cost = sample_cost ? (uint32_t*)d_tile_cost_ : nullptr;
         frame_.tile_cost_keep = order_fresh_ > 0 ? 0u : 4u;      // see Renderer::render
         if (sample_cost && order_fresh_ > 0) order_fresh_--;
+        // hot tiles as in Renderer::render, computed in front of the launch (two tiny launches beside a 2.5 ms frame): a pixel in a
+        // capped RNG state inside an empty tile otherwise starts its 32-vertex walk at the end of the launch
+        frame_.hot_tiles = nullptr;
+        frame_.hot_next = frame_.hot_reset = nullptr;
+        if (hot_promote_ && frame_.tile_mask != nullptr && frame_.flight_mode == 1u && frame_.flight_n > 0) {
+            NRC_HIP(hipMemsetAsync((uint32_t*)d_hot_ + kHotTilesMax, 0, 4, stream_));
+            launch_hot_tiles(frame_, (uint32_t*)d_hot_, stream_);
+            frame_.hot_tiles = (const uint32_t*)d_hot_;
+        }
         NRC_HIP(hipEventRecord(ev_[0], stream_));
         launch_mc_render(scene_.d, cam_, frame_, path_length_, blend_factor, (float*)d_out_, (float*)d_info_,
                          count_fetches_ ? (unsigned long long*)d_fetch_ : nullptr, stream_);
@@ -1460,6 +1473,8 @@ private:
     SceneDev scene_;
     void *d_out_ = nullptr, *d_info_ = nullptr, *d_fetch_ = nullptr, *d_tile_mask_ = nullptr;
     void *d_flight_bits_ = nullptr, *d_flight_sel_ = nullptr;
+    void* d_hot_ = nullptr;      // hot-tile list (DevFrame::hot_tiles), rebuilt in front of every launch
+    bool hot_promote_ = true;
     nrc_camera nrc_cam_{};
     bool mask_dirty_ = true, empty_skip_ = true;
     hipEvent_t ev_[2] = {nullptr, nullptr};

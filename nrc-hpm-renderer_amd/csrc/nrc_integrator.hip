@@ -1239,6 +1239,51 @@ __global__ __launch_bounds__(64) void k_hot_tiles(DevFrame fr, uint32_t* __restr
     }
 }
 
+// The tile of a camera kernel's wave.  With a hot-tile list (DevFrame::hot_tiles) the launch has kHotTilesMax waves in front of the
+// ordered ones: wave k traces hot tile k, and the wave the order gives that tile to leaves.  false: the wave has nothing to do.
+__device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* lx_, uint32_t* y_, uint32_t* slot_, bool* inside_, bool* hot_wave_)
+{
+    uint32_t lx = 0, y = 0, slot = 0;
+    bool inside;
+    bool hot_wave = false;
+    {
+        uint32_t d = __builtin_amdgcn_readfirstlane(blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+        if (fr.hot_tiles != nullptr) {
+            // the launch has kHotTilesMax waves in front of the ordered ones: wave k traces hot tile k, and the wave the order
+            // gives that tile to leaves
+            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+            uint32_t hot_n;
+            u32x8 hv;
+            asm volatile("s_load_dword %0, %2, 0x20\n\ts_load_dwordx8 %1, %2, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hot_n), "=&s"(hv) : "s"(fr.hot_tiles) : "memory");
+            hot_n = min(hot_n, kHotTilesMax);
+            const uint32_t hot[kHotTilesMax] = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
+            if (d < kHotTilesMax) {
+                if (d == 0u && fr.hot_reset != nullptr && (threadIdx.x & 63u) == 0u) *fr.hot_reset = 0u;
+                if (d >= hot_n) return false;
+                uint32_t t = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kHotTilesMax; k++) t = d == k ? hot[k] : t;
+                const uint32_t lane = threadIdx.x & 63u;
+                lx = (t & 0xffffu) * 8u + (lane & 7u);
+                y = (t >> 16) * 8u + (lane >> 3);
+                inside = lx < fr.w && y < fr.h;
+                hot_wave = true;
+            } else {
+                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot);
+                const uint32_t t = __builtin_amdgcn_readfirstlane(((y >> 3) << 16) | (lx >> 3));
+                bool is_hot = false;
+#pragma unroll
+                for (uint32_t k = 0; k < kHotTilesMax; k++) is_hot |= (k < hot_n) & (t == hot[k]);
+                if (is_hot) return false;
+            }
+        } else {
+            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot);
+        }
+    }
+    *lx_ = lx; *y_ = y; *slot_ = slot; *inside_ = inside; *hot_wave_ = hot_wave;
+    return true;
+}
+
 // what a tile cost in this launch, kept as a decaying maximum over the sampled launches (DevFrame::tile_cost_keep)
 __device__ __forceinline__ void store_tile_cost(const DevFrame& fr, uint32_t slot, unsigned long long cycles)
 {
@@ -1274,42 +1319,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     uint32_t lx = 0, y = 0, slot = 0;
-    bool inside;
-    bool hot_wave = false;
-    {
-        uint32_t d = __builtin_amdgcn_readfirstlane(blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-        if (fr.hot_tiles != nullptr) {
-            // the launch has kHotTilesMax waves in front of the ordered ones: wave k traces hot tile k, and the wave the order
-            // gives that tile to leaves
-            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-            uint32_t hot_n;
-            u32x8 hv;
-            asm volatile("s_load_dword %0, %2, 0x20\n\ts_load_dwordx8 %1, %2, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hot_n), "=&s"(hv) : "s"(fr.hot_tiles) : "memory");
-            hot_n = min(hot_n, kHotTilesMax);
-            const uint32_t hot[kHotTilesMax] = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
-            if (d < kHotTilesMax) {
-                if (d == 0u && fr.hot_reset != nullptr && (threadIdx.x & 63u) == 0u) *fr.hot_reset = 0u;
-                if (d >= hot_n) return;
-                uint32_t t = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < kHotTilesMax; k++) t = d == k ? hot[k] : t;
-                const uint32_t lane = threadIdx.x & 63u;
-                lx = (t & 0xffffu) * 8u + (lane & 7u);
-                y = (t >> 16) * 8u + (lane >> 3);
-                inside = lx < fr.w && y < fr.h;
-                hot_wave = true;
-            } else {
-                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot);
-                const uint32_t t = __builtin_amdgcn_readfirstlane(((y >> 3) << 16) | (lx >> 3));
-                bool is_hot = false;
-#pragma unroll
-                for (uint32_t k = 0; k < kHotTilesMax; k++) is_hot |= (k < hot_n) & (t == hot[k]);
-                if (is_hot) return;
-            }
-        } else {
-            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot);
-        }
-    }
+    bool inside, hot_wave;
+    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave)) return;
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
@@ -1487,8 +1498,9 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
-    uint32_t lx = 0, y = 0, slot;
-    const bool inside = pixel_of_wave_tile(fr, &lx, &y, &slot);
+    uint32_t lx = 0, y = 0, slot = 0;
+    bool inside, hot_wave;
+    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave)) return;
     CtxT<COUNT> c{sc, 0.0f, 0u};
     c.occ = occ;
     // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
@@ -1533,7 +1545,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
         if (info) info[pix] = a;
     }
     if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
-    if (fr.tile_cost != nullptr && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
+    if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
         store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4);
 }
 
@@ -2006,7 +2018,9 @@ void launch_flight_select(const float* table, float lambda, uint32_t* count_and_
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s)
 {
-    hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, wave_tile_grid(fr.w, fr.h), dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,
+    dim3 grid = wave_tile_grid(fr.w, fr.h);
+    if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,
                        cam, fr, path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
     NRC_HIP(hipGetLastError());
 }
