@@ -1216,10 +1216,11 @@ __global__ __launch_bounds__(256) void k_flight_select(const float* __restrict__
 }
 
 // the tiles with a pixel in a capped RNG state (list mode), for DevFrame::hot_tiles: hot[kHotTilesMax] counts them (zeroed by the
-// caller), the first kHotTilesMax are kept in hot[0..].  The kernel runs BESIDE k_gen_rays, whose five waves per SIMD leave 32 of
-// a lane's 512 VGPRs and three of eight wave slots: one-wave workgroups of 10 VGPRs start anywhere at once (as 256 workgroups of
-// 1024 threads the kernel waited for gen_rays to thin out and the next gen_rays waited for it: +0.012 ms per frame).  Eight
-// pixels per thread.
+// caller), the first kHotTilesMax are kept in hot[0..].  Used in front of a camera kernel whose list is not there yet -- k_gen_rays
+// builds the next frame's list itself (DevFrame::hot_next); this kernel serves its first frame, pinned random numbers and
+// k_mc_render.  One-wave workgroups of 10 VGPRs: they find room beside the camera kernels of other renderers, whose five waves
+// per SIMD leave 32 of a lane's 512 VGPRs (1024-thread workgroups waited for such a kernel to thin out: 99 us instead of 3).
+// Eight pixels per thread.
 __global__ __launch_bounds__(64) void k_hot_tiles(DevFrame fr, uint32_t* __restrict__ hot)
 {
     NRC_RAISE_WAVE_PRIORITY(16);
