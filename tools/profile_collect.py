@@ -54,6 +54,8 @@ def main():
     put(first(src + "/prof_c5/**/*kernel_stats.csv"), "c5_kernel_stats.csv")
     put(first(src + "/prof_mlp/**/*kernel_stats.csv"), "mlp_kernel_stats.csv")
     put(first(src + "/prof_mlp128/**/*kernel_stats.csv"), "mlp128_kernel_stats.csv")
+    put(os.path.join(src, "mlp_trace_tail.txt"), "mlp_kernel_trace_tail.txt")
+    put(os.path.join(src, "mlp128_trace_tail.txt"), "mlp128_kernel_trace_tail.txt")
     put(first(src + "/pmc_fetch/**/*counter_collection.csv"), "pmc_fetch_size.csv")
     put(first(src + "/pmc_write/**/*counter_collection.csv"), "pmc_write_size.csv")
     if all(os.path.isdir(os.path.join(src, d)) for d in ("pmc_fetch", "pmc_write", "pmc_tcc")):

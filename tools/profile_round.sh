@@ -20,11 +20,14 @@ fi
 if has mlp; then
   echo "== mlp kernel trace (dense k_infer alone)"
   (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_mlp" -o mlp -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 20) > "$OUT/prof_mlp.log" 2>&1 || exit 1
+  python3 tools/trace_tail.py "$(find "$OUT/prof_mlp" -name "*kernel_trace.csv" | head -1)" k_infer 100 > "$OUT/mlp_trace_tail.txt" 2>&1
+  export NRC_BENCH_MLP_WARM=5      # (the counter passes serialise every dispatch: no clock ramp to wait out, and 400 more dispatches to count)
   echo "== mlp MFMA counters"
   (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
       -d "$OUT/pmc_mlp_mfma" -o mlp -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 4) > "$OUT/pmc_mlp_mfma.log" 2>&1 || exit 1
   (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES SQ_VALU_MFMA_COEXEC_CYCLES \
       -d "$OUT/pmc_mlp_sq" -o mlp -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 4) > "$OUT/pmc_mlp_sq.log" 2>&1 || exit 1
+  unset NRC_BENCH_MLP_WARM
 fi
 if has bench; then
   echo "== bench (plain)" && timeout -k 10 400 "$PY" bench.py --steps 100 --warmup 10 > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
@@ -44,6 +47,7 @@ if has c5; then
   (cd /tmp && timeout -k 10 400 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_c5" -o c5 -- "$PY" "$REPO/bench.py" --config c5 --steps 12 --warmup 2 --no-cpu-baseline) > "$OUT/prof_c5.log" 2>&1 || exit 1
   echo "== dense 8x128 inference kernel trace"
   (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_mlp128" -o mlp128 -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 20 128 8) > "$OUT/prof_mlp128.log" 2>&1 || exit 1
+  python3 tools/trace_tail.py "$(find "$OUT/prof_mlp128" -name "*kernel_trace.csv" | head -1)" k_infer_gen 100 > "$OUT/mlp128_trace_tail.txt" 2>&1
 fi
 if has pin; then
   echo "== exr pin calibration" && timeout -k 10 600 "$PY" tests/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
