@@ -793,6 +793,7 @@ public:
         if (w == 0 || h == 0) fail("render size must be non-zero");
         if (((size_t)w * h) % 16 != 0) fail("NRC requires inferCount to be a multiple of 16");   // before anything is allocated
         frame_ = make_frame(w, h, tile);
+        nq_ = query_count(w, h);      // the inference buffers hold whole 8x8 pixel tiles (tile-major, query_index)
         scene_.upload(scene);
         calc_train_subset(cfg.train_batch_count * cache.train_batch_size());
         tg_.spp = cfg.train_spp;
@@ -804,13 +805,13 @@ public:
         // compositing (stream C) read set N % kGenSets while gen_rays (stream A) is already one or two frames ahead
         for (int k = 0; k < kGenSets; k++) {
             alloc(&d_primary2_[k], px * 16); alloc(&d_info2_[k], px * 4); alloc(&d_origin2_[k], px * 16);
-            alloc(&d_dir2_[k], px * 16); alloc(&d_infer_in2_[k], px * 20);
+            alloc(&d_dir2_[k], px * 16); alloc(&d_infer_in2_[k], (size_t)nq_ * 20);
         }
         d_primary_ = d_primary2_[0]; d_info_ = d_info2_[0]; d_origin_ = d_origin2_[0]; d_dir_ = d_dir2_[0];
         d_infer_in_ = d_infer_in2_[0];
         for (auto& e : ev_train_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : ev_comp_done_) NRC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        alloc(&d_out_, px * 16); alloc(&d_infer_out_, px * 12);
+        alloc(&d_out_, px * 16); alloc(&d_infer_out_, (size_t)nq_ * 12);
         // train rays are double-buffered as well: frame N+1's train-ray generation (stream D) overlaps frame N's backward pass
         for (int k = 0; k < 2; k++) { alloc(&d_train_in2_[k], T * 20); alloc(&d_train_target2_[k], T * 12); }
         d_train_in_ = d_train_in2_[0]; d_train_target_ = d_train_target2_[0];
@@ -862,7 +863,7 @@ public:
         std::vector<uint32_t> ring(2 + ring_entries_ * 6, 0);
         for (size_t r = 0; r < ring_entries_; r++) { float one = 1.0f; std::memcpy(&ring[2 + 6 * r + 5], &one, 4); }
         NRC_HIP(hipMemcpy(d_ring_, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
-        cache_.init((uint32_t)px, (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_, (float*)d_train_target_, s);
+        cache_.init(nq_, (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_, (float*)d_train_target_, s);
     }
 
     ~Renderer()
@@ -1001,7 +1002,7 @@ public:
         // (re)bind this renderer's I/O buffers: several renderers may share one cache (Reference::CompareNrc evaluates the
         // same NRC from another camera, src/Reference.cpp:71-107)
         cache_.acquire(this, Cs, B);
-        cache_.bind((uint32_t)((size_t)w_ * h_), (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
+        cache_.bind(nq_, (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
                     (float*)d_train_target_);
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
         cache_.infer_all(nullptr, Cs, !dense_infer_);
@@ -1196,6 +1197,7 @@ public:
             void* const* sets[5] = {d_primary2_, d_info2_, d_origin2_, d_dir2_, d_infer_in2_};
             const size_t sizes[5] = {px * 16, px * 4, px * 16, px * 16, px * 20};
             if (bytes) *bytes = sizes[which % 16];
+            if (which % 16 == 4) return public_queries(sets[4][k], 5);
             return sets[which % 16][k];
         }
         switch (which) {
@@ -1203,8 +1205,8 @@ public:
         case 1: p = d_info_; b = px * 4; break;
         case 2: p = d_origin_; b = px * 16; break;
         case 3: p = d_dir_; b = px * 16; break;
-        case 4: p = d_infer_in_; b = px * 20; break;
-        case 5: p = d_infer_out_; b = px * 12; break;
+        case 4: p = public_queries(d_infer_in_, 5); b = px * 20; break;
+        case 5: p = public_queries(d_infer_out_, 3); b = px * 12; break;
         case 6: p = d_train_in_; b = T * 20; break;
         case 7: p = d_train_target_; b = T * 12; break;
         case 8: p = d_ring_; b = 8 + ring_entries_ * 24; break;
@@ -1212,6 +1214,15 @@ public:
         }
         if (bytes) *bytes = b;
         return p;
+    }
+    // the reference's x * H + y order of a query / radiance buffer (a copy: the renderer itself keeps them tile-major)
+    void* public_queries(const void* tiled, uint32_t floats_per_query)
+    {
+        void*& dst = floats_per_query == 5 ? d_pub_in_ : d_pub_out_;
+        if (!dst) alloc(&dst, (size_t)w_ * h_ * floats_per_query * 4);
+        launch_query_layout(frame_, floats_per_query, (const float*)tiled, (float*)dst, stream_);
+        NRC_HIP(hipStreamSynchronize(stream_));
+        return dst;
     }
     // The compositing kernel runs on the renderer's own stream C.  Handing out the framebuffer orders the caller's stream
     // behind the latest compositing pass (device-side wait, no host block), so whatever the caller enqueues next on the stream
@@ -1290,6 +1301,8 @@ private:
     static constexpr int kGenSets = NRC_GEN_SETS;
     void *d_info2_[kGenSets] = {}, *d_origin2_[kGenSets] = {}, *d_dir2_[kGenSets] = {};
     void *d_primary2_[kGenSets] = {}, *d_infer_in2_[kGenSets] = {};
+    uint32_t nq_ = 0;                                   // queries per frame in the renderer's tile-major order (query_count)
+    void *d_pub_in_ = nullptr, *d_pub_out_ = nullptr;   // x * H + y copies of the query / radiance buffers, made when asked for
     hipEvent_t ev_train_done_[2] = {nullptr, nullptr}, ev_comp_done_[kGenSets] = {};
     uint64_t frame_index_ = 0;
     void *d_infer_in_ = nullptr, *d_infer_out_ = nullptr, *d_train_in_ = nullptr, *d_train_target_ = nullptr;

@@ -1121,6 +1121,17 @@ __host__ __device__ inline uint32_t camera_row_blocks(uint32_t w)
     return blocks_x | 1u;
 }
 // *slot: the wave's default slot (index into DevFrame::tile_cost)
+// The renderer's query / radiance buffers are tile-major INSIDE the renderer: query ((ty * tiles_x + tx) * 64 + (y & 7) * 8 + (x & 7)) is
+// pixel (x, y) of the camera kernels' 8x8 tile (tx, ty) -- a gen_rays wave stores its 64 queries as one 1 280-byte run, and the 32
+// queries of an inference tile are four rows of eight neighbouring pixels, so the compositing epilogue of the inference kernel reads
+// and writes whole 128-byte row segments of the images.  Tiles beyond the image's edge keep all-zero queries (never computed).  The
+// reference's x * H + y order (nrc/prep_infer_rays.comp:31) is what nrc_renderer_buffer hands out (k_query_layout), and what the
+// cache's own API speaks.
+__host__ __device__ inline size_t query_index(uint32_t w, uint32_t lx, uint32_t y)
+{
+    const uint32_t tiles_x = (w + 7u) >> 3;
+    return ((size_t)((y >> 3) * tiles_x + (lx >> 3)) << 6) + ((y & 7u) << 3) + (lx & 7u);
+}
 // launch slot (workgroup * 4 + wave) -> the wave's pixel
 __device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_t d, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
 {
@@ -1362,7 +1373,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 const size_t pix = (size_t)y * fr.w + lx;
                 primary[pix] = make_float4(e.x, e.y, e.z, 1.0f);
                 info[pix] = 0.0f;
-                float* qo = infer_in + ((size_t)lx * fr.h + y) * 5u;
+                float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
                 for (int k = 0; k < 5; k++) qo[k] = 0.0f;
             }
@@ -1469,7 +1480,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         info[pix] = did_scatter ? 1.0f : 0.0f;
         // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
         // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
-        float* qo = infer_in + ((size_t)lx * fr.h + y) * 5u;
+        float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
         for (int k = 0; k < 5; k++) qo[k] = q[k];
     }
@@ -1825,7 +1836,7 @@ __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nr
     NRC_RAISE_WAVE_PRIORITY(2);
     uint32_t lx, y;
     if (!pixel_of_thread(fr, &lx, &y)) return;
-    const size_t pix = (size_t)y * fr.w + lx, lin = (size_t)lx * fr.h + y;
+    const size_t pix = (size_t)y * fr.w + lx, lin = query_index(fr.w, lx, y);
     const float4 p = primary[pix];
     float cr = p.x, cg = p.y, cb = p.z;
     if (show_nrc == 1u && info[pix] == 1.0f) {
@@ -1837,6 +1848,15 @@ __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nr
     const float ib = 1.0f - blend_factor;
     out_rgba[pix] = make_float4(blend_factor * cr + ib * prev.x, blend_factor * cg + ib * prev.y,
                                 blend_factor * cb + ib * prev.z, blend_factor * 1.0f + ib * prev.w);
+}
+
+// tile-major (query_index) -> the reference's x * H + y order, C floats per query: what nrc_renderer_buffer hands out
+__global__ __launch_bounds__(256) void k_query_layout(DevFrame fr, uint32_t C, const float* __restrict__ tiled, float* __restrict__ linear)
+{
+    uint32_t lx, y;
+    if (!pixel_of_thread(fr, &lx, &y)) return;
+    const size_t q = query_index(fr.w, lx, y), lin = (size_t)lx * fr.h + y;
+    for (uint32_t c = 0; c < C; c++) linear[lin * C + c] = tiled[q * C + c];
 }
 
 // ------------------------------------------------------------------------------------------------ ref/cmp1, norm, cmp2
@@ -2048,6 +2068,13 @@ void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor,
                        (const float4*)primary, info, infer_out, (float4*)out_rgba);
     NRC_HIP(hipGetLastError());
 }
+
+void launch_query_layout(const DevFrame& fr, uint32_t floats_per_query, const float* tiled, float* linear, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_query_layout, pixel_grid(fr.w, fr.h), dim3(256), 0, s, fr, floats_per_query, tiled, linear);
+    NRC_HIP(hipGetLastError());
+}
+uint32_t query_count(uint32_t w, uint32_t h) { return ceil_div(w, 8) * ceil_div(h, 8) * 64u; }
 
 void launch_compare(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, float* d_result5,
                     hipStream_t s)

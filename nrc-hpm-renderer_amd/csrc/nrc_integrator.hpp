@@ -92,6 +92,9 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 // {lo.xyz, hi.xyz} that together cover every non-empty voxel with a margin of one voxel.  mask: ceil(tiles/32) + 1 words, zeroed.
 // finds the pixels of the frame whose RNG state is in fr.flight_list (flight_mode 1) and appends their tiles to hot (count zeroed by the caller: hot[kHotTilesMax])
 void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s);
+// tile-major query order of the renderer's inference buffers (see query_index in nrc_integrator.hip) -> x * H + y
+void launch_query_layout(const DevFrame& fr, uint32_t floats_per_query, const float* tiled, float* linear, hipStream_t s);
+uint32_t query_count(uint32_t w, uint32_t h);      // queries in tile-major order: whole 8x8 tiles
 void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s);
 uint32_t tile_mask_words(uint32_t w, uint32_t h);
 // table[m] = optical distance covered by the 128 free flights a delta walk draws from RNG state m when it rejects every collision
