@@ -269,15 +269,19 @@ public:
 
     // skip_zero: device-side replacement of the reference's per-batch host filter (src/NrcHpmRenderer.cu:332-337,
     // prep_infer_rays.comp:43-45): the renderer zero-fills the query of every pixel that did not scatter
-    void infer_all(const uint32_t* filter, hipStream_t s, bool skip_zero = false)          // Inference, :134-145
+    // composite: the renderer's compositing pass as the epilogue of the inference launches (fused 6x64 model only, can_composite)
+    void infer_all(const uint32_t* filter, hipStream_t s, bool skip_zero = false, const CompositeArgs* composite = nullptr)          // Inference, :134-145
     {
         if (!initialised_) throw std::logic_error("SkyRenderer ERROR: InferAndTrain before Init");
         for (size_t i = 0; i < infer_batches_.size(); i++) {
             if (filter != nullptr && filter[i] == 0) continue;
             const auto& b = infer_batches_[i];
-            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, s, skip_zero);
+            CompositeArgs ca;
+            if (composite) { ca = *composite; ca.q_base = b.first; }
+            mlp_->infer(d_infer_in_ + (size_t)b.first * 5, d_infer_out_ + (size_t)b.first * 3, b.second, true, s, skip_zero, composite ? &ca : nullptr);
         }
     }
+    bool can_composite() const { return mlp_->can_composite(); }
 
     // Train, :147-156, on stream `st` (backward, gradient hook, optimizer).  When `st` is not the stream inference runs on,
     // the optimizer additionally waits for ev_infer_done -- the inference pass BEFORE the latest one: the fp16 inference image
@@ -826,7 +830,14 @@ public:
         alloc(&d_flight_sel_, (1 + kFlightListMax) * 4);
         for (auto& h : d_hot_) { alloc(&h, 64); NRC_HIP(hipMemset(h, 0, 64)); }
         hot_promote_ = getenv("NRC_NO_HOT_TILES") == nullptr;
-        hot_ahead_ = getenv("NRC_HOT_TILES_INLINE") == nullptr;      // diagnostic: always compute the list in front of gen_rays
+        hot_ahead_ = getenv("NRC_HOT_TILES_INLINE") == nullptr;
+        // Compositing as the epilogue of the inference launch: built, bit-identical to k_composite
+        // (test_fused_composite_epilogue_equals_the_separate_pass), and OFF -- frame 0.2702-0.2725 -> 0.291-0.294 ms.  The epilogue's
+        // loads (primary colour, scatter flag, framebuffer) are a dependent round trip to memory per 32-sample tile in a persistent
+        // kernel that runs two waves per SIMD, dead tiles included, and 124 instead of 117 VGPRs make the workgroups wait longer
+        // for room beside gen_rays: the inference stage went from 0.31 to 0.73 ms and pulled the training chain with it.
+        // NRC_FUSED_COMPOSITE=1 switches it on.
+        fuse_composite_ = getenv("NRC_FUSED_COMPOSITE") != nullptr;      // diagnostic: always compute the list in front of gen_rays
         // costliest-first launch order of gen_rays' tiles: costs of frame N order frame N + 2 (sorted on stream D beside frame N + 1)
         n_slots_ = camera_slots(w, h);
         alloc(&d_tile_cost_, (size_t)n_slots_ * 4);
@@ -1004,8 +1015,19 @@ public:
         cache_.acquire(this, Cs, B);
         cache_.bind(nq_, (float*)d_infer_in_, (float*)d_infer_out_, (float*)d_train_in_,
                     (float*)d_train_target_);
+        // Compositing (nrc/render.comp) CAN be the epilogue of the inference launch for the fused 6x64 model (fuse_composite_, off by
+        // default: slower, see the constructor): the queries are in tile-major order, so an inference tile's 32 pixels are four
+        // 128-byte row segments of the images.  The generic models always use k_composite.  (The framebuffer is ONE image that compositing
+        // blends in place: a consumer stream that was handed the previous frame and announced the end of its read holds this
+        // frame's compositing back until then -- here in front of the fused launch, below in front of k_composite.)
+        const bool fused_composite = fuse_composite_ && cache_.can_composite();
+        if (fused_composite && consumer_pending_) {
+            NRC_HIP(hipStreamWaitEvent(Cs, ev_consumer_, 0));
+            consumer_pending_ = false;
+        }
+        CompositeArgs comp{(const float*)d_primary_, (const float*)d_info_, (float*)d_out_, w_, h_, show_nrc_, 0u, blend_factor};
         // no host read-back of the batch filter: every batch is launched, all-zero (unscattered) query tiles skip the network
-        cache_.infer_all(nullptr, Cs, !dense_infer_);
+        cache_.infer_all(nullptr, Cs, !dense_infer_, fused_composite ? &comp : nullptr);
         if (stage_events_) NRC_HIP(hipEventRecord(ev_[3], Cs));
         NRC_HIP(hipEventRecord(ev_infer_done_[pp], Cs));
         if (train) cache_.train_all(B, (B != Cs && frame_index_ > 0) ? ev_infer_done_[pp ^ 1] : nullptr,
@@ -1018,8 +1040,9 @@ public:
             NRC_HIP(hipStreamWaitEvent(Cs, ev_consumer_, 0));
             consumer_pending_ = false;
         }
-        launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
-                         (const float*)d_infer_out_, (float*)d_out_, Cs);
+        if (!fused_composite)
+            launch_composite(frame_, show_nrc_, blend_factor, (const float*)d_primary_, (const float*)d_info_,
+                             (const float*)d_infer_out_, (float*)d_out_, Cs);
         if (stage_events_) NRC_HIP(hipEventRecord(ev_[4], Cs));
         NRC_HIP(hipEventRecord(ev_comp_done_[gp], Cs));
         frame_index_++;
@@ -1301,6 +1324,7 @@ private:
     static constexpr int kGenSets = NRC_GEN_SETS;
     void *d_info2_[kGenSets] = {}, *d_origin2_[kGenSets] = {}, *d_dir2_[kGenSets] = {};
     void *d_primary2_[kGenSets] = {}, *d_infer_in2_[kGenSets] = {};
+    bool fuse_composite_ = false;
     uint32_t nq_ = 0;                                   // queries per frame in the renderer's tile-major order (query_count)
     void *d_pub_in_ = nullptr, *d_pub_out_ = nullptr;   // x * H + y copies of the query / radiance buffers, made when asked for
     hipEvent_t ev_train_done_[2] = {nullptr, nullptr}, ev_comp_done_[kGenSets] = {};

@@ -382,10 +382,36 @@ __device__ __forceinline__ void forward_tiles(const uint4* lw, int lane, int h, 
 // this one at every batch size, so the simpler order stayed.)
 // persistent workgroups; NT 32-sample tiles per wave per iteration; the next iteration's queries are loaded (20 B per
 // sample, straight from HBM/L2 into registers) before the current tiles are computed, so their latency is hidden.
-template <int DEPTH, int THREADS, int NT, int ABL = 0>
+// nrc/render.comp:23-41 for the pixel of query q (tile-major order): c = primary.rgb + (showNrc && scattered ? max(0, nrc) * primary.w : 0),
+// out = blend * c + (1 - blend) * out_prev, alpha likewise towards 1.  The arithmetic is k_composite's, operation for operation
+// and without contraction, so the fused and the separate pass give the same bits.
+__device__ __forceinline__ void composite_query(const CompositeArgs& ca, uint32_t q, float nr, float ng, float nb)
+{
+#pragma clang fp contract(off)
+    const uint32_t tiles_x = (ca.w + 7u) >> 3;
+    const uint32_t tile = q >> 6, in_tile = q & 63u;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t lx = tx * 8u + (in_tile & 7u), y = ty * 8u + (in_tile >> 3);
+    if (lx >= ca.w || y >= ca.h) return;
+    const size_t pix = (size_t)y * ca.w + lx;
+    const float4 p = reinterpret_cast<const float4*>(ca.primary)[pix];
+    float cr = p.x, cg = p.y, cb = p.z;
+    if (ca.show_nrc == 1u && ca.info[pix] == 1.0f) {
+        cr += fmaxf(0.0f, nr) * p.w;
+        cg += fmaxf(0.0f, ng) * p.w;
+        cb += fmaxf(0.0f, nb) * p.w;
+    }
+    float4* fb = reinterpret_cast<float4*>(ca.framebuffer) + pix;
+    const float4 prev = *fb;
+    const float ib = 1.0f - ca.blend_factor;
+    *fb = make_float4(ca.blend_factor * cr + ib * prev.x, ca.blend_factor * cg + ib * prev.y,
+                      ca.blend_factor * cb + ib * prev.z, ca.blend_factor * 1.0f + ib * prev.w);
+}
+
+template <int DEPTH, int THREADS, int NT, int ABL = 0, bool FUSE = false>
 __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
-                                                  int skip_zero = 0)
+                                                  int skip_zero = 0, CompositeArgs ca = CompositeArgs{})
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -454,6 +480,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
                 __builtin_nontemporal_store(y[t][0], o);
                 __builtin_nontemporal_store(y[t][1], o + 1);
                 __builtin_nontemporal_store(y[t][2], o + 2);
+                if constexpr (FUSE) composite_query(ca, ca.q_base + sidx, y[t][0], y[t][1], y[t][2]);
             }
 #pragma unroll
             for (int i = 0; i < 5; i++) x[t][i] = xn[t][i];
@@ -1945,10 +1972,15 @@ int Mlp::num_cus()
 
 template <int THREADS, int NT>
 static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n, const uint4* img,
-                         int skip_zero)
+                         int skip_zero, const CompositeArgs* composite = nullptr)
 {
+    if (composite != nullptr) {
+        hipLaunchKernelGGL((k_infer<6, THREADS, NT, 0, true>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
+                           (unsigned long long*)nullptr, skip_zero, *composite);
+        return;
+    }
     hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
-                       (unsigned long long*)nullptr, skip_zero);
+                       (unsigned long long*)nullptr, skip_zero, CompositeArgs{});
 }
 
 // fp16 feature buffer of the generic path ([n][E16]); grows on demand (never inside a captured region: first use sizes it)
@@ -1964,9 +1996,10 @@ void Mlp::ensure_features(uint32_t n, int slot)
     feat_n_[slot] = n;
 }
 
-void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries)
+void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries, const CompositeArgs* composite)
 {
     if (n == 0) return;
+    if (composite != nullptr && !fused_) throw std::logic_error("SkyRenderer ERROR: compositing epilogue asked of a generic model");
     const uint4* img = (const uint4*)(use_ema ? d_pk_infer_[infer_set_] : d_pk_fwd_);
     if (!fused_) {
         // EMA inference of a Frequency(12) + OneBlob(4) model encodes inside the MLP kernel (image in the encoder's input order);
@@ -2059,7 +2092,7 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     else if (threads == 256 && nt == 4) launch_infer<256, 4>(blocks, lds, s, d_in, d_out, n, img, sz);
     else
 #endif
-    launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz);
+    launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz, composite);
     NRC_HIP(hipGetLastError());
 }
 

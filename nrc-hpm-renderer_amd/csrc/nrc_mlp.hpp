@@ -14,6 +14,17 @@ struct MlpLayer {
     uint32_t off;   // offset into the canonical fp32 parameter vector ([out][in] row-major)
 };
 
+// nrc/render.comp as the epilogue of the renderer's inference launch: the queries are in the renderer's tile-major order (query
+// q_base + i = pixel (x, y) of 8x8 tile (tx, ty), see query_index in nrc_integrator.hip), so the 32 queries of an inference tile are
+// four rows of eight pixels.  primary / info / framebuffer are [h][w] images.
+struct CompositeArgs {
+    const float* primary;      // float4: rgb, throughput
+    const float* info;         // didScatter
+    float* framebuffer;        // float4, blended in place
+    uint32_t w, h, show_nrc, q_base;
+    float blend_factor;
+};
+
 class Mlp {
 public:
     explicit Mlp(const nrc_config& cfg);
@@ -23,7 +34,10 @@ public:
 
     // network->inference: y = MLP_ema(encode(x)); in [n][5], out [n][3] (device, fp32)
     // skip_zero_queries (renderer only): 32-sample tiles whose queries are all exactly zero store 0 without running the network
-    void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries = false);
+    void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries = false,
+               const CompositeArgs* composite = nullptr);
+    // the fused 6x64 inference kernel can composite in its epilogue (nrc/render.comp); the generic kernels cannot
+    bool can_composite() const { return fused_; }
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
     // widen_grid_grad (models with a trainable table): also write the table gradient into the fp32 gradient vector -- needed only
     // by readers of the vector (dense exchange, gradient hook, debug read-back); the optimizer reads the packed fp16 table itself

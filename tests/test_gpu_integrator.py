@@ -737,6 +737,33 @@ def test_hot_tiles_are_started_first_and_change_no_pixel(api, orc, sc, cloud16, 
     assert o["info"][3, 2] == 1.0 and o["info"][:8, :8].sum() == 1.0
 
 
+def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, torch_gpu, monkeypatch):
+    """nrc/render.comp as the epilogue of the inference launch (NRC_FUSED_COMPOSITE=1; the queries are tile-major inside the
+    renderer) blends the same image, bit for bit, as k_composite behind the launch -- trained, blended frames of a ragged size"""
+    W, H = 328, 200
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=14)
+    frs = np.asarray(sc.frame_randoms(6, seed=9), np.float32)
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.setenv("NRC_FUSED_COMPOSITE", "1")
+        else:
+            monkeypatch.delenv("NRC_FUSED_COMPOSITE", raising=False)
+        nrc = api.NeuralRadianceCache(cfg)
+        ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
+        ren.RenderFrames(frs, True)
+        out[fused] = (ren.GetImage().cpu().numpy().copy(), ren.Buffer("infer_output").cpu().numpy().copy(),
+                      ren.Buffer("infer_input").cpu().numpy().copy(), nrc.GetLoss(), ren.StageStats()["render"])
+        ren.Destroy()
+        nrc.Destroy()
+    for k in range(3):
+        assert same_bits(out[True][k], out[False][k])
+    assert out[True][3] == out[False][3]
+    assert out[True][0][..., :3].std() > 0.01 and (out[True][0][..., 3] == 1.0).all()
+
+
 def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc, cloud16, torch_gpu):
     """the costliest-first launch order of gen_rays' tiles: after the first sort the order is no longer the identity, it is a
     permutation of all tile slots with the provably empty tiles behind the cloud's, and every frame -- primary pass, queries,
