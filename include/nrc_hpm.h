@@ -251,7 +251,10 @@ int nrc_renderer_destroy(nrc_renderer_t* r);
 /* intermediate device buffers of the most recent frame, after synchronising all of the renderer's streams (tests /
  * multi-GPU; the sets rotate, so ask again after every Render): 0 primary colour+throughput [h][w][4], 1 primary info [h][w],
  * 2 nrc ray origin [h][w][4], 3 nrc ray dir [h][w][4] (train-grid pixels only unless set_full_vertex_images), 4 infer input [w*h][5], 5 infer output [w*h][3],
- * 6 train input [T][5], 7 train target [T][3], 8 train ring {head, tail, RayInfo[ring]} */
+ * 6 train input [T][5], 7 train target [T][3], 8 train ring {head, tail, RayInfo[ring]}.  Buffers 4 and 5 are handed out in the
+ * reference's order, query x*H+y (nrc/prep_infer_rays.comp:31), as a COPY made by this call: inside the renderer they are
+ * tile-major (the 64 queries of an 8x8 pixel tile contiguous), and the cache's own API (nrc_cache_init / infer) speaks x*H+y
+ * whatever its caller's order is. */
 void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes);
 /* Empty-space early-out (on by default): camera rays that provably cannot come within a voxel of non-empty density skip their
  * delta-tracking walk -- the walk could only reject every tentative collision, leave the volume unscattered and produce env(rd),
