@@ -1488,7 +1488,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const 
 struct WgradTile {
     uint32_t a_row0, b_row0, m_valid, n_valid, param_off, in_dim;
 };
-constexpr int WGRAD_WAVES = 7;
+#ifndef NRC_WGRAD_WAVES
+#define NRC_WGRAD_WAVES 7
+#endif
+constexpr int WGRAD_WAVES = NRC_WGRAD_WAVES;
 constexpr uint32_t WGRAD_CHUNK = 128;
 
 __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __restrict__ deltas,
