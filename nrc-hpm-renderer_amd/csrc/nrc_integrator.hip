@@ -1440,6 +1440,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             dbg_old = dir;
 #endif
             dir = new_ray_dir(c, dir, true);
+#ifdef NRC_DIAG_LASTDIR
+            // the direction as it left new_ray_dir goes to memory AT ONCE; the end of the kernel reads it back and compares it with the
+            // registers it is about to store: did the value change in the register file, or was it computed differently?
+            if (inside) origin[(size_t)y * fr.w + lx] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+#endif
             if ((uint32_t)i >= primary_ray_length) {
                 if (c.rand(1.0f) >= primary_ray_prob || i == 128) walking = false;
             }
@@ -1459,8 +1464,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             }
             if (on_grid) {
 #ifdef NRC_DIAG_LASTDIR
-                origin[pix] = make_float4(dbg_old.x, dbg_old.y, dbg_old.z, dbg_rng_in);      // (the incoming direction instead of the vertex)
-                dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+                const float4 early = origin[pix];      // (written right behind the last new_ray_dir, see there)
+                const bool moved = did_scatter && (nrc_f2u(early.x) != nrc_f2u(dir.x) || nrc_f2u(early.y) != nrc_f2u(dir.y) || nrc_f2u(early.z) != nrc_f2u(dir.z));
+                // the incoming direction instead of the vertex -- or, when the registers no longer hold what was computed, that value
+                origin[pix] = moved ? make_float4(early.x, early.y, early.z, dbg_rng_in) : make_float4(dbg_old.x, dbg_old.y, dbg_old.z, dbg_rng_in);
+                dirs[pix] = make_float4(dir.x, dir.y, dir.z, moved ? 1.0f : 0.0f);
 #else
                 origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
                 dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);

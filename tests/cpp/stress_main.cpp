@@ -149,7 +149,7 @@ static const char* kBufNames[9] = {"primary", "info", "origin", "dir", "infer_in
 struct Snapshot {
     std::vector<float> image;
     std::vector<std::vector<unsigned char>> bufs;      // the nine renderer buffers of the last frame
-    std::vector<std::vector<unsigned char>> sets[4];   // gen_rays output sets (the last four frames): primary, info, infer_input
+    std::vector<std::vector<unsigned char>> sets[6];   // gen_rays output sets (the last six frames): primary, info, infer_input
     std::vector<float> w, ema;
     float loss = 0.0f;
 };
@@ -190,7 +190,7 @@ static Snapshot render(const Setup& su, const nrc_config& cfg, uint32_t gw, uint
     s.image.resize((size_t)lw * gh * 4);
     HIPCHK(hipMemcpy(s.image.data(), d_img, s.image.size() * 4, hipMemcpyDeviceToHost));
     if (g_keep_sets)
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 6; k++)
             for (int b : {0, 1, 4, 2, 3}) {
                 size_t bytes = 0;
                 void* p = nrc_renderer_buffer(r, b + 16 * (k + 1), &bytes);
@@ -304,7 +304,7 @@ int main(int argc, char** argv)
                         shown++;
                         const uint32_t x = (uint32_t)(p % GW), y = (uint32_t)(p / GW);
                         const uint32_t strip = x / block, r = strip % world, lx = (strip / world) * block + x % block, lw = GW / world;
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < 6; k++) {
                             const float* pt = (const float*)&parts[r].sets[k][0][((size_t)y * lw + lx) * 16];
                             const float* pw = (const float*)&whole.sets[k][0][((size_t)y * GW + x) * 16];
                             const float* it = (const float*)&parts[r].sets[k][1][((size_t)y * lw + lx) * 4];
@@ -317,17 +317,17 @@ int main(int argc, char** argv)
                             const float* dt = (const float*)&parts[r].sets[k][4][((size_t)y * lw + lx) * 16];
                             const float* dw = (const float*)&whole.sets[k][4][((size_t)y * GW + x) * 16];
                             if (dp || di || dq)
-                                std::printf("   px (%u, %u) set %d: origin image (product: vertex; -DNRC_DIAG_LASTDIR: incoming direction) %s, final dir %s, [diag build: rng before the last new_ray_dir %s]; LASTDIR rng %08x in %08x %08x %08x out_tiles %08x %08x %08x out_whole %08x %08x %08x\n",
+                                std::printf("   px (%u, %u) set %d: origin image (product: vertex; -DNRC_DIAG_LASTDIR: incoming direction) %s, final dir %s, [diag build: rng before the last new_ray_dir %s]; LASTDIR rng %08x in %08x %08x %08x out_tiles %08x %08x %08x out_whole %08x %08x %08x moved_in_registers tiles %g whole %g\n",
                                             x, y, k, std::memcmp(ot, ow, 12) ? "DIFF" : "same", std::memcmp(dt, dw, 12) ? "DIFF" : "same", std::memcmp(ot + 3, ow + 3, 4) ? "DIFF" : "same",
                                             ((const unsigned*)ow)[3], ((const unsigned*)ow)[0], ((const unsigned*)ow)[1], ((const unsigned*)ow)[2], ((const unsigned*)dt)[0], ((const unsigned*)dt)[1],
-                                            ((const unsigned*)dt)[2], ((const unsigned*)dw)[0], ((const unsigned*)dw)[1], ((const unsigned*)dw)[2]);
+                                            ((const unsigned*)dt)[2], ((const unsigned*)dw)[0], ((const unsigned*)dw)[1], ((const unsigned*)dw)[2], dt[3], dw[3]);
                             if (dp || di || dq)
                                 std::printf("   px (%u, %u) set %d: primary %s info %s query %s | tiles prim %.9g %.9g %.9g %.9g info %g q %.9g %.9g %.9g %.9g %.9g | whole prim %.9g %.9g %.9g %.9g info %g q %.9g %.9g %.9g %.9g %.9g\n",
                                             x, y, k, dp ? "DIFF" : "same", di ? "DIFF" : "same", dq ? "DIFF" : "same", pt[0], pt[1], pt[2], pt[3], it[0], qt[0], qt[1], qt[2], qt[3], qt[4],
                                             pw[0], pw[1], pw[2], pw[3], iw[0], qw[0], qw[1], qw[2], qw[3], qw[4]);
                         }
                     }
-                    std::printf("  (sets hold the last four of the %u frames; no line above = the gen_rays outputs of those frames agree at the differing pixels)\n", su.frames);
+                    std::printf("  (sets hold the last six of the %u frames; no line above = the gen_rays outputs of those frames agree at the differing pixels)\n", su.frames);
                     g_keep_sets = false;
                     // which side moved: render both again and compare each with its first rendering
                     Snapshot whole2 = render(su, cfg, GW, GH, GW, nullptr, false, true);
@@ -358,12 +358,12 @@ int main(int argc, char** argv)
                 const int reps = (int)su.frames;
                 std::vector<float> first_img;
                 for (int rep = 0; rep < reps; rep++) {
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < 6; k++) {
                         en::nrc_check(nrc_renderer_set_frame_random(r, &su.randoms[0]));
                         en::nrc_check(nrc_renderer_render(r, 0));
                     }
-                    std::vector<std::vector<unsigned char>> sets[4];
-                    for (int k = 0; k < 4; k++)
+                    std::vector<std::vector<unsigned char>> sets[6];
+                    for (int k = 0; k < 6; k++)
                         for (int b : {0, 1, 4}) {
                             size_t bytes = 0;
                             void* p = nrc_renderer_buffer(r, b + 16 * (k + 1), &bytes);
@@ -375,7 +375,7 @@ int main(int argc, char** argv)
                     const char* names[3] = {"primary", "info", "infer_input"};
                     const size_t stride[3] = {16, 4, 20};
                     bool any = false;
-                    for (int k = 1; k < 4; k++)
+                    for (int k = 1; k < 6; k++)
                         for (int b = 0; b < 3; b++) {
                             if (sets[k][b] == sets[0][b]) continue;
                             any = true;
