@@ -368,30 +368,58 @@ __device__ __forceinline__ float hg_phase(const DevScene& s, float cos_theta)
     return (0.5f * (1.0f - g2)) / (x * sqrtf(x));
 }
 
+#ifndef NRC_DIAG_BISECT
+#define NRC_DIAG_BISECT_ROT(on, bit) do { } while (0)
+#else
+// (sub-regions of the SECOND rotation of new_ray_dir: 64 the axis normalisation, 128 sincos, 256 the matrix and its product)
+#define NRC_DIAG_BISECT_ROT(on, bit) do { if (SECOND && ((NRC_DIAG_BISECT) & (bit))) __builtin_amdgcn_s_setprio((on) ? 3 : 0); } while (0)
+#endif
+template <bool SECOND = false>
 __device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
 {
+    NRC_DIAG_BISECT_ROT(true, 64);
     axis = normalize(axis);
+    NRC_DIAG_BISECT_ROT(false, 64);
     float s, co;
+    NRC_DIAG_BISECT_ROT(true, 128);
     nrc_sincosf(angle, &s, &co);
+    NRC_DIAG_BISECT_ROT(false, 128);
+    NRC_DIAG_BISECT_ROT(true, 256);
     float oc = 1.0f - co;
     const float ox = oc * axis.x, oy = oc * axis.y, oz = oc * axis.z;
     V3 c0 = v3(nrc_fmaf_(ox, axis.x, co), nrc_fmaf_(ox, axis.y, -(axis.z * s)), nrc_fmaf_(oz, axis.x, axis.y * s));
     V3 c1 = v3(nrc_fmaf_(ox, axis.y, axis.z * s), nrc_fmaf_(oy, axis.y, co), nrc_fmaf_(oy, axis.z, -(axis.x * s)));
     V3 c2 = v3(nrc_fmaf_(oz, axis.x, -(axis.y * s)), nrc_fmaf_(oy, axis.z, axis.x * s), nrc_fmaf_(oz, axis.z, co));
-    return v3(nrc_fmaf_(c2.x, v.z, nrc_fmaf_(c1.x, v.y, c0.x * v.x)),
-              nrc_fmaf_(c2.y, v.z, nrc_fmaf_(c1.y, v.y, c0.y * v.x)),
-              nrc_fmaf_(c2.z, v.z, nrc_fmaf_(c1.z, v.y, c0.z * v.x)));
+    const V3 r = v3(nrc_fmaf_(c2.x, v.z, nrc_fmaf_(c1.x, v.y, c0.x * v.x)),
+                    nrc_fmaf_(c2.y, v.z, nrc_fmaf_(c1.y, v.y, c0.y * v.x)),
+                    nrc_fmaf_(c2.z, v.z, nrc_fmaf_(c1.z, v.y, c0.z * v.x)));
+    NRC_DIAG_BISECT_ROT(false, 256);
+    return r;
 }
 
+// DIAGNOSTIC (tools/stress_lastdir.sh, -DNRC_DIAG_BISECT=<mask> on top of -DNRC_DIAG_LOWPRIO=8): the camera kernels run at wave
+// priority 0 except inside the code regions whose bit is set -- which stretch of code has to be protected for the frames to agree?
+//   1 the whole new_ray_dir call, 2 its normalisations of the old direction and the axis, 4 the polar angle, 8 the first rotation,
+//   16 the azimuth draw and the second rotation, 32 the final normalisation
+#ifdef NRC_DIAG_BISECT
+#define NRC_BISECT_ON(bit) do { if ((NRC_DIAG_BISECT) & (bit)) __builtin_amdgcn_s_setprio(3); } while (0)
+#define NRC_BISECT_OFF(bit) do { if ((NRC_DIAG_BISECT) & (bit)) __builtin_amdgcn_s_setprio(0); } while (0)
+#else
+#define NRC_BISECT_ON(bit) do { } while (0)
+#define NRC_BISECT_OFF(bit) do { } while (0)
+#endif
 template <class C>
 __device__ __forceinline__ V3 new_ray_dir(C& c, V3 old_dir, bool phase_sampling)
 {
     NRC_PROF(c, 4);
+    NRC_BISECT_ON(2);
     old_dir = normalize(old_dir);
     V3 ortho = old_dir.z < old_dir.x ? v3(old_dir.y, -old_dir.x, 0.0f) : v3(0.0f, -old_dir.z, old_dir.y);
     if (ortho.x == 0.0f && ortho.y == 0.0f && ortho.z == 0.0f) ortho = v3(0.0f, 1.0f, 0.0f);   // robustness
     ortho = normalize(ortho);
+    NRC_BISECT_OFF(2);
     float angle;
+    NRC_BISECT_ON(4);
     if (phase_sampling) {
         float g = c.sc.g;
         float cos_theta;
@@ -405,10 +433,20 @@ __device__ __forceinline__ V3 new_ray_dir(C& c, V3 old_dir, bool phase_sampling)
     } else {
         angle = c.rand(NRC_PI);
     }
+    NRC_BISECT_OFF(4);
+    NRC_BISECT_ON(8);
     V3 nd = rotate(ortho, angle, old_dir);
+    NRC_BISECT_OFF(8);
+    NRC_BISECT_ON(16);
+    NRC_BISECT_ON(512);      // (512: the azimuth draw alone)
     angle = c.rand(NRC_TWO_PI);
-    nd = rotate(old_dir, angle, nd);
-    return normalize(nd);
+    NRC_BISECT_OFF(512);
+    nd = rotate<true>(old_dir, angle, nd);
+    NRC_BISECT_OFF(16);
+    NRC_BISECT_ON(32);
+    nd = normalize(nd);
+    NRC_BISECT_OFF(32);
+    return nd;
 }
 
 // ---- include/path_trace.glsl
@@ -1439,7 +1477,9 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             dbg_rng_in = c.rng;
             dbg_old = dir;
 #endif
+            NRC_BISECT_ON(1);
             dir = new_ray_dir(c, dir, true);
+            NRC_BISECT_OFF(1);
 #ifdef NRC_DIAG_LASTDIR
             // the direction as it left new_ray_dir goes to memory AT ONCE; the end of the kernel reads it back and compares it with the
             // registers it is about to store: did the value change in the register file, or was it computed differently?

@@ -40,6 +40,23 @@ __global__ void k_spin(unsigned long long cycles, unsigned* sink)
     while (__builtin_amdgcn_s_memtime() - t0 < cycles) acc = acc * 1664525u + 1013904223u;
     if (acc == 0xdeadbeefu) sink[0] = acc;
 }
+// the same spin with other instruction mixes (which execution resource does the perturbation go through?): 3 full-rate integer
+// (shift / xor / add, no multiply), 4 transcendental (v_sin_f32 / v_rcp_f32), 5 no vector work at all (scalar clock polling only),
+// 6 as 1 without the raised priority
+template <int KIND>
+__global__ void k_spin_kind(unsigned long long cycles, unsigned* sink)
+{
+    if (KIND != 6) __builtin_amdgcn_s_setprio(3);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned acc = threadIdx.x;
+    float f = 0.001f * (float)threadIdx.x;
+    while (__builtin_amdgcn_s_memtime() - t0 < cycles) {
+        if (KIND == 3) acc = (acc ^ (acc << 5)) + 0x9e3779b9u;
+        else if (KIND == 4) f = __builtin_amdgcn_sinf(f) + __builtin_amdgcn_rcpf(f + 2.0f);
+        else if (KIND == 6) acc = acc * 1664525u + 1013904223u;
+    }
+    if (acc == 0xdeadbeefu || f == 123.456f) sink[0] = acc;
+}
 __global__ __launch_bounds__(1024) void k_spin_lds(unsigned long long cycles, unsigned* sink)
 {
     __shared__ unsigned lds[16 * 1024];      // 64 KB: competes with k_infer / k_train_fwd_bwd for a CU's LDS
@@ -72,6 +89,10 @@ struct Perturber {
                 // bursts of 20-60 us at irregular intervals
                 const unsigned long long cyc = 2000ull + (unsigned long long)((n * 2654435761u) >> 20);      // 100 MHz clock: 20 .. 61 us
                 if (kind == 1) hipLaunchKernelGGL(k_spin, dim3(256), dim3(64), 0, s, cyc, sink);
+                else if (kind == 3) hipLaunchKernelGGL(k_spin_kind<3>, dim3(256), dim3(64), 0, s, cyc, sink);
+                else if (kind == 4) hipLaunchKernelGGL(k_spin_kind<4>, dim3(256), dim3(64), 0, s, cyc, sink);
+                else if (kind == 5) hipLaunchKernelGGL(k_spin_kind<5>, dim3(256), dim3(64), 0, s, cyc, sink);
+                else if (kind == 6) hipLaunchKernelGGL(k_spin_kind<6>, dim3(256), dim3(64), 0, s, cyc, sink);
                 else hipLaunchKernelGGL(k_spin_lds, dim3(128), dim3(1024), 0, s, cyc, sink);
                 if ((++n & 7u) == 0) HIPCHK(hipStreamSynchronize(s));
                 launches++;
