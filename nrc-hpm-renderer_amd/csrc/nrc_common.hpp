@@ -61,14 +61,13 @@ struct Pcg32 {
 }  // namespace nrc
 
 // Every kernel of the library that can share a SIMD with k_gen_rays raises its waves to the SAME user wave priority, the highest
-// (s_setprio 3).  Reason (tests/cpp/stress_main.cpp): a k_gen_rays wave that shares its SIMD with waves of a
+// (s_setprio 3).  Reason (tests/cpp/stress_main.cpp): a k_gen_rays wave that shared its SIMD with waves of a
 // HIGHER issue priority now and then -- 2-3 % of 72-frame runs when the inference kernel alone is raised; twice in ~60 runs of
-// round 2's build, whose streams differed in queue priority only -- leaves the path's last new_ray_dir with a different direction
-// in lanes 48..63 although every input is identical: the NRC query of those 16 pixels changes, nothing else.  Neither scratch, nor
-// the lane-pair tails, nor the spacing of transcendental instructions has a part in it (each was removed or padded without
-// effect).  With every kernel at one priority the event did not occur in 300 runs that otherwise show it 6-11 times; raising the
-// camera kernels ALONE does the same but starves the side streams (frame 0.279 -> 0.298 ms).  One common level costs nothing
-// against none.
+// round 2's build, whose streams differed in queue priority only -- left new_ray_dir with a different direction in lanes 48..63
+// although every input was identical.  The code that did it was found later (packed FP32 instructions with operand swizzles that
+// the SLP vectoriser had made of the second rotation; the integrator is compiled with -fno-slp-vectorize now, csrc/Makefile) and the
+// kernel no longer fails in that arrangement; the common priority stays as the second guard -- it costs nothing against none
+// (raising the camera kernels ALONE starves the side streams: frame 0.279 -> 0.298 ms).
 //   bit: 1 inference / training kernels (nrc_mlp.hip), 2 k_composite, 4 train-ray kernels, 8 camera kernels, 16 helpers
 //   -DNRC_DIAG_LOWPRIO=<mask>: DIAGNOSTIC builds leave those groups at the default priority 0 (8 = the configuration that fails)
 #ifndef NRC_WAVE_PRIORITY
