@@ -85,7 +85,7 @@ def test_camera_kernels_use_no_scratch():
                                "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
         text = open(out).read()
     mk = open(os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc", "Makefile")).read()
-    assert "STRICT = -ffp-contract=off -fno-slp-vectorize" in mk      # (the flags compiled here are the Makefile's)
+    assert "-fno-slp-vectorize $(EXTRA)" in mk and "STRICT = -ffp-contract=off" in mk      # (the flags compiled here are the Makefile's)
     # the cause of round 2's non-determinism: packed-FP32 code the SLP vectoriser made of new_ray_dir, with
     # operand swizzles -- no v_pk_mov_b32 and no op_sel / neg_hi on a packed FP32 instruction may be left in the camera kernels
     # (op_sel_hi:[...] is how the hand-written f2 arithmetic broadcasts a scalar operand: allowed)
