@@ -70,7 +70,7 @@ def test_headers_compile_standalone():
 
 
 
-def test_camera_kernels_use_no_scratch():
+def test_camera_kernels_use_no_scratch_and_no_compiler_made_packed_fp32():
     """k_gen_rays / k_mc_render / k_prep_train must not spill: the one value k_gen_rays used to spill (8 bytes per lane of scratch) came
     back stale in lanes 48..63 when high-priority waves of other queues were co-resident -- the cause of both non-determinism events
     of round 2.  Compiles the device code of nrc_integrator.hip with the Makefile's flags and reads the
@@ -89,10 +89,15 @@ def test_camera_kernels_use_no_scratch():
     # the cause of round 2's non-determinism: packed-FP32 code the SLP vectoriser made of new_ray_dir, with
     # operand swizzles -- no v_pk_mov_b32 and no op_sel / neg_hi on a packed FP32 instruction may be left in the camera kernels
     # (op_sel_hi:[...] is how the hand-written f2 arithmetic broadcasts a scalar operand: allowed)
-    body = text[text.index("k_gen_raysILb0E"):]
-    body = body[:body.index(".Lfunc_end")]
-    assert "v_pk_mov_b32" not in body
-    assert not re.search(r"v_pk_(fma|mul|add)_f32[^\n]* (op_sel:|neg_hi:|neg_lo:)", body)
+    swizzled = re.compile(r"v_pk_(fma|mul|add)_f32[^\n]* (op_sel:|neg_hi:|neg_lo:)")
+    assert "v_pk_mov_b32" not in text and not swizzled.search(text)
+    # ... nor in the MLP kernels (the generic-model kernels had a few)
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "mlp.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--cuda-device-only",
+                               "-S", "-o", out, os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc", "nrc_mlp.hip")], stderr=subprocess.DEVNULL)
+        mlp = open(out).read()
+    assert "v_pk_mov_b32" not in mlp and not swizzled.search(mlp)
     seen = 0
     for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text):
         if any(k in m.group(1) for k in ("k_gen_rays", "k_mc_render")):
