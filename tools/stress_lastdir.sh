@@ -3,11 +3,12 @@
 # (-DNRC_DIAG_LASTDIR -DNRC_DIAG_LOWPRIO=8): for every affected pixel the log says whether the direction the kernel stored at its
 # end is still the one new_ray_dir had produced (written to memory right behind the call) -- i.e. whether the value changed in
 # the register file or was computed differently.   tools/stress_lastdir.sh build | tools/stress_lastdir.sh <processes> [out dir]
+# (the product is compiled with -fno-slp-vectorize since the cause was found: this diagnostic build switches the vectoriser back ON)
 set -u
 cd "$(dirname "$0")/.."
 BIN=tests/cpp/_build
 if [ "${1:-}" = "build" ]; then
-    make -C nrc-hpm-renderer_amd/csrc ARCH=gfx950 OUT=../lib_ld "EXTRA=-DNRC_DIAG_LASTDIR -DNRC_DIAG_LOWPRIO=8" > /dev/null || exit 1
+    make -C nrc-hpm-renderer_amd/csrc ARCH=gfx950 OUT=../lib_ld "EXTRA=-fslp-vectorize -DNRC_DIAG_LASTDIR -DNRC_DIAG_LOWPRIO=8" > /dev/null || exit 1
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O2 -Iinclude tests/cpp/stress_main.cpp -o $BIN/stress_main_ld \
         -Lnrc-hpm-renderer_amd/lib_ld -lnrc_hpm -pthread "-Wl,-rpath,\$ORIGIN/../../../nrc-hpm-renderer_amd/lib_ld" || exit 1
     exit 0
