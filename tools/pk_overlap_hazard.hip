@@ -54,6 +54,18 @@ __global__ __launch_bounds__(256) void k_victim(unsigned seed, unsigned iters, u
             asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(c), "v"(b));
             e = f2{__builtin_fmaf(d0.y, c.x, b.x), __builtin_fmaf(d0.x, c.x, b.y)};
         }
+        if (CASE == 5 || CASE == 6) {
+            // the instruction the assembly bisection of the failing build ended at (tools/asm_patch_experiment.sh):
+            //     v_pk_fma_f32 v[54:55], v[88:89], v[16:17], v[54:55] op_sel:[0,1,0]      D = S0 * S1.hi + D, accumulator in place,
+            // its accumulator halves written by a v_mul_f32 and a v_mov_b32 just before (CASE 6 reproduces that too)
+            f2 acc = c;
+            float spare;
+            if (CASE == 6) asm volatile("v_mul_f32 %0, %3, %4\n\tv_mov_b32 %1, %5\n\tv_mul_f32 %2, %3, %3" : "=&v"(acc.x), "=&v"(acc.y), "=&v"(spare) : "v"(b.x), "v"(a.y), "v"(b.y));
+            const f2 acc0 = CASE == 6 ? f2{b.x * a.y, b.y} : c;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+            d = acc;
+            e = f2{__builtin_fmaf(a.x, b.y, acc0.x), __builtin_fmaf(a.y, b.y, acc0.y)};
+        }
         if (CASE == 2) {
             asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
             e = f2{__builtin_fmaf(a.y, b.x, c.x), __builtin_fmaf(a.x, b.x, c.y)};
@@ -137,5 +149,7 @@ int main(int argc, char** argv)
     run_case<1>("v_pk_mov_b32 in place (D.lo = S0.hi, D.hi = old D.lo)", seconds, true, d_hist, d_checks, d_sink);
     run_case<2>("v_pk_fma_f32 with crossed halves, separate destination (control)", seconds, true, d_hist, d_checks, d_sink);
     run_case<4>("chain: in-place fma -> in-place mov -> in-place fma", seconds, true, d_hist, d_checks, d_sink);
+    run_case<5>("v_pk_fma_f32 D, S0, S1, D op_sel:[0,1,0] (the bisection's instruction)", seconds, true, d_hist, d_checks, d_sink);
+    run_case<6>("... behind v_mul_f32 / v_mov_b32 writes of its accumulator halves", seconds, true, d_hist, d_checks, d_sink);
     return 0;
 }
