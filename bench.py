@@ -88,9 +88,10 @@ def visible_gpus():
                 pass
     except OSError:
         n = 0
-    if n == 0:                       # no KFD view (containers): torch's count does not initialise the runtime on this image
-        import torch
-        n = torch.cuda.device_count()
+    if n == 0:
+        # no KFD view (some containers): nothing here may touch the HIP runtime -- this process starts the ranks -- so the request is
+        # trusted (None) and a rank without a device fails by itself ("rank r has no device")
+        return None
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -102,7 +103,7 @@ def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a fresh child job, relay rank 0's line"""
     shared = os.environ.get("NRC_BENCH_SHARED_GPU") == "1"      # rehearsal on ONE device: all ranks on cuda:0, gloo + hook exchange
     have = visible_gpus()
-    if have < args.gpus and not shared:
+    if have is not None and have < args.gpus and not shared:
         print("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run under an %d-GPU label"
               % (args.gpus, have, args.gpus), file=sys.stderr)
         return 2
@@ -507,6 +508,7 @@ def main():
             "exchange": exchange,
             "stage_ms": {k: stats[k] for k in ("gen_rays", "prep_train", "train", "infer", "render", "total")},
             "loss": loss,
+            "build_id": api.build_id(),
             "roofline": roof_gen if dominant_is_gen else roof_mlp,
             "roofline_mlp": roof_mlp,
             "roofline_integrator": roof_gen,
@@ -538,6 +540,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(scene, W, H)
         out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
         out["gpu_mc_vs_cpu"] = out["gpu_mc_baseline"]["value"] / out["cpu_baseline"]["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_reason"] = ("--no-cpu-baseline" if args.no_cpu_baseline else
+                                      "reported on rank 0 at N=1 only (the contract's bounded host-core sample); this is an N=%d line" % world)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

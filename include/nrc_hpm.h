@@ -184,7 +184,9 @@ typedef struct nrc_camera {
  * global_w x global_h frame, every x_stride-th strip starting with strip x_offset: local column i (i = 0..width-1) is the global
  * column (x_offset + (i / x_block) * x_stride) * x_block + i % x_block; width passed to create is the LOCAL column count.
  * x_block must be a power of two; 0 means 1 (single interleaved columns).  {0,1,W,H,0} = whole frame.  Strips of 8 columns keep
- * the 8x8-pixel tile a wavefront renders contiguous on the screen (coherent walks, as on one GPU) at the same load balance. */
+ * the 8x8-pixel tile a wavefront renders contiguous on the screen (coherent walks, as on one GPU) at the same load balance.
+ * ABI note: the struct has FIVE fields (20 bytes) since nrc_version() "0.2"; "0.1" had four (16 bytes, no x_block) -- a caller built
+ * against the older header must be recompiled (the library would read x_block past the end of its struct). */
 typedef struct nrc_tile {
     uint32_t x_offset, x_stride, global_w, global_h;
     uint32_t x_block;

@@ -86,6 +86,11 @@ ABI_SYMBOLS = [
 _lib = None
 
 
+def build_id():
+    """the hash of sources + compiler + flags the loaded library was built from (csrc/Makefile: NRC_BUILD_ID, the tail of nrc_version())"""
+    return load_library().nrc_version().decode().rsplit("build ", 1)[1]
+
+
 def load_library():
     """dlopen libnrc_hpm.so (built by __graft_entry__.build() / csrc/Makefile).  No fallback."""
     global _lib

@@ -1313,6 +1313,12 @@ __device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* l
                 uint32_t t = 0;
 #pragma unroll
                 for (uint32_t k = 0; k < kHotTilesMax; k++) t = d == k ? hot[k] : t;
+                // k_hot_tiles appends one entry per capped PIXEL: two such pixels in one tile list the tile twice, and the tile must
+                // still be traced exactly once (k_mc_render blends in place) -- the later duplicate leaves
+                bool dup = false;
+#pragma unroll
+                for (uint32_t k = 0; k + 1u < kHotTilesMax; k++) dup |= (k < d) & (hot[k] == t);
+                if (dup) return false;
                 const uint32_t lane = threadIdx.x & 63u;
                 lx = (t & 0xffffu) * 8u + (lane & 7u);
                 y = (t >> 16) * 8u + (lane >> 3);

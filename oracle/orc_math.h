@@ -8,7 +8,7 @@
  * GLSL built-ins are implementation defined (no bit-exact spec), so this build *defines* them:
  * Cephes-style single-precision polynomials whose Horner steps are explicit single-rounding
  * fused multiply-adds (fmaf on the host == v_fma_f32 on the device), correctly rounded / and sqrt.  The HIP product carries its own statement of
- * the same polynomials (nrc-hpm-renderer_amd/csrc/nrc_math.h); tests/test_math_parity.py checks
+ * the same polynomials (nrc-hpm-renderer_amd/csrc/nrc_math.h); tests/test_gpu_math.py checks
  * the two bit-for-bit on the GPU.  Compile with -ffp-contract=off.
  */
 #ifndef ORC_MATH_H

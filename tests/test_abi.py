@@ -70,37 +70,78 @@ def test_headers_compile_standalone():
 
 
 
-def test_camera_kernels_use_no_scratch_and_no_compiler_made_packed_fp32():
-    """k_gen_rays / k_mc_render / k_prep_train must not spill: the one value k_gen_rays used to spill (8 bytes per lane of scratch) came
-    back stale in lanes 48..63 when high-priority waves of other queues were co-resident -- the cause of both non-determinism events
-    of round 2.  Compiles the device code of nrc_integrator.hip with the Makefile's flags and reads the
-    kernels' metadata."""
-    import re
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "nrc-hpm-renderer_amd", "lib", "libnrc_hpm.so")
+CSRC = os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc")
+
+
+def shipped_code_objects(tmp):
+    """the gfx950 code objects inside the SHIPPED lib/libnrc_hpm.so (one per translation unit), as (disassembly, notes) pairs.
+    llvm-objdump --offloading writes the bundles' members next to its input, so it runs on a copy."""
+    import glob
+    import shutil
+    import subprocess
+    so = os.path.join(tmp, "libnrc_hpm.so")
+    shutil.copy(LIB, so)
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = []
+    for co in sorted(glob.glob(so + ".*gfx950")):
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+        out.append((dis, notes))
+    return out
+
+
+def kernel_bodies(dis):
+    """{mangled name: disassembly text} of one code object"""
+    out = {}
+    for block in re.split(r"\n(?=[0-9a-f]{16} <[^>]+>:)", dis):
+        m = re.match(r"[0-9a-f]{16} <([^>]+)>:", block)
+        if m:
+            out[m.group(1)] = block
+    return out
+
+
+def test_shipped_library_is_the_build_of_these_sources_and_flags(api):
+    """round 3 shipped a lib/ older than its Makefile's flags and nothing noticed.  The Makefile hashes every source
+    of the library, the boundary header, the compiler version and the flags into NRC_BUILD_ID (what nrc_version() returns); a lib/ that
+    was not rebuilt after an edit of any of them fails here."""
+    import subprocess
+    want = subprocess.run(["make", "-s", "-C", CSRC, "print-build-id"], check=True, capture_output=True, text=True).stdout.strip()
+    assert re.fullmatch(r"[0-9a-f]{16}", want), want
+    got = api.load_library().nrc_version().decode()
+    assert got.endswith("build " + want), (got, want, "lib/libnrc_hpm.so is stale: run `python __graft_entry__.py` (make -C nrc-hpm-renderer_amd/csrc)")
+    assert api.build_id() == want
+
+
+def test_shipped_kernels_have_no_scratch_in_the_camera_kernels_and_no_swizzled_packed_fp32():
+    """The checks of DESIGN.md section 7.1 on the code objects INSIDE the shipped library (round 3 made them on a fresh compile of the
+    sources and passed while lib/ held 21 such instructions): no v_pk_mov_b32, no packed FP32 instruction of any kind with op_sel: /
+    neg_lo: / neg_hi: operand modifiers (op_sel_hi:[...] is how the hand-written f2 arithmetic broadcasts a scalar operand: allowed),
+    0 bytes of scratch in k_gen_rays / k_mc_render, and every kernel that can be co-resident with the camera kernels raises its wave
+    priority (s_setprio) so that none outranks them."""
     import subprocess
     import tempfile
-    src = os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc", "nrc_integrator.hip")
+    swizzled = re.compile(r"v_pk_[a-z0-9_]*_f32[^\n]*\b(op_sel:|neg_hi:|neg_lo:)")
+    # kernels that never run beside a frame (set-up, metrics, tests) or run at the default priority, below the camera kernels
+    no_prio_ok = ("k_flight_table", "k_query_layout", "k_compare_", "k_test_", "k_publish_loss")
+    n_kernels = n_camera = 0
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "integ.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                               "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
-        text = open(out).read()
-    mk = open(os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc", "Makefile")).read()
-    assert "-fno-slp-vectorize $(EXTRA)" in mk and "STRICT = -ffp-contract=off" in mk      # (the flags compiled here are the Makefile's)
-    # the cause of round 2's non-determinism (DESIGN.md section 7.1): packed-FP32 code the SLP vectoriser made of new_ray_dir, with
-    # operand swizzles -- no v_pk_mov_b32 and no op_sel / neg_hi on a packed FP32 instruction may be left in the camera kernels
-    # (op_sel_hi:[...] is how the hand-written f2 arithmetic broadcasts a scalar operand: allowed)
-    swizzled = re.compile(r"v_pk_(fma|mul|add)_f32[^\n]* (op_sel:|neg_hi:|neg_lo:)")
-    assert "v_pk_mov_b32" not in text and not swizzled.search(text)
-    # ... nor in the MLP kernels (the generic-model kernels had a few)
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "mlp.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--cuda-device-only",
-                               "-S", "-o", out, os.path.join(ROOT, "nrc-hpm-renderer_amd", "csrc", "nrc_mlp.hip")], stderr=subprocess.DEVNULL)
-        mlp = open(out).read()
-    assert "v_pk_mov_b32" not in mlp and not swizzled.search(mlp)
-    seen = 0
-    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text):
-        if any(k in m.group(1) for k in ("k_gen_rays", "k_mc_render")):
-            seen += 1
-            assert int(m.group(2)) == 0, (m.group(1), m.group(2))
-    assert seen >= 4          # k_gen_rays<0/1>, k_mc_render<0/1>  (k_prep_train -- 16 384 rays, latency-bound -- keeps 36 bytes)
+        objs = shipped_code_objects(d)
+    assert len(objs) == 3                                    # nrc_mlp, nrc_integrator, nrc_api
+    for dis, notes in objs:
+        assert "v_pk_mov_b32" not in dis
+        bad = swizzled.search(dis)
+        assert bad is None, bad.group(0)
+        for name, body in kernel_bodies(dis).items():
+            n_kernels += 1
+            if "s_setprio" not in body:
+                assert any(k in name for k in no_prio_ok), name
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            if any(k in m.group(1) for k in ("k_gen_rays", "k_mc_render")):
+                n_camera += 1
+                assert int(m.group(2)) == 0, (m.group(1), m.group(2))
+    assert n_kernels >= 70 and n_camera >= 4       # k_gen_rays<0/1>, k_mc_render<0/1>  (k_prep_train -- 16 384 rays, latency-bound -- keeps a few bytes)
+    # the workaround was validated with this compiler; another one has to be stressed again (tests/test_gpu_stress.py, tools/stress*.sh)
+    ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
+    assert "HIP version: 7.2" in ver, "re-validate -fno-slp-vectorize + s_setprio (DESIGN.md 7.1) on this compiler: " + ver.splitlines()[0]

@@ -737,6 +737,49 @@ def test_hot_tiles_are_started_first_and_change_no_pixel(api, orc, sc, cloud16, 
     assert o["info"][3, 2] == 1.0 and o["info"][:8, :8].sum() == 1.0
 
 
+# pixels (1080, 90) and (1083, 90) of a 1920x1080 frame -- the same 8x8 tile -- both start in RNG state 0 with this frame random
+# (tests/rng_search.py pair 1920 1080): k_hot_tiles, which appends one entry per capped PIXEL, lists tile (135, 11) twice
+PAIR_STATE0_FRAME_RANDOM = [0.6137924194335938, 0.015384615398943424, 0.75, 0.125]
+
+
+def test_a_tile_listed_twice_in_the_hot_list_is_still_traced_once(api, orc, sc, cloud16, torch_gpu):
+    """two capped pixels in one tile gave two hot waves on that tile; k_mc_render blends in place (out = b * col + (1 - b) *
+    prev), so the tile could be blended twice.  The later duplicate now leaves (camera_wave_tile): the blended Monte-Carlo frame and
+    the gen_rays outputs of that tile row are the oracle's, bit for bit"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import rng_search
+    W, H = 1920, 1080
+    for px in ((1080, 90), (1083, 90)):
+        assert float(rng_search.init_random(px[0], px[1], W, H, PAIR_STATE0_FRAME_RANDOM)) == 0.0
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H)
+    rows = (88, 96)
+    mc = api.McHpmRenderer(W, H, 8, True, cam, scene)
+    ref = np.zeros((H, W, 4), np.float32)
+    for k, fr in enumerate((FRAME_RANDOM, PAIR_STATE0_FRAME_RANDOM)):      # blend factors 1, 1/2: the second frame reads the first
+        mc.SetFrameRandom(fr)
+        mc.Render()
+        orc.mc_render(scene, cam, W, H, 8, fr, blend=1.0 / (k + 1), out=ref, rows=rows, threads=8)
+    img = mc.GetImage().cpu().numpy()
+    mc.Destroy()
+    assert same_bits(img[rows[0]:rows[1]], ref[rows[0]:rows[1]])
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=21)
+    nrc = api.NeuralRadianceCache(cfg)
+    ren = api.NrcHpmRenderer(W, H, False, cam, cfg, scene, nrc)
+    ren.SetFrameRandom(PAIR_STATE0_FRAME_RANDOM)
+    ren.Render(None, False)
+    tiles, n, ahead = ren.HotTiles()
+    assert n == 2 and tiles == [(135, 11), (135, 11)] and not ahead      # listed twice (one entry per capped pixel) ...
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, PAIR_STATE0_FRAME_RANDOM, rows=rows, threads=8)
+    prim = ren.Buffer("primary").cpu().numpy().reshape(H, W, 4)
+    info = ren.Buffer("info").cpu().numpy().reshape(H, W)
+    assert same_bits(prim[rows[0]:rows[1]], o["primary"][rows[0]:rows[1]]) and same_bits(info[rows[0]:rows[1]], o["info"][rows[0]:rows[1]])
+    assert info[90, 1080] == 1.0 and info[90, 1083] == 1.0               # ... both pixels scattered at their entry points
+    ren.Destroy()
+    nrc.Destroy()
+
+
 def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, torch_gpu, monkeypatch):
     """nrc/render.comp as the epilogue of the inference launch (NRC_FUSED_COMPOSITE=1; the queries are tile-major inside the
     renderer) blends the same image, bit for bit, as k_composite behind the launch -- trained, blended frames of a ragged size"""

@@ -103,7 +103,9 @@ def test_hpm_scene_update_rotates_only_the_dynamic_preset(sc):
 
 def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
     """`python bench.py --gpus 2` without a launcher environment on a box with fewer than two GPUs: a non-zero exit and no result
-    line -- never one rank under an N-GPU label (no GPU is touched: the device count comes from the KFD topology / torch's count)"""
+    line -- never one rank under an N-GPU label.  The launching parent must not touch the HIP runtime (it starts the ranks): it counts
+    devices in the KFD topology only and refuses there; without a KFD view (this container) it trusts --gpus and every rank without a
+    device fails by itself"""
     import os
     import subprocess
     import sys
@@ -114,4 +116,7 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NRC_BENCH_SHARED_GPU")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120, env=env, cwd=root)
-    assert r.returncode == 2 and r.stdout.strip() == "" and "refusing" in r.stderr
+    assert r.returncode != 0 and r.stdout.strip() == "" and ("refusing" in r.stderr or "has no device" in r.stderr)
+    src = open(os.path.join(root, "bench.py")).read()
+    launcher = src[src.index("def visible_gpus"):src.index("# ---------------------------------------------------------------------------------------------------------------- workloads")]
+    assert "import torch" not in launcher and "torch.cuda" not in launcher
