@@ -149,6 +149,15 @@ int nrc_cache_set_stream(nrc_cache_t* c, void* stream);
  * training kernels are ordered on -- the exchange (all-reduce) must be issued on it */
 typedef void (*nrc_grad_hook)(void* user, float* d_grad, uint32_t n_params, float* d_loss, void* stream);
 int nrc_cache_set_grad_hook(nrc_cache_t* c, nrc_grad_hook hook, void* user);
+/* Collectives of a multi-GPU frame that are NOT the gradient exchange -- the frame gather and the metric reduction below -- go through
+ * the communicator nrc_cache_comm_init made; a cache without one can be given the caller's transport instead (the tests' gloo
+ * rehearsal, a host that brings MPI): allreduce sums n doubles in place over all ranks, allgather fills d_recv = [world][bytes_per_rank]
+ * with every rank's d_send; both work on device memory and return 0 on success.  The library has waited for `stream` (a hipStream_t)
+ * when it calls a hook, so a transport that stages through host memory may read the buffers at once; what the hook writes must be
+ * complete, or ordered on `stream`, when it returns. */
+typedef int (*nrc_allreduce_f64_fn)(void* user, double* d_buf, uint32_t n, void* stream);
+typedef int (*nrc_allgather_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);
+int nrc_cache_set_collective_hooks(nrc_cache_t* c, int rank, int world, nrc_allreduce_f64_fn allreduce, nrc_allgather_fn allgather, void* user);
 /* checkpointing: which = 0 master weights, 1 EMA weights, 2 Adam m, 3 Adam v, 4 gradient (host fp32 arrays) */
 int nrc_cache_get_params(nrc_cache_t* c, int which, float* host_out);
 int nrc_cache_set_params(nrc_cache_t* c, int which, const float* host_in);
@@ -239,6 +248,14 @@ int nrc_renderer_release_frame(nrc_renderer_t* r, void* consumer_stream);
 int nrc_renderer_is_blending(nrc_renderer_t* r);
 /* ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493): scan-line EXR, FLOAT RGBA */
 int nrc_renderer_export_exr(nrc_renderer_t* r, const char* path);
+/* Multi-GPU (new: SURVEY.md section 8e, "gather tiles to rank 0 or reduce only the metrics").  A frame sharded by nrc_tile is put
+ * together again: every rank of the frame calls, every rank receives the whole [global_h][global_w] RGBA32F image in d_global_rgba
+ * (device).  One all-gather of the ranks' column strips through the cache's communicator (nrc_cache_comm_init, or the hooks of
+ * nrc_cache_set_collective_hooks) and a de-interleave kernel; bit-identical to the frame one GPU renders.  An unsharded renderer
+ * copies its framebuffer.  export_exr_gathered is ExportOutputImageToFile (src/NrcHpmRenderer.cu:437-493) of such a run: collective,
+ * rank `root` writes the file. */
+int nrc_renderer_gather_frame(nrc_renderer_t* r, float* d_global_rgba, void* stream);
+int nrc_renderer_export_exr_gathered(nrc_renderer_t* r, const char* path, int root);
 /* EvaluateTimestampQueries + GetFrameTimeMS (src/NrcHpmRenderer.cu:495-530,556-559): synchronises; stage_ms may be
  * NULL or float[8] = {clear(0), gen_rays, prep_infer(0: fused into gen_rays), train, prep_train, inference, composite,
  * total}.  The renderer pipelines frames over four streams (train-ray generation, training, inference + compositing of
@@ -323,6 +340,13 @@ int nrc_mc_renderer_destroy(nrc_mc_renderer_t* r);
  * device RGBA32F images of w*h pixels; result5 (host) = {mse, refMean, ownMean, ownVar, validPixelCount} */
 int nrc_compare_images(const float* d_ref_rgba, const float* d_own_rgba, uint32_t w, uint32_t h, void* stream,
                        float result5[5]);
+
+/* the same Result for a frame sharded over ranks (Reference::CompareNrc / CompareMc of a multi-GPU run, src/Reference.cpp:72-107):
+ * every rank passes ITS pixels of the reference and of its image (n_local_pixels, any partition of the frame), the five sums are
+ * formed locally in fp64 and summed over the ranks with two small all-reduces (4 + 1 doubles) through `comm`'s communicator; every
+ * rank receives the whole frame's Result.  Equal to nrc_compare_images of the gathered frame up to the rounding of the fp64 sums. */
+int nrc_compare_images_sharded(nrc_cache_t* comm, const float* d_ref_local_rgba, const float* d_own_local_rgba, uint32_t n_local_pixels,
+                               void* stream, float result5[5]);
 
 /* device-resident RGBA32F image [h][w] for nrc_compare_images: a copy of host_rgba (NULL: zeros) -- the reference image that
  * Reference::GenRefImages loads from reference/<scene>/0.exr into a VkImage (src/Reference.cpp:608-660) */

@@ -327,6 +327,11 @@ public:
     void CommInit(const void* uniqueId128, int rank, int world) { nrc_check(nrc_cache_comm_init(h_, uniqueId128, rank, world)); }
     void CommInfo(int* rank, int* world) const { nrc_check(nrc_cache_comm_info(h_, rank, world)); }
     bool CommSparse() const { return nrc_cache_comm_sparse(h_) != 0; }      // HashGrid table gradient exchanged as lists
+    // frame gather / metric reduction over a transport of the host's own (a cache without CommInit): include/nrc_hpm.h
+    void SetCollectiveHooks(int rank, int world, nrc_allreduce_f64_fn allreduce, nrc_allgather_fn allgather, void* user)
+    {
+        nrc_check(nrc_cache_set_collective_hooks(h_, rank, world, allreduce, allgather, user));
+    }
 
 private:
     nrc_cache_t* h_ = nullptr;
@@ -338,6 +343,8 @@ public:
                    const nrc_scene& hpmScene, NeuralRadianceCache& nrc, void* stream = nullptr, const nrc_tile* tile = nullptr)
     {
         nrc_check(nrc_renderer_create(width, height, blend ? 1 : 0, camera, &appConfig.c, &hpmScene, nrc.Handle(), tile, stream, &h_));
+        if (tile) tile_ = *tile;
+        else { tile_.x_offset = 0; tile_.x_stride = 1; tile_.global_w = width; tile_.global_h = height; tile_.x_block = 1; }
     }
     // the reference's own argument list (include/engine/graphics/renderer/NrcHpmRenderer.hpp:19-26)
     NrcHpmRenderer(uint32_t width, uint32_t height, bool blend, const Camera* camera, const AppConfig& appConfig,
@@ -359,7 +366,17 @@ public:
     {
         if (h_) { nrc_renderer_destroy(h_); h_ = nullptr; }
     }
-    void ExportOutputImageToFile(void* /*queue*/, const std::string& filePath) const { nrc_check(nrc_renderer_export_exr(h_, filePath.c_str())); }
+    // src/NrcHpmRenderer.cu:437-493.  A renderer that draws one tile of a multi-GPU frame exports the WHOLE frame: the call is then
+    // collective over the frame's ranks (all-gather through the cache's communicator) and rank `root` writes the file.
+    void ExportOutputImageToFile(void* /*queue*/, const std::string& filePath, int root = 0) const
+    {
+        if (IsSharded()) nrc_check(nrc_renderer_export_exr_gathered(h_, filePath.c_str(), root));
+        else nrc_check(nrc_renderer_export_exr(h_, filePath.c_str()));
+    }
+    // the whole [global_h][global_w] RGBA32F frame into dGlobalImage (device) on every rank of the frame; collective when sharded
+    void GatherFrame(float* dGlobalImage, void* stream) const { nrc_check(nrc_renderer_gather_frame(h_, dGlobalImage, stream)); }
+    bool IsSharded() const { return tile_.x_stride > 1; }
+    const nrc_tile& Tile() const { return tile_; }
     void EvaluateTimestampQueries() { (void)nrc_renderer_frame_time_ms(h_, stage_ms_); }
     const float* GetImage() const { return nrc_renderer_framebuffer(h_); }     // RGBA32F [height][width]
     const float* GetImage(void* consumerStream) const { return nrc_renderer_framebuffer_on(h_, consumerStream); }
@@ -377,6 +394,7 @@ public:
 
 private:
     nrc_renderer_t* h_ = nullptr;
+    nrc_tile tile_{};
     float stage_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -436,14 +454,36 @@ public:
         float GetCV() const { return std::sqrt(ownVar) / ownMean; }
     };
 
+    // Multi-GPU (new): with `tile` (this rank's shard of a tile->global_w x tile->global_h frame; width = the LOCAL column count) and
+    // `comm` (the cache whose communicator -- nrc_cache_comm_init or collective hooks -- spans the frame's ranks) the reference image is
+    // cut to this rank's columns and Compare* reduce the five sums over the ranks (nrc_compare_images_sharded): every rank gets the
+    // whole frame's Result.  The reference image itself must exist then (generate it with a single-GPU run).
     Reference(uint32_t width, uint32_t height, const AppConfig& appConfig, const HpmScene& scene, void* queue,
-              const std::string& referenceRoot = "reference/", uint32_t generateFrames = 8192)
+              const std::string& referenceRoot = "reference/", uint32_t generateFrames = 8192, const nrc_tile* tile = nullptr,
+              NeuralRadianceCache* comm = nullptr)
         : m_Width(width), m_Height(height), m_Queue(queue),
-          m_RefCamera(vec3(64.0f, 0.0f, 0.0f), vec3(-1.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), static_cast<float>(width) / static_cast<float>(height),
-                      radians(60.0f), 0.1f, 100.0f)
+          m_RefCamera(vec3(64.0f, 0.0f, 0.0f), vec3(-1.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f),
+                      static_cast<float>(tile ? tile->global_w : width) / static_cast<float>(tile ? tile->global_h : height), radians(60.0f), 0.1f, 100.0f),
+          m_Comm(comm)
     {
         const std::string dir = referenceRoot + std::to_string(appConfig.scene.id) + "/";
         const std::string path = dir + "0.exr";
+        if (tile && tile->x_stride > 1) {
+            if (!comm) throw std::runtime_error("SkyRenderer ERROR: a sharded Reference needs the cache whose communicator spans the frame's ranks");
+            uint32_t w = 0, h = 0;
+            const std::vector<float> rgba = LoadExrRGBA(path, &w, &h);      // throws when the file is missing
+            if (w != tile->global_w || h != tile->global_h) throw std::runtime_error("SkyRenderer ERROR: " + path + " has wrong resolution");
+            const uint32_t block = tile->x_block ? tile->x_block : 1u;
+            std::vector<float> local((size_t)width * height * 4);
+            for (uint32_t y = 0; y < height; y++)
+                for (uint32_t i = 0; i < width; i++) {
+                    const uint32_t gx = (tile->x_offset + (i / block) * tile->x_stride) * block + i % block;      // include/nrc_hpm.h: nrc_tile
+                    std::memcpy(&local[((size_t)y * width + i) * 4], &rgba[((size_t)y * w + gx) * 4], 16);
+                }
+            nrc_check(nrc_image_create(width, height, local.data(), &m_RefImage));
+            m_Sharded = true;
+            return;
+        }
         if (!std::filesystem::is_directory(dir)) {
             std::printf("Reference folder for scene %u was not found. Creating reference images\n", appConfig.scene.id);
             McHpmRenderer refRenderer(width, height, 64, true, &m_RefCamera, scene, queue);
@@ -490,7 +530,8 @@ private:
     Result Compare(const float* dOwnImage)
     {
         float r[5];
-        nrc_check(nrc_compare_images(m_RefImage, dOwnImage, m_Width, m_Height, m_Queue, r));
+        if (m_Sharded) nrc_check(nrc_compare_images_sharded(m_Comm->Handle(), m_RefImage, dOwnImage, m_Width * m_Height, m_Queue, r));
+        else nrc_check(nrc_compare_images(m_RefImage, dOwnImage, m_Width, m_Height, m_Queue, r));
         Result result;
         result.mse = r[0]; result.refMean = r[1]; result.ownMean = r[2]; result.ownVar = r[3]; result.validPixelCount = (uint32_t)r[4];
         std::printf("MSE: %f | rBias: %f | rVar: %f\n", result.mse, result.GetRelBias(), result.GetRelVar());      // Log::Info, :99-103
@@ -500,6 +541,8 @@ private:
     void* m_Queue;
     Camera m_RefCamera;
     float* m_RefImage = nullptr;
+    NeuralRadianceCache* m_Comm = nullptr;
+    bool m_Sharded = false;
 };
 
 }  // namespace en

@@ -56,6 +56,8 @@ class NrcTile(C.Structure):
 
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)
+ALLREDUCE_F64_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)
+ALLGATHER_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/nrc_hpm.h declares (tests/test_abi.py checks the built library exports all of them)
 ABI_SYMBOLS = [
@@ -63,6 +65,7 @@ ABI_SYMBOLS = [
     "nrc_cache_create", "nrc_cache_init", "nrc_cache_init_events", "nrc_cache_infer_and_train", "nrc_cache_destroy", "nrc_cache_get_loss",
     "nrc_cache_get_loss_blocking", "nrc_cache_get_loss_async", "nrc_cache_comm_info", "nrc_cache_comm_time_exchange", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
+    "nrc_cache_set_collective_hooks", "nrc_renderer_gather_frame", "nrc_renderer_export_exr_gathered", "nrc_compare_images_sharded",
     "nrc_renderer_set_cost_order", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order", "nrc_renderer_set_hot_tiles", "nrc_renderer_hot_tiles",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
@@ -387,6 +390,55 @@ class NeuralRadianceCache:
         self._hook_keep = GRAD_HOOK(tramp)
         _check(self.L.nrc_cache_set_grad_hook(self.h, self._hook_keep, None))
 
+    def SetCollectiveHooks(self, rank, world, group=None):
+        """the frame gather / metric reduction of a cache WITHOUT a native RCCL communicator go through torch.distributed (any backend:
+        the gloo rehearsals of tests/ stage through host memory).  nrc_cache_set_collective_hooks."""
+        import torch
+        import torch.distributed as dist
+
+        def on(stream):
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0)))
+
+        def staged(t):
+            if dist.get_backend(group) == "nccl":
+                return t
+            return t.cpu()      # host-staged transport (the library has waited for its own work on the stream: include/nrc_hpm.h)
+
+        def allreduce(_user, buf, n, stream):
+            try:
+                with on(stream):
+                    t = _wrap_device(buf, int(n) * 8, torch.float64, (int(n),))
+                    h = staged(t)
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                    if h is not t:
+                        t.copy_(h)
+                        torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception as e:      # noqa: BLE001 -- a Python exception must not unwind through the C frames
+                print("collective hook (all-reduce) failed: %r" % (e,))
+                return 1
+
+        def allgather(_user, send, recv, nbytes, stream):
+            try:
+                with on(stream):
+                    s_ = _wrap_device(send, int(nbytes), torch.uint8, (int(nbytes),))
+                    r_ = _wrap_device(recv, int(nbytes) * world, torch.uint8, (world, int(nbytes)))
+                    if dist.get_backend(group) == "nccl":
+                        dist.all_gather_into_tensor(r_.view(-1), s_, group=group)
+                    else:
+                        parts = [torch.empty(int(nbytes), dtype=torch.uint8) for _ in range(world)]
+                        hs = staged(s_)
+                        dist.all_gather(parts, hs, group=group)
+                        r_.copy_(torch.stack(parts))
+                        torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception as e:      # noqa: BLE001
+                print("collective hook (all-gather) failed: %r" % (e,))
+                return 1
+
+        self._coll_keep = (ALLREDUCE_F64_HOOK(allreduce), ALLGATHER_HOOK(allgather))
+        _check(self.L.nrc_cache_set_collective_hooks(self.h, C.c_int(rank), C.c_int(world), self._coll_keep[0], self._coll_keep[1], None))
+
     def GetParams(self, which=0):
         out = np.zeros(self.ParamCount(), np.float32)
         _check(self.L.nrc_cache_get_params(self.h, C.c_int(which), out.ctypes.data_as(C.c_void_p)))
@@ -433,6 +485,7 @@ class NrcHpmRenderer:
         self._scene = make_c_scene(hpmScene)
         cam = make_c_camera(camera)
         t = None
+        self.tile = tuple(int(x) for x in tile) if tile is not None else None
         if tile is not None:
             t = NrcTile(*[int(x) for x in tile])
         h = C.c_void_p()
@@ -473,8 +526,22 @@ class NrcHpmRenderer:
         r = (C.c_float * 4)(*[float(x) for x in r4])
         _check(self.L.nrc_renderer_set_frame_random(self.h, r))
 
-    def ExportOutputImageToFile(self, queue, filePath):
-        _check(self.L.nrc_renderer_export_exr(self.h, filePath.encode()))
+    def ExportOutputImageToFile(self, queue, filePath, root=0):
+        """src/NrcHpmRenderer.cu:437-493.  A sharded renderer (tile of a multi-GPU frame) exports the WHOLE frame: collective over the
+        frame's ranks, rank `root` writes the file"""
+        if self.tile is not None and self.tile[1] > 1:
+            _check(self.L.nrc_renderer_export_exr_gathered(self.h, filePath.encode(), C.c_int(root)))
+        else:
+            _check(self.L.nrc_renderer_export_exr(self.h, filePath.encode()))
+
+    def GatherFrame(self, stream=None):
+        """the whole [global_h, global_w, 4] frame of a sharded renderer as a new torch CUDA tensor, on every rank (collective: one
+        all-gather through the cache's communicator + a de-interleave kernel); an unsharded renderer returns a copy of its image"""
+        import torch
+        gw, gh = (self.tile[2], self.tile[3]) if self.tile is not None else (self.width, self.height)
+        out = torch.empty((gh, gw, 4), device="cuda", dtype=torch.float32)
+        _check(self.L.nrc_renderer_gather_frame(self.h, _dev_ptr(out), _stream_ptr(stream)))
+        return out
 
     def GetFrameTimeMS(self):
         return float(self.L.nrc_renderer_frame_time_ms(self.h, None))
@@ -677,6 +744,16 @@ def CompareImages(ref, own, stream=None):
     h, w = ref.shape[0], ref.shape[1]
     _check(load_library().nrc_compare_images(_dev_ptr(ref), _dev_ptr(own), C.c_uint32(w), C.c_uint32(h),
                                              _stream_ptr(stream), r))
+    return dict(mse=r[0], ref_mean=r[1], own_mean=r[2], own_var=r[3], valid=r[4])
+
+
+def CompareImagesSharded(nrc, ref_local, own_local, stream=None):
+    """Reference::Result of a frame sharded over ranks: every rank passes ITS pixels (torch CUDA RGBA32F [h, local_w, 4]) and receives
+    the whole frame's metrics -- five local fp64 sums, two small all-reduces through `nrc`'s communicator (collective call)"""
+    r = (C.c_float * 5)()
+    n = int(ref_local.shape[0]) * int(ref_local.shape[1])
+    assert tuple(ref_local.shape) == tuple(own_local.shape) and ref_local.is_contiguous() and own_local.is_contiguous()
+    _check(load_library().nrc_compare_images_sharded(nrc.h, _dev_ptr(ref_local), _dev_ptr(own_local), C.c_uint32(n), _stream_ptr(stream), r))
     return dict(mse=r[0], ref_mean=r[1], own_mean=r[2], own_var=r[3], valid=r[4])
 
 

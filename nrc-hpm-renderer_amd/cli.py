@@ -8,6 +8,11 @@ The 17 positional arguments are the reference's (src/AppConfig.cpp:154-182); wit
 camera against a reference image, one line `frame mse relBias CV` in `output/ <config-name>/log.txt` (the literal space is the
 reference's, src/main.cu:240,446).  The reference image is `--reference FILE.exr` or, like Reference::GenRefImages
 (src/Reference.cpp:566-606), a blended MC render (PATH_LENGTH 64, --ref-frames frames).
+
+Multi-GPU (new): `--gpus N` starts N ranks (python -m torch.distributed.run; or start the module under that
+launcher yourself).  The frame is sharded by interleaved strips of 8 pixel columns, the MLP gradients are all-reduced every training
+step, the per-frame metrics are reduced over the ranks (five fp64 sums, nrc_compare_images_sharded) and `--export` writes the WHOLE
+frame from rank 0 (nrc_renderer_gather_frame).  Rank 0 owns the log.  NRC_CLI_SHARED_GPU=1 rehearses the ranks on one device (gloo).
 """
 import argparse
 import math
@@ -33,10 +38,27 @@ def main(argv=None):
     ap.add_argument("--ref-frames", type=int, default=256)
     ap.add_argument("--output", default="output")
     ap.add_argument("--export", default=None, help="write the final NRC image to this EXR")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks the frame is sharded over (one GPU each)")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # start the ranks before anything touches the GPU in this process (a process that has initialised HIP must not spawn them)
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "nrc_hpm_renderer_amd.cli"] + list(sys.argv[1:] if argv is None else argv)
+        return subprocess.call(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
     import torch
-    from . import api, io_exr, io_vdb, scene as sc
+    from . import api, io_exr, io_vdb, parallel, scene as sc
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and "RANK" in os.environ:
+        raise SystemExit("SkyRenderer ERROR: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    shared_gpu = os.environ.get("NRC_CLI_SHARED_GPU") == "1"
 
     if args.config and len(args.config) != 17:
         raise SystemExit("SkyRenderer ERROR: Argument count does not match requirements for AppConfig")
@@ -50,13 +72,29 @@ def main(argv=None):
     scene = sc.make_scene(density, scene_id=cfg.scene_id, env=env)
     W, H = args.width, args.height
     camera = sc.make_camera(aspect=W / H)            # src/main.cu:180-187
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(0 if shared_gpu else int(os.environ.get("LOCAL_RANK", "0")))
+    tile, lw, cols = None, W, None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if shared_gpu else "nccl", rank=rank, world_size=world)
+        tile, lw = parallel.column_tile(rank, world, W, H), parallel.local_width(rank, world, W)
+        cols = torch.from_numpy(parallel.rank_columns(rank, world, W)).cuda()
+        if (lw * H) % 16:
+            raise SystemExit("SkyRenderer ERROR: rank %d's %d x %d tile is not a multiple of 16 pixels" % (rank, lw, H))
 
     nrc = api.NeuralRadianceCache(cfg)
-    nrc_renderer = api.NrcHpmRenderer(W, H, False, camera, cfg, scene, nrc)
+    if world > 1:
+        # one exchange step per train batch: the library's own RCCL all-reduce (one device per rank), or the gloo hook of a rehearsal
+        parallel.attach_gradient_allreduce(nrc, world, native=not shared_gpu)
+        if shared_gpu:
+            nrc.SetCollectiveHooks(rank, world)      # (with the native communicator the gather / metric reduction use RCCL too)
+    nrc_renderer = api.NrcHpmRenderer(lw, H, False, camera, cfg, scene, nrc, tile=tile)
     out_dir = os.path.join(args.output, " " + cfg.GetName())
-    os.makedirs(out_dir, exist_ok=True)
-    log = open(os.path.join(out_dir, "log.txt"), "w")
+    log = None
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        log = open(os.path.join(out_dir, "log.txt"), "w")
 
     ref = None
     if args.benchmark:
@@ -64,13 +102,15 @@ def main(argv=None):
             ref = torch.from_numpy(io_exr.read_exr(args.reference)).cuda()
             if ref.shape[0] != H or ref.shape[1] != W:
                 raise SystemExit("SkyRenderer ERROR: reference image resolution mismatch")     # src/Reference.cpp:627
+            if cols is not None:
+                ref = ref[:, cols, :].contiguous()      # this rank's columns
         else:
-            mc = api.McHpmRenderer(W, H, 64, True, camera, scene)
+            mc = api.McHpmRenderer(lw, H, 64, True, camera, scene, tile=tile)      # (every rank blends its own columns)
             for _ in range(args.ref_frames):
                 mc.Render()
             ref = mc.GetImage().clone()
             mc.Destroy()
-        eval_renderer = api.NrcHpmRenderer(W, H, False, camera, cfg, scene, nrc)        # Reference::CompareNrc renders with train=false
+        eval_renderer = api.NrcHpmRenderer(lw, H, False, camera, cfg, scene, nrc, tile=tile)        # Reference::CompareNrc renders with train=false
 
     for frame in range(args.frames):
         nrc_renderer.Render(None, True)
@@ -80,19 +120,27 @@ def main(argv=None):
             break
         if ref is not None:
             eval_renderer.Render(None, False)
-            r = api.CompareImages(ref, eval_renderer.GetImage())
+            if world > 1:
+                r = api.CompareImagesSharded(nrc, ref, eval_renderer.GetImage().contiguous())      # collective: the whole frame's Result
+            else:
+                r = api.CompareImages(ref, eval_renderer.GetImage())
             rel_bias = (r["own_mean"] - r["ref_mean"]) / r["ref_mean"] if r["ref_mean"] else 0.0
             cv = math.sqrt(max(r["own_var"], 0.0)) / r["own_mean"] if r["own_mean"] else 0.0
-            log.write("%d %g %g %g\n" % (frame, r["mse"], rel_bias, cv))
-        if frame % 16 == 0 or frame == args.frames - 1:
+            if log is not None:
+                log.write("%d %g %g %g\n" % (frame, r["mse"], rel_bias, cv))
+        if rank == 0 and (frame % 16 == 0 or frame == args.frames - 1):
             print("frame %d: loss %.5f, %.3f ms" % (frame, loss, nrc_renderer.GetFrameTimeMS()))
-    log.close()
+    if log is not None:
+        log.close()
     if args.export:
-        nrc_renderer.ExportOutputImageToFile(None, args.export)
+        nrc_renderer.ExportOutputImageToFile(None, args.export)      # sharded: collective, rank 0 writes the whole frame
     nrc_renderer.Destroy()
     if ref is not None:
         eval_renderer.Destroy()
     nrc.Destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

@@ -335,7 +335,9 @@ __device__ __forceinline__ Addr2 fetch2_addr(const C& c, V3 dir, V3 start, float
     const uint32_t x1 = (uint32_t)fx.y, y1 = (uint32_t)fy.y, z1 = (uint32_t)fz.y;
     const uint32_t idx0 = index24(z0, s.ny, y0, s.nx, x0);
     const uint32_t idx1 = index24(z1, s.ny, y1, s.nx, x1);
-    if (c.occ != nullptr) {      // occupancy bit of the voxel's cell from LDS: an empty cell's byte is 0 without asking memory
+    {      // occupancy bit of the voxel's cell from LDS: an empty cell's byte is 0 without asking memory.  (The table always exists --
+           // Scene::build_occupancy_bits; all ones under NRC_NO_OCCUPANCY --: a test for it here is a branch and four mask merges in
+           // every tracking loop, and scalar instructions cost a SIMD as much issue time as vector ones: tools/issue_mix.hip)
         const uint32_t sh = s.occ_shift;
         uint32_t c0 = index24(z0 >> sh, s.occ_gy, y0 >> sh, s.occ_gx, x0 >> sh);
         uint32_t c1 = index24(z1 >> sh, s.occ_gy, y1 >> sh, s.occ_gx, x1 >> sh);
@@ -665,6 +667,15 @@ __device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool al
 // the overlap is gone.  Lanes that have finished keep their results and issue no gathers (offset 2^31).
 // UNI: the call sits in wave-uniform control flow (every lane of the wave executes it, `valid` says which lanes have a walk), so
 // the lanes without a walk can help with the thin trips at the end (ratio_pairs)
+// Round 4: the predicates the loop carries from trip to trip (who still walks, whether the located trip's collisions lie inside the
+// segment) are 64-bit LANE MASKS in scalar registers, not per-lane bools.  A loop-carried bool is a divergent i1 phi, which the
+// compiler merges with three scalar instructions per predicate, per loop header and per exit (s_andn2 / s_and / s_or with exec:
+// 30 of them in front of every delta trip) -- and a scalar instruction costs a SIMD as much issue time as a vector one here
+// (tools/issue_mix.hip: at five waves per SIMD a v_fma_f32 1.6 clocks, a v_fma_f32 + s_and_b64 pair 3.6).  A uniform mask is an
+// ordinary 64-bit value: its phi is a copy.  lane_bool() hands it to v_cndmask as the select mask (no instruction).
+__device__ __forceinline__ bool lane_bool(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ unsigned long long lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 template <bool UNI = false, class C>
 __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
 {
@@ -674,46 +685,50 @@ __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid 
     const float inv = c.sc.inv_max_density;
     float tr = 1.0f;
     float rng = c.rng;
-    bool alive = valid;
+    unsigned long long alive_m = lane_mask(valid);
     RatioTrip a = ratio_trip(rng, 0.0f, t_max, inv);
+    unsigned long long live1_m = lane_mask(a.live1), second_m = lane_mask(a.second);
     Addr2 ia = fetch2_addr(c, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
     float bs = rng, bt = 0.0f;                 // base of the located trip `a`: chain value and position before its first draw
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
-        rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
-        alive &= a.live1;
+        rng = lane_bool(alive_m & ~live1_m) ? a.s1 : rng;             // collision 1 beyond the segment: the walk ends on this draw
+        alive_m &= live1_m;
 #ifdef NRC_DIAG_CUT_TAIL
-        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
+        if (__popcll(alive_m) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
 #else
-        if (__ballot(alive) == 0ull) break;
+        if (alive_m == 0ull) break;
 #endif
 #if NRC_PAIR_TAIL
         if constexpr (UNI) {
-            const unsigned long long am = __ballot(alive);
-            if (__popcll(am) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
-                ratio_pairs(c, am, alive, start, dir, t_max, inv, bs, bt, i, tr, rng);
+            if (__popcll(alive_m) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
+                ratio_pairs(c, alive_m, lane_bool(alive_m), start, dir, t_max, inv, bs, bt, i, tr, rng);
                 break;
             }
         }
 #endif
+        const bool alive = lane_bool(alive_m);
         if (alive) NRC_PROF(c, 3);
-        NRC_PROF_LIVE(0, __ballot(alive));
+        NRC_PROF_LIVE(0, alive_m);
         const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
         __builtin_amdgcn_sched_barrier(0);
         const bool last = i + 2 >= 128;
-        const bool more = alive & a.second & !last;
+        const unsigned long long two_m = alive_m & second_m;
+        const unsigned long long more_m = last ? 0ull : two_m;
+        const bool more = lane_bool(more_m);
         const RatioTrip b = ratio_trip(a.s2, a.t2, t_max, inv);      // ... fly while the next trip is located
         const Addr2 ib = fetch2_addr(c, dir, start, b.t1, b.t2, more & b.live1, more & b.live1 & b.second);
         __builtin_amdgcn_sched_barrier(0);
         const f2 dens = fetch2_density(c.sc, fa);
-        const bool two = alive & a.second;
-        c.count(alive ? (a.second ? 2u : 1u) : 0u);
+        c.count(alive ? (lane_bool(second_m) ? 2u : 1u) : 0u);
         tr = alive ? tr * nrc_fmaf_(-dens.x, inv, 1.0f) : tr;
-        tr = two ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
-        rng = (alive & (!a.second | last)) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
-        alive = more;
+        tr = lane_bool(two_m) ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
+        rng = lane_bool(alive_m & ~more_m) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
+        alive_m = more_m;
+        live1_m = lane_mask(b.live1);
+        second_m = lane_mask(b.second);
         bs = a.s2;
         bt = a.t2;
-        a = b;
+        a.s1 = b.s1; a.s2 = b.s2; a.t1 = b.t1; a.t2 = b.t2;
         ia = ib;
     }
     c.rng = rng;
@@ -991,63 +1006,72 @@ __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit,
     const float t_max = length(sub(ex, ro));
     const float inv = c.sc.inv_max_density;
     float rng = c.rng;
-    bool alive = valid, hit = false, vexit = false;
+    // loop-carried predicates as uniform lane masks (see ratio_track)
+    unsigned long long alive_m = lane_mask(valid), hit_m = 0ull, vexit_m = 0ull;
     float t_hit = 0.0f;
     DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
+    unsigned long long live1_m = lane_mask(a.live1), second_m = lane_mask(a.second);
     Addr2 ia = fetch2_addr(c, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
     float bs = rng, bt = 0.0f;                 // base of the located trip `a`
     for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:161); predicated like ratio_track
-        const bool out1 = alive & !a.live1;                          // collision 1 beyond the exit point
-        rng = out1 ? a.s1 : rng;
-        vexit |= out1;
-        alive &= a.live1;
+        const unsigned long long out1_m = alive_m & ~live1_m;        // collision 1 beyond the exit point
+        rng = lane_bool(out1_m) ? a.s1 : rng;
+        vexit_m |= out1_m;
+        alive_m &= live1_m;
 #ifdef NRC_DIAG_CUT_TAIL
-        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
+        if (__popcll(alive_m) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
 #else
-        if (__ballot(alive) == 0ull) break;
+        if (alive_m == 0ull) break;
 #endif
 #if NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
         if constexpr (UNI) {
-            const unsigned long long am = __ballot(alive);
-            if (__popcll(am) <= 31) {        // few walks left: two lanes each (delta_pairs)
-                delta_pairs(c, am, alive, ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
+            if (__popcll(alive_m) <= 31) {        // few walks left: two lanes each (delta_pairs)
+                bool hit = lane_bool(hit_m), vexit = lane_bool(vexit_m);
+                delta_pairs(c, alive_m, lane_bool(alive_m), ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
+                hit_m = lane_mask(hit);
+                vexit_m = lane_mask(vexit);
                 break;
             }
         }
 #endif
+        const bool alive = lane_bool(alive_m);
         if (alive) NRC_PROF(c, 2);
-        NRC_PROF_LIVE(2, __ballot(alive));
+        NRC_PROF_LIVE(2, alive_m);
         const Fetch2 fa = fetch2_load(c, ia);
         __builtin_amdgcn_sched_barrier(0);
         const bool last = i + 2 >= 128;
         const DeltaTrip b = delta_trip(a.a2, a.t2, t_max, inv);      // located ahead; used only if this trip accepts nothing
-        const bool maybe = alive & a.second & !last;
+        const bool maybe = lane_bool(last ? 0ull : (alive_m & second_m));
         const Addr2 ib = fetch2_addr(c, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
         __builtin_amdgcn_sched_barrier(0);
         const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
         c.count(alive ? 1u : 0u);
-        const bool acc1 = alive & (dens.x > a.a1);
-        const bool alive2 = alive & !acc1;
-        const bool out2 = alive2 & !a.second;                        // collision 2 beyond the exit point
-        const bool alive3 = alive2 & a.second;
-        c.count(alive3 ? 1u : 0u);
-        const bool acc2 = alive3 & (dens.y > a.a2);
-        hit |= acc1 | acc2;
-        t_hit = acc1 ? a.t1 : (acc2 ? a.t2 : t_hit);
-        vexit |= out2;
+        const unsigned long long acc1_m = alive_m & lane_mask(dens.x > a.a1);
+        const unsigned long long alive2_m = alive_m & ~acc1_m;
+        const unsigned long long out2_m = alive2_m & ~second_m;      // collision 2 beyond the exit point
+        const unsigned long long alive3_m = alive2_m & second_m;
+        c.count(lane_bool(alive3_m) ? 1u : 0u);
+        const unsigned long long acc2_m = alive3_m & lane_mask(dens.y > a.a2);
+        hit_m |= acc1_m | acc2_m;
+        t_hit = lane_bool(acc1_m) ? a.t1 : (lane_bool(acc2_m) ? a.t2 : t_hit);
+        vexit_m |= out2_m;
         // RNG state of the event that ended the walk: accept 1 -> a1, exit 2 -> s2, accept 2 or the 128-collision cap -> a2
-        rng = acc1 ? a.a1 : rng;
-        rng = out2 ? a.s2 : rng;
-        rng = (alive3 & (acc2 | last)) ? a.a2 : rng;
-        alive = alive3 & !acc2 & !last;
+        rng = lane_bool(acc1_m) ? a.a1 : rng;
+        rng = lane_bool(out2_m) ? a.s2 : rng;
+        rng = lane_bool(last ? alive3_m : acc2_m) ? a.a2 : rng;
+        alive_m = last ? 0ull : (alive3_m & ~acc2_m);
+        live1_m = lane_mask(b.live1);
+        second_m = lane_mask(b.second);
         bs = a.a2;
         bt = a.t2;
-        a = b;
-        ia.i0 = alive ? ib.i0 : 0x80000000u;                         // a lane that has just finished fetches nothing next trip
-        ia.i1 = alive ? ib.i1 : 0x80000000u;
+        a.s1 = b.s1; a.a1 = b.a1; a.s2 = b.s2; a.a2 = b.a2; a.t1 = b.t1; a.t2 = b.t2;
+        const bool go = lane_bool(alive_m);
+        ia.i0 = go ? ib.i0 : 0x80000000u;                            // a lane that has just finished fetches nothing next trip
+        ia.i1 = go ? ib.i1 : 0x80000000u;
     }
     c.rng = rng;
-    *volume_exit = vexit;
+    const bool hit = lane_bool(hit_m);
+    *volume_exit = lane_bool(vexit_m);
     if (hit) return madd(rd, t_hit, ro);
     if constexpr (UNI) {
         if (!valid) return ro;          // no walk: no draw
@@ -1171,12 +1195,19 @@ __host__ __device__ inline size_t query_index(uint32_t w, uint32_t lx, uint32_t 
     return ((size_t)((y >> 3) * tiles_x + (lx >> 3)) << 6) + ((y & 7u) << 3) + (lx & 7u);
 }
 // launch slot (workgroup * 4 + wave) -> the wave's pixel
-__device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_t d, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
+__device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_t d, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr,
+                                                     uint32_t* part_ = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
     const uint32_t row_blocks = camera_row_blocks(fr.w);
-    if (fr.tile_order != nullptr) d = scalar_load(fr.tile_order + d);      // costliest tiles first
+    uint32_t part = 0u;
+    if (fr.tile_order != nullptr) {      // costliest tiles first; the costliest of all as two half tiles (DevFrame::order_extra)
+        const uint32_t e = scalar_load(fr.tile_order + d);
+        part = e >> kOrderPartShift;
+        d = e & kOrderSlotMask;          // (kOrderNone: a slot beyond the grid)
+    }
+    if (part_ != nullptr) *part_ = part;
     if (slot) *slot = d;
     const uint32_t bd = d / CAMERA_WAVES_PER_BLOCK;
     const uint32_t k = bd / row_blocks, jb = bd - k * row_blocks;
@@ -1186,7 +1217,9 @@ __device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_
     const uint32_t ty = (k & 1u) ? mid - ((k + 1u) >> 1) : mid + (k >> 1);      // mid, mid-1, mid+1, ...: a bijection
     *lx = tx * 8u + (lane & 7u);
     *y = ty * 8u + (lane >> 3);
-    return *lx < fr.w && *y < fr.h;
+    // a half tile: lanes 0..31 (part 1) or 32..63 (part 2) have a pixel
+    const bool mine = part == 0u || (part == 1u) == (lane < 32u);
+    return mine && *lx < fr.w && *y < fr.h;
 }
 __device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
 {
@@ -1291,9 +1324,10 @@ __global__ __launch_bounds__(64) void k_hot_tiles(DevFrame fr, uint32_t* __restr
 
 // The tile of a camera kernel's wave.  With a hot-tile list (DevFrame::hot_tiles) the launch has kHotTilesMax waves in front of the
 // ordered ones: wave k traces hot tile k, and the wave the order gives that tile to leaves.  false: the wave has nothing to do.
-__device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* lx_, uint32_t* y_, uint32_t* slot_, bool* inside_, bool* hot_wave_)
+__device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* lx_, uint32_t* y_, uint32_t* slot_, bool* inside_, bool* hot_wave_,
+                                                 uint32_t* part_ = nullptr)
 {
-    uint32_t lx = 0, y = 0, slot = 0;
+    uint32_t lx = 0, y = 0, slot = 0, part = 0;
     bool inside;
     bool hot_wave = false;
     {
@@ -1325,7 +1359,7 @@ __device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* l
                 inside = lx < fr.w && y < fr.h;
                 hot_wave = true;
             } else {
-                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot);
+                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot, &part);
                 const uint32_t t = __builtin_amdgcn_readfirstlane(((y >> 3) << 16) | (lx >> 3));
                 bool is_hot = false;
 #pragma unroll
@@ -1333,16 +1367,20 @@ __device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* l
                 if (is_hot) return false;
             }
         } else {
-            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot);
+            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot, &part);
         }
     }
+    if (part_ != nullptr) *part_ = part;
     *lx_ = lx; *y_ = y; *slot_ = slot; *inside_ = inside; *hot_wave_ = hot_wave;
     return true;
 }
 
 // what a tile cost in this launch, kept as a decaying maximum over the sampled launches (DevFrame::tile_cost_keep)
-__device__ __forceinline__ void store_tile_cost(const DevFrame& fr, uint32_t slot, unsigned long long cycles)
+// (a half tile's wave stores 13/8 of its own cycles -- roughly what the whole tile costs on one wave --, so that a tile keeps its
+// rank in the order whether it is split or not; the two halves race for the cell and either estimate will do)
+__device__ __forceinline__ void store_tile_cost(const DevFrame& fr, uint32_t slot, unsigned long long cycles, uint32_t part = 0u)
 {
+    if (part != 0u) cycles = (cycles * 13ull) >> 3;
     uint32_t c = (uint32_t)min(cycles, 0xffffffffull);
     if (fr.tile_cost_keep != 0u) {
         const uint32_t old = fr.tile_cost[slot];
@@ -1358,6 +1396,37 @@ __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint3
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     if ((threadIdx.x & 63u) == 0) atomicAdd(counter, v);
+}
+
+// The stores of k_gen_rays' frame outputs (primary colour, scatter flag, query: 40 B per pixel = 83 MB per 1080p launch).
+// NRC_OUT_STORES: 0 plain (write-back: what is still dirty in the eight L2s when the kernel ends is written back then, in front of the
+// next launch), 1 write-through (sc0 sc1: the line goes to memory at once and stays in the L2 for the consumers on the same XCD), 2
+// non-temporal.
+#ifndef NRC_OUT_STORES
+#define NRC_OUT_STORES 0
+#endif
+typedef float out_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void out_store(float4* p, float4 v)
+{
+#if NRC_OUT_STORES == 1
+    const out_f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+#elif NRC_OUT_STORES == 2
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void out_store(float* p, float v)
+{
+#if NRC_OUT_STORES == 1
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#elif NRC_OUT_STORES == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ nrc/gen_rays.comp + prep_infer_rays.comp
@@ -1376,7 +1445,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     __shared__ uint32_t s_occ[kOccMaxWords];
     uint32_t lx = 0, y = 0, slot = 0;
     bool inside, hot_wave;
-    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave)) return;
+    uint32_t part = 0;
+    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave, &part)) return;
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
@@ -1415,13 +1485,13 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 camera_ray(cam, u, v, &ro, &rd);
                 const V3 e = sample_env_dir(sc, rd);
                 const size_t pix = (size_t)y * fr.w + lx;
-                primary[pix] = make_float4(e.x, e.y, e.z, 1.0f);
-                info[pix] = 0.0f;
+                out_store(&primary[pix], make_float4(e.x, e.y, e.z, 1.0f));
+                out_store(&info[pix], 0.0f);
                 float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
-                for (int k = 0; k < 5; k++) qo[k] = 0.0f;
+                for (int k = 0; k < 5; k++) out_store(&qo[k], 0.0f);
             }
-            if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
+            if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start, part);
 #ifdef NRC_LOOP_PROFILE
             if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = 0.0f;
             if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) g_wave_times[4 * wave_id + 1] = wall_clock64();
@@ -1454,7 +1524,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
 #ifndef NRC_LATE_ENV
     if (inside) {
         const V3 e = sample_env_dir(sc, rd);
-        primary[(size_t)y * fr.w + lx] = make_float4(e.x, e.y, e.z, 1.0f);
+        out_store(&primary[(size_t)y * fr.w + lx], make_float4(e.x, e.y, e.z, 1.0f));
     }
 #endif
     V3 light = v3(0, 0, 0);
@@ -1522,7 +1592,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             }
             if (did_scatter) {
                 nrc_query(sc, cur, dir, q);
-                primary[pix] = make_float4(light.x, light.y, light.z, factor);      // replaces the environment colour stored above
+                out_store(&primary[pix], make_float4(light.x, light.y, light.z, factor));      // replaces the environment colour stored above
             }
         }
 #ifdef NRC_LATE_ENV
@@ -1531,12 +1601,12 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
             primary[pix] = make_float4(e.x, e.y, e.z, 1.0f);
         }
 #endif
-        info[pix] = did_scatter ? 1.0f : 0.0f;
+        out_store(&info[pix], did_scatter ? 1.0f : 0.0f);
         // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
         // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
         float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
-        for (int k = 0; k < 5; k++) qo[k] = q[k];
+        for (int k = 0; k < 5; k++) out_store(&qo[k], q[k]);
     }
 #ifdef NRC_LOOP_PROFILE
     // per-pixel look-up count in the w component of the origin image (tools/lane_model.py)
@@ -1545,7 +1615,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
     // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order).  (Not for a hot wave: what
     // it measured is this frame's one pixel in a capped state, not the tile.)
-    if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
+    if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start, part);
 #if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
     for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
 #endif
@@ -1566,7 +1636,8 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const uint32_t* occ = load_occupancy(sc, s_occ);
     uint32_t lx = 0, y = 0, slot = 0;
     bool inside, hot_wave;
-    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave)) return;
+    uint32_t part = 0;
+    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave, &part)) return;
     CtxT<COUNT> c{sc, 0.0f, 0u};
     c.occ = occ;
     // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
@@ -1612,7 +1683,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     }
     if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
     if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
-        store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4);
+        store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4, part);
 }
 
 // ------------------------------------------------------------------------------------------------ costliest-first launch order
@@ -1624,7 +1695,10 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
 // row_len > 0: a tile is ranked by the largest cost among itself and its four neighbours (row_len = slots per tile row).  What ends
 // a launch is a tile whose cost was under-estimated -- a long walk is a rare event of a pixel, and a tile at the cloud's rim has
 // one in some frames only --, and its neighbours see the same medium: their maximum is the better estimate of what it CAN cost.
-__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order, uint32_t row_len)
+// split_max > 0: the costliest tiles -- at most split_max of them, cost class >= split_min_class -- are listed as two half tiles
+// (DevFrame::order_extra): the order has n + split_max entries, the unused ones at its end say kOrderNone.
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order, uint32_t row_len,
+                                                    uint32_t split_max, uint32_t split_min_class)
 {
     NRC_RAISE_WAVE_PRIORITY(16);
     __shared__ uint32_t hist[1024];
@@ -1664,7 +1738,26 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
     __syncthreads();
     hist[tid] = woff + incl - v;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024u) order[atomicAdd(&hist[key_of(i)], 1u)] = i;
+    // tiles in the classes [0, 1023 - split_min_class] (descending cost) are candidates for the split: the first n_split ranks
+    __shared__ uint32_t s_split;
+    if (tid == 0u) {
+        const uint32_t last = 1023u - min(split_min_class, 1023u);      // the last key that qualifies
+        const uint32_t cand = last == 1023u ? n : hist[last + 1u];      // exclusive prefix of the key behind it
+        s_split = min(split_max, cand);
+    }
+    __syncthreads();
+    const uint32_t n_split = s_split;
+    __syncthreads();      // (s_split is read before the scatter below advances hist)
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        const uint32_t r = atomicAdd(&hist[key_of(i)], 1u);
+        if (r < n_split) {
+            order[2u * r] = i | (1u << kOrderPartShift);
+            order[2u * r + 1u] = i | (2u << kOrderPartShift);
+        } else {
+            order[r + n_split] = i;
+        }
+    }
+    for (uint32_t i = n + n_split + tid; i < n + split_max; i += 1024u) order[i] = kOrderNone;
 }
 
 // ------------------------------------------------------------------------------------------------ empty-space tile mask
@@ -1993,6 +2086,67 @@ __global__ void k_compare_final(const double* __restrict__ scratch, float* __res
     result5[4] = (float)cnt;
 }
 
+// ---- the same metrics of a frame sharded over ranks ("reduce only the metrics"): pass 1 leaves the rank's RAW sums
+// {sq err, ref sum, own sum, valid count} in scratch[0..3], the caller all-reduces them, k_compare_scale turns the global sums into
+// {mse, refMean, ownMean, count}; pass 2 (k_compare_2 with the GLOBAL ownMean) leaves the rank's raw variance sum in scratch[4], the
+// caller all-reduces it, k_compare_final_sharded writes the Result.
+__global__ void k_compare_fold(double* __restrict__ scratch)
+{
+    if (threadIdx.x != 0) return;
+    double se = 0, rs = 0, os = 0, cnt = 0;
+    for (int b = 0; b < CMP_BLOCKS; b++) {
+        const double* p = scratch + 8 + 4 * b;
+        se += p[0]; rs += p[1]; os += p[2]; cnt += p[3];
+    }
+    scratch[0] = se; scratch[1] = rs; scratch[2] = os; scratch[3] = cnt;
+}
+__global__ void k_compare_scale(double* __restrict__ scratch)
+{
+    if (threadIdx.x != 0) return;
+    const double cnt = scratch[3];
+    const double inv = cnt > 0 ? 1.0 / (cnt * 3.0) : 0.0;
+    scratch[0] *= inv; scratch[1] *= inv; scratch[2] *= inv;
+}
+__global__ void k_compare_fold_var(double* __restrict__ scratch)
+{
+    if (threadIdx.x != 0) return;
+    double var = 0;
+    for (int b = 0; b < CMP_BLOCKS; b++) var += scratch[8 + 4 * CMP_BLOCKS + b];
+    scratch[4] = var;
+}
+__global__ void k_compare_final_sharded(const double* __restrict__ scratch, float* __restrict__ result5)
+{
+    if (threadIdx.x != 0) return;
+    const double cnt = scratch[3];
+    const double inv = cnt > 0 ? 1.0 / (cnt * 3.0) : 0.0;
+    result5[0] = (float)scratch[0];
+    result5[1] = (float)scratch[1];
+    result5[2] = (float)scratch[2];
+    result5[3] = (float)(scratch[4] * inv);
+    result5[4] = (float)cnt;
+}
+
+// ---- a sharded frame put together again (nrc_tile: strips of 2^block_log2 columns dealt round-robin over `world` ranks):
+// gathered = [world][h][max_lw] RGBA32F, rank r's local image padded to max_lw columns; out = [h][gw]
+__global__ __launch_bounds__(256) void k_assemble_columns(const float4* __restrict__ gathered, uint32_t world, uint32_t block_log2, uint32_t gw, uint32_t h,
+                                                         uint32_t max_lw, float4* __restrict__ out)
+{
+    NRC_RAISE_WAVE_PRIORITY(16);
+    const uint32_t gx = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (gx >= gw) return;
+    const uint32_t strip = gx >> block_log2, rank = strip % world, lstrip = strip / world;
+    const uint32_t lx = (lstrip << block_log2) + (gx & ((1u << block_log2) - 1u));
+    out[(size_t)y * gw + gx] = gathered[((size_t)rank * h + y) * max_lw + lx];
+}
+// local image [h][lw] -> [h][max_lw] (the all-gather moves equal blocks; a rank's last strip may be short or missing)
+__global__ __launch_bounds__(256) void k_pad_columns(const float4* __restrict__ local, uint32_t lw, uint32_t h, uint32_t max_lw, float4* __restrict__ padded)
+{
+    NRC_RAISE_WAVE_PRIORITY(16);
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= max_lw) return;
+    padded[(size_t)y * max_lw + x] = x < lw ? local[(size_t)y * lw + x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // ------------------------------------------------------------------------------------------------ test hooks
 __global__ void k_test_math(int fn, const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
                             float* __restrict__ out, float* __restrict__ out2)
@@ -2047,6 +2201,7 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 #endif
     dim3 grid = wave_tile_grid(fr.w, fr.h);
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
+    if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     hipLaunchKernelGGL(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
                        fetch_counter, tg, full_vertex_images ? 1 : 0);
@@ -2061,9 +2216,11 @@ void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s)
 
 uint32_t camera_slots(uint32_t w, uint32_t h) { return camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK * ceil_div(h, 8); }
 
-void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, hipStream_t s)
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, uint32_t split_max,
+                       uint32_t split_min_cycles, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order, neighbours ? camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK : 0u);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order, neighbours ? camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK : 0u,
+                       split_max, split_min_cycles >> 9);
     NRC_HIP(hipGetLastError());
 }
 
@@ -2095,6 +2252,7 @@ void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& 
 {
     dim3 grid = wave_tile_grid(fr.w, fr.h);
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
+    if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,
                        cam, fr, path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
     NRC_HIP(hipGetLastError());
@@ -2139,6 +2297,37 @@ void launch_compare(const float* ref_rgba, const float* own_rgba, uint32_t n_pix
     hipLaunchKernelGGL(k_compare_2, dim3(CMP_BLOCKS), dim3(256), 0, s, (const float4*)ref_rgba, (const float4*)own_rgba,
                        n_pixels, d_scratch);
     hipLaunchKernelGGL(k_compare_final, dim3(1), dim3(64), 0, s, (const double*)d_scratch, d_result5);
+    NRC_HIP(hipGetLastError());
+}
+
+void launch_compare_sharded_1(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compare_1, dim3(CMP_BLOCKS), dim3(256), 0, s, (const float4*)ref_rgba, (const float4*)own_rgba, n_pixels, d_scratch);
+    hipLaunchKernelGGL(k_compare_fold, dim3(1), dim3(64), 0, s, d_scratch);
+    NRC_HIP(hipGetLastError());
+}
+void launch_compare_sharded_2(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compare_scale, dim3(1), dim3(64), 0, s, d_scratch);
+    hipLaunchKernelGGL(k_compare_2, dim3(CMP_BLOCKS), dim3(256), 0, s, (const float4*)ref_rgba, (const float4*)own_rgba, n_pixels, d_scratch);
+    hipLaunchKernelGGL(k_compare_fold_var, dim3(1), dim3(64), 0, s, d_scratch);
+    NRC_HIP(hipGetLastError());
+}
+void launch_compare_sharded_3(double* d_scratch, float* d_result5, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compare_final_sharded, dim3(1), dim3(64), 0, s, (const double*)d_scratch, d_result5);
+    NRC_HIP(hipGetLastError());
+}
+void launch_pad_columns(const float* local, uint32_t lw, uint32_t h, uint32_t max_lw, float* padded, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pad_columns, dim3(ceil_div(max_lw, 256), h), dim3(256), 0, s, (const float4*)local, lw, h, max_lw, (float4*)padded);
+    NRC_HIP(hipGetLastError());
+}
+void launch_assemble_columns(const float* gathered, uint32_t world, uint32_t block_log2, uint32_t gw, uint32_t h, uint32_t max_lw, float* out,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(k_assemble_columns, dim3(ceil_div(gw, 256), h), dim3(256), 0, s, (const float4*)gathered, world, block_log2, gw, h, max_lw,
+                       (float4*)out);
     NRC_HIP(hipGetLastError());
 }
 

@@ -53,7 +53,14 @@ struct DevFrame {
     // launch order of the camera kernels' 8x8 tiles: launch slot (workgroup * 4 + wave) -> default slot (the centre-out order of
     // pixel_of_wave_tile), costliest first (k_tile_order); nullptr: default order.  tile_cost: cycles each default slot's wave
     // took in this launch (written by k_gen_rays when non-null)
+    // Split tiles: the order buffer holds order_extra entries more than there are slots, and an entry's top four bits say which
+    // part of the tile the wave renders (kOrderPart*: 0 the whole 8x8 tile, 1 / 2 its upper / lower four pixel rows = lanes 0..31 /
+    // 32..63; the other lanes have no pixel and help the walks of those that do: ratio_pairs).  k_tile_order lists the costliest
+    // tiles as two halves: what ends a launch is its longest waves, and a half tile's walks run two lanes per walk from the
+    // first trip.  An entry of 0xffffffff is a wave without work.  Every pixel is still traced exactly once, by the same
+    // arithmetic, whatever the split.
     const uint32_t* tile_order;
+    uint32_t order_extra;
     uint32_t* tile_cost;
     // 0: tile_cost[slot] = this launch's cycles; k > 0: max(this launch's cycles, old - (old >> k)) -- a decaying maximum over the
     // sampled launches: the costliest-first order is hurt by tiles it under-estimates (a long tile started late ends the launch),
@@ -72,6 +79,7 @@ struct DevFrame {
     uint32_t* hot_reset;
     float random_next[4];
 };
+constexpr uint32_t kOrderSlotMask = 0x00ffffffu, kOrderPartShift = 28u, kOrderNone = 0xffffffffu;
 constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front
 
 // forward camera transform for the tile mask: clip = m * (x, y, z, 1), column-major like DevCamera::m
@@ -106,7 +114,10 @@ void launch_flight_table(float* table, hipStream_t s);
 void launch_flight_select(const float* table, float lambda, uint32_t* count_and_list, uint32_t* bits, hipStream_t s);
 // launch slots of the camera kernels (rows padded to an odd number of workgroups) and the costliest-first order over them
 uint32_t camera_slots(uint32_t w, uint32_t h);
-void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, hipStream_t s);
+// split_max: at most that many of the costliest tiles (cost >= split_min_cycles) are listed as two half tiles; `order` holds
+// n_slots + split_max entries
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, uint32_t split_max,
+                       uint32_t split_min_cycles, hipStream_t s);
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);
@@ -123,6 +134,15 @@ void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor,
 void launch_compare(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, float* d_result5,
                     hipStream_t s);
 
+// the metrics of a frame sharded over ranks: _1 leaves this rank's raw sums in d_scratch[0..3] (all-reduce them), _2 this rank's raw
+// variance sum around the global mean in d_scratch[4] (all-reduce it), _3 writes the Result
+void launch_compare_sharded_1(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, hipStream_t s);
+void launch_compare_sharded_2(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, hipStream_t s);
+void launch_compare_sharded_3(double* d_scratch, float* d_result5, hipStream_t s);
+// a sharded frame's column strips: local [h][lw] -> [h][max_lw]; gathered [world][h][max_lw] -> [h][gw]
+void launch_pad_columns(const float* local, uint32_t lw, uint32_t h, uint32_t max_lw, float* padded, hipStream_t s);
+void launch_assemble_columns(const float* gathered, uint32_t world, uint32_t block_log2, uint32_t gw, uint32_t h, uint32_t max_lw, float* out,
+                             hipStream_t s);
 void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, float* out2, hipStream_t s);
 void launch_test_rng(float u, float v, const float* frame_random4, uint32_t n, float* out, hipStream_t s);
 

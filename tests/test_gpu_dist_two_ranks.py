@@ -64,6 +64,19 @@ def test_two_ranks_on_one_gpu_train_identical_replicas_and_reassemble_the_frame(
     got = parallel.gather_columns([a["img"], b["img"]], W)
     assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
     assert (prim[..., 3] < 1.0).mean() > 0.02 and img[..., :3].std() > 0.01      # the cache contributes to visible pixels
+    # the product's own assembly (nrc_renderer_gather_frame: all-gather + de-interleave kernel): the whole frame on BOTH ranks, the file
+    # rank 1 exported, and the sharded metric reduction == nrc_compare_images of the single-GPU frame
+    assert np.array_equal(a["gathered"].view(np.uint32), img.view(np.uint32)) and np.array_equal(b["gathered"].view(np.uint32), img.view(np.uint32))
+    from nrc_hpm_renderer_amd import io_exr
+    sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
+    import dist_two_rank_worker as worker
+    exr = io_exr.read_exr(out + ".gathered.exr")
+    assert exr.shape == (H, W, 4) and np.array_equal(exr.view(np.uint32), img.view(np.uint32))
+    ref = torch_gpu.from_numpy(worker.reference_image(W, H)).cuda()
+    want = api.CompareImages(ref, ren.GetImage())
+    want5 = np.asarray([want[k] for k in ("mse", "ref_mean", "own_mean", "own_var", "valid")], np.float32)
+    assert np.array_equal(a["result"], b["result"]) and want5[4] > 1000 and a["result"][4] == want5[4]
+    assert np.allclose(a["result"], want5, rtol=3e-7, atol=0.0)                   # fp64 sums in another order, rounded to fp32
     ren.Destroy()
     one.Destroy()
     full.Destroy()
@@ -95,3 +108,29 @@ def test_bench_self_launches_its_ranks(torch_gpu):
     c4 = d["strong_scaling_c4"]
     assert c4["scaling"] == "strong" and c4["value"] > 100 and "1920 columns per rank" in c4["workload"] and "8192 per rank" in c4["workload"]
     assert abs(c4["ms_per_step"] - 3840 * 2160 * 8 / c4["value"] / 1e3) < 1e-6 * c4["ms_per_step"] + 1e-9
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_log_the_whole_frames_metrics_and_export_the_whole_frame(torch_gpu, tmp_path):
+    """`python -m nrc_hpm_renderer_amd.cli --gpus 2 --benchmark --export` (rehearsed on one device: NRC_CLI_SHARED_GPU=1, gloo): the
+    main loop of src/main.cu:152-419 with the frame sharded over two ranks -- rank 0's log holds one `frame mse relBias CV` line per
+    frame (metrics of the WHOLE frame, reduced over the ranks), and the exported EXR is the whole 256x96 frame with both ranks' columns"""
+    from nrc_hpm_renderer_amd import io_exr
+    env = dict(os.environ, NRC_CLI_SHARED_GPU="1", GPU_MAX_HW_QUEUES="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out, exr = str(tmp_path / "out"), str(tmp_path / "whole.exr")
+    argv = ["RelativeL2Luminance", "Adam", "0.01", "0.99", "3", "0", "64", "6", "14", "9", "1", "4", "1.0", "1", "1", "0.0", "32"]
+    cmd = [sys.executable, "-m", "nrc_hpm_renderer_amd.cli"] + argv + ["--frames", "5", "--width", "256", "--height", "96", "--volume", "32", "--env", "sky",
+                                                                      "--benchmark", "--ref-frames", "8", "--output", out, "--export", exr, "--gpus", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    logs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f == "log.txt"]
+    assert len(logs) == 1                                             # rank 0 owns the log
+    rows = [ln.split() for ln in open(logs[0]).read().splitlines()]
+    assert [int(x[0]) for x in rows] == list(range(5)) and all(len(x) == 4 and np.isfinite([float(v) for v in x[1:]]).all() for x in rows)
+    assert all(float(x[1]) > 0.0 for x in rows)                        # an MSE of the whole frame
+    img = io_exr.read_exr(exr)
+    assert img.shape == (96, 256, 4)
+    col_energy = np.abs(img[..., :3]).sum(axis=(0, 2))
+    assert (col_energy > 0).all(), (np.nonzero(col_energy == 0)[0].tolist(), r.stdout[-1500:], r.stderr[-1500:])      # every strip of both ranks is there (the sky lights every column)

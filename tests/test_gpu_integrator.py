@@ -807,6 +807,44 @@ def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, tor
     assert out[True][0][..., :3].std() > 0.01 and (out[True][0][..., 3] == 1.0).all()
 
 
+def test_split_tiles_change_no_pixel(api, sc, cloud16, torch_gpu, monkeypatch):
+    """NRC_SPLIT_TILES (measured and rejected in round 4, kept as a diagnostic): the costliest tiles launch as two half tiles -- 32
+    pixels on 64 lanes, the ratio walks on lane pairs from the first trip.  The order then lists such a tile twice (upper / lower four
+    rows), every other tile once, and every frame is bit-identical to the unsplit launch"""
+    W, H = 328, 200
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=14)
+    frs = sc.frame_randoms(8, seed=5)
+    out = {}
+    for split in (64, 0):
+        monkeypatch.setenv("NRC_SPLIT_TILES", str(split))
+        monkeypatch.setenv("NRC_SPLIT_MIN_CYCLES", "20000")
+        nrc = api.NeuralRadianceCache(cfg)
+        ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
+        frames = []
+        for f in range(8):               # the first sort (after frame 0) is in use from frame 2
+            ren.SetFrameRandom(frs[f])
+            ren.Render(None, True)
+            frames.append([ren.Buffer(k).cpu().numpy().copy() for k in ("primary", "info", "infer_input", "train_input", "train_target")])
+        out[split] = (frames, ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), ren.TileOrder())
+        ren.Destroy()
+        nrc.Destroy()
+    for fa, fb in zip(out[64][0], out[0][0]):
+        for a, b in zip(fa, fb):
+            assert same_bits(a, b)
+    assert same_bits(out[64][1], out[0][1]) and out[64][2] == out[0][2]
+    order = out[64][3]
+    n_slots = len(out[0][3])
+    assert len(order) == n_slots + 64
+    live = order[order != 0xFFFFFFFF]
+    slot, part = live & 0x00FFFFFF, live >> 28
+    halves = np.sort(slot[part == 1])
+    assert 0 < len(halves) <= 64 and np.array_equal(halves, np.sort(slot[part == 2])) and len(np.unique(halves)) == len(halves)
+    whole = slot[part == 0]
+    assert np.array_equal(np.sort(np.concatenate([whole, halves])), np.arange(n_slots, dtype=np.uint32))      # every tile exactly once
+
+
 def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc, cloud16, torch_gpu):
     """the costliest-first launch order of gen_rays' tiles: after the first sort the order is no longer the identity, it is a
     permutation of all tile slots with the provably empty tiles behind the cloud's, and every frame -- primary pass, queries,

@@ -12,6 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
+def reference_image(W, H):
+    """a seeded stand-in for reference/<scene>/0.exr: RGBA32F, alpha 0 outside a disc (cmp1.comp skips those pixels)"""
+    rng = np.random.default_rng(11)
+    ref = rng.random((H, W, 4), dtype=np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ref[..., 3] = (((xx - W / 2) / (W / 2)) ** 2 + ((yy - H / 2) / (H / 2)) ** 2 < 0.8).astype(np.float32)
+    return ref
+
+
 def main():
     out_path = sys.argv[1]
     import torch
@@ -49,10 +58,21 @@ def main():
     ren.SetFrameRandom(frs[frames])
     ren.Render(None, False)
     img = ren.GetImage().cpu().numpy().copy()
+    # the product's own frame assembly and metric reduction (VERDICT r03 missing 1): collective calls through the cache's collective
+    # hooks (gloo here; the native RCCL communicator on a multi-GPU node) -- every rank gets the whole frame and the whole frame's Result
+    nrc.SetCollectiveHooks(rank, world)
+    gathered = ren.GatherFrame().cpu().numpy().copy()
+    ref_full = reference_image(W, H)
+    cols = parallel.rank_columns(rank, world, W)
+    ref_local = torch.from_numpy(np.ascontiguousarray(ref_full[:, cols, :])).cuda()
+    res = api.CompareImagesSharded(nrc, ref_local, ren.GetImage().contiguous())
+    exr_path = out_path + ".gathered.exr"
+    ren.ExportOutputImageToFile(None, exr_path, root=1)                   # collective; rank 1 writes
     np.savez(out_path + ".%d.npz" % rank, rank=rank, world=world, losses=np.asarray(losses, np.float64), grad=grad, train_in=train_in,
              train_target=train_target, primary=primary, img=img, w=state["w"], ema=state["ema"], m=state["m"], v=state["v"], step=state["step"],
              w_prev=state_before_last["w"], ema_prev=state_before_last["ema"], m_prev=state_before_last["m"], v_prev=state_before_last["v"],
-             step_prev=state_before_last["step"], frame_randoms=frs)
+             step_prev=state_before_last["step"], frame_randoms=frs, gathered=gathered,
+             result=np.asarray([res[k] for k in ("mse", "ref_mean", "own_mean", "own_var", "valid")], np.float32))
     ren.Destroy()
     nrc.Destroy()
     dist.barrier()
