@@ -80,12 +80,13 @@ inline void inflate(const unsigned char* src, size_t n, std::vector<unsigned cha
         const uint32_t last = b.get(1), type = b.get(2);
         if (type == 0) {
             b.cnt = 0;
-            if (b.pos + 4 > b.n) fail("EXR: truncated stored block");
+            if (b.pos > b.n || 4 > b.n - b.pos) fail("EXR: truncated stored block");
             const uint32_t len = b.p[b.pos] | (b.p[b.pos + 1] << 8);
             b.pos += 4;
-            if (b.pos + len > b.n) fail("EXR: truncated stored block");
+            if (len > b.n - b.pos) fail("EXR: truncated stored block");
             out.insert(out.end(), b.p + b.pos, b.p + b.pos + len);
             b.pos += len;
+            if (out.size() > expect) fail("EXR: a compressed block inflates to the wrong size");
         } else if (type == 1 || type == 2) {
             Huff lit, dist;
             uint8_t lens[320];
@@ -122,6 +123,7 @@ inline void inflate(const unsigned char* src, size_t n, std::vector<unsigned cha
             }
             for (;;) {
                 const int sym = lit.decode(b);
+                if (out.size() > expect) fail("EXR: a compressed block inflates to the wrong size");      // (never grow past what the chunk may hold)
                 if (sym < 256) out.push_back((unsigned char)sym);
                 else if (sym == 256) break;
                 else {
@@ -152,7 +154,8 @@ inline std::vector<float> LoadExrRGBA(const std::string& path, uint32_t* width, 
     if (!f) fail("TinyEXR failed to load " + path);      // the reference's message (src/Reference.cpp:625)
     std::vector<unsigned char> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     size_t p = 0;
-    auto need = [&](size_t n) { if (p + n > d.size()) fail(path + ": truncated EXR file"); };
+    // (overflow-safe: p and n come from the file)
+    auto need = [&](size_t n) { if (p > d.size() || n > d.size() - p) fail(path + ": truncated EXR file"); };
     auto u32 = [&]() { need(4); uint32_t v; std::memcpy(&v, &d[p], 4); p += 4; return v; };
     auto cstr = [&]() { std::string s; for (;;) { need(1); const char c = (char)d[p++]; if (!c) break; s.push_back(c); } return s; };
     if (u32() != 20000630u) fail(path + " is not an OpenEXR file");
@@ -167,9 +170,14 @@ inline std::vector<float> LoadExrRGBA(const std::string& path, uint32_t* width, 
         const uint32_t size = u32();
         need(size);
         const size_t a = p;
+        const size_t attr_end = a + size;
+        auto attr_need = [&](size_t n) { if (p > attr_end || n > attr_end - p) fail(path + ": EXR attribute " + name + " is too short"); };
         if (name == "channels") {
-            while (d[p] != 0) {
+            for (;;) {
+                attr_need(1);
+                if (d[p] == 0) break;
                 const std::string cn = cstr();
+                attr_need(16);
                 int32_t pixel_type;
                 std::memcpy(&pixel_type, &d[p], 4);
                 if (pixel_type != 2) fail(path + ": only FLOAT channels are supported");
@@ -180,12 +188,15 @@ inline std::vector<float> LoadExrRGBA(const std::string& path, uint32_t* width, 
                 channels.push_back(cn);
             }
         } else if (name == "compression") {
+            attr_need(1);
             compression = d[p];
         } else if (name == "dataWindow") {
+            attr_need(16);
             int32_t w[4];
             std::memcpy(w, &d[p], 16);
             xmin = w[0]; ymin = w[1]; xmax = w[2]; ymax = w[3];
         } else if (name == "lineOrder") {
+            attr_need(1);
             line_order = d[p];
         }
         p = a + size;
@@ -193,6 +204,7 @@ inline std::vector<float> LoadExrRGBA(const std::string& path, uint32_t* width, 
     (void)line_order;      // chunks carry their own y coordinate
     if (channels.empty() || xmax < xmin || ymax < ymin) fail(path + ": EXR header without channels or data window");
     if (compression != 0 && compression != 2 && compression != 3) fail(path + ": EXR compression " + std::to_string(compression) + " is not supported (NONE, ZIPS, ZIP)");
+    if ((int64_t)xmax - xmin >= 65536 || (int64_t)ymax - ymin >= 65536) fail(path + ": EXR data window is too large");
     const uint32_t W = (uint32_t)(xmax - xmin + 1), H = (uint32_t)(ymax - ymin + 1);
     const uint32_t lines_per_chunk = compression == 3 ? 16u : 1u;
     const uint32_t n_chunks = (H + lines_per_chunk - 1) / lines_per_chunk;
@@ -211,14 +223,16 @@ inline std::vector<float> LoadExrRGBA(const std::string& path, uint32_t* width, 
     const size_t line_bytes = (size_t)W * 4 * channels.size();
     std::vector<unsigned char> raw, tmp;
     for (uint32_t c = 0; c < n_chunks; c++) {
+        if (offsets[c] > d.size()) fail(path + ": EXR chunk offset outside the file");
         p = (size_t)offsets[c];
         need(8);
         int32_t y0, packed;
         std::memcpy(&y0, &d[p], 4); std::memcpy(&packed, &d[p + 4], 4);
         p += 8;
+        if (packed < 0) fail(path + ": EXR chunk of negative size");
         need((size_t)packed);
+        if ((int64_t)y0 < ymin || (int64_t)y0 - ymin >= (int64_t)H) fail(path + ": EXR chunk outside the data window");
         const uint32_t row0 = (uint32_t)(y0 - ymin);
-        if (row0 >= H) fail(path + ": EXR chunk outside the data window");
         const uint32_t rows = std::min(lines_per_chunk, H - row0);
         const size_t expect = line_bytes * rows;
         const unsigned char* src = &d[p];

@@ -41,7 +41,7 @@ struct Reader {
     explicit Reader(const std::vector<unsigned char>& data) : d(data) {}
     const unsigned char* take(size_t n)
     {
-        if (p + n > d.size()) fail("VDB file is truncated");
+        if (p > d.size() || n > d.size() - p) fail("VDB file is truncated");      // (overflow-safe: p and n come from the file)
         const unsigned char* r = d.data() + p;
         p += n;
         return r;
@@ -150,13 +150,19 @@ inline VdbVolume ReadVdb(const std::string& path)
     (void)r.str();                                         // instance parent
     const int64_t grid_pos = r.get<int64_t>(), block_pos = r.get<int64_t>(), end_pos = r.get<int64_t>();
     if (gtype.find("Tree_float_5_4_3") == std::string::npos) fail("VDB grid type " + gtype + " is not supported (need Tree_float_5_4_3)");
+    // the three stream positions come from the file: inside it, and in order
+    if (grid_pos < 0 || block_pos < grid_pos || end_pos < block_pos || (uint64_t)end_pos > data.size()) fail("VDB grid descriptor points outside the file");
     r.p = (size_t)grid_pos;
     const uint32_t flags = r.get<uint32_t>();
     auto gmeta = r.meta();
     if (!gmeta.count("file_bbox_min") || !gmeta.count("file_bbox_max")) fail("VDB grid has no file_bbox metadata");
+    if (gmeta["file_bbox_min"].size() < 12 || gmeta["file_bbox_max"].size() < 12) fail("VDB file_bbox metadata is too short");
     std::memcpy(v.bboxMin, gmeta["file_bbox_min"].data(), 12);
     std::memcpy(v.bboxMax, gmeta["file_bbox_max"].data(), 12);
-    if (gmeta.count("file_voxel_count")) std::memcpy(&v.fileVoxelCount, gmeta["file_voxel_count"].data(), 8);
+    if (gmeta.count("file_voxel_count")) {
+        if (gmeta["file_voxel_count"].size() < 8) fail("VDB file_voxel_count metadata is too short");
+        std::memcpy(&v.fileVoxelCount, gmeta["file_voxel_count"].data(), 8);
+    }
     const int64_t ext[3] = {(int64_t)v.bboxMax[0] - v.bboxMin[0] + 1, (int64_t)v.bboxMax[1] - v.bboxMin[1] + 1, (int64_t)v.bboxMax[2] - v.bboxMin[2] + 1};
     if (ext[0] <= 0 || ext[1] <= 0 || ext[2] <= 0 || ext[0] * ext[1] * ext[2] > ((int64_t)1 << 31)) fail("VDB file_bbox is empty or too large");
     v.nx = (uint32_t)ext[0]; v.ny = (uint32_t)ext[1]; v.nz = (uint32_t)ext[2];

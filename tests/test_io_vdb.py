@@ -61,3 +61,70 @@ def test_cpp_exr_reader_equals_the_python_reader(tmp_path):
         assert r.returncode == 0, r.stderr
         a = np.fromfile(out, np.float32).reshape(1080, 1920, 4)
         assert np.array_equal(a.view(np.uint32), io_exr.read_exr(src).view(np.uint32))
+
+
+def _build_asan(name):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "tests", "cpp", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, name + "_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", name + ".cpp"), "-o", exe])
+    return exe
+
+
+def _mutations(data, rng, n):
+    """truncations, bytes flipped in the header region, and 32/64-bit fields overwritten with huge / negative values"""
+    out = [data[:k] for k in (0, 3, 8, 40, 100, len(data) // 2, len(data) - 1)]
+    for _ in range(n):
+        b = bytearray(data)
+        pos = int(rng.integers(0, min(len(b), 600)))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            b[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            b[pos:pos + 4] = (0xFFFFFFF0).to_bytes(4, "little")
+        else:
+            b[pos:pos + 8] = (0x7FFFFFFFFFFFFFF0).to_bytes(8, "little")
+        out.append(bytes(b[:len(data)]))
+    return out
+
+
+def test_cpp_readers_reject_malformed_files_without_reading_out_of_bounds(tmp_path):
+    """offsets and sizes the VDB / EXR readers take from the file are checked overflow-safely -- a truncated or corrupted
+    file ends in `SkyRenderer ERROR` (exit 1) or is read (exit 0), never in an out-of-bounds access (the readers run under
+    AddressSanitizer + UBSan here: a report aborts with another status)"""
+    import subprocess
+    from nrc_hpm_renderer_amd import io_exr
+    rng = np.random.default_rng(3)
+    img = rng.random((24, 20, 4), dtype=np.float32)
+    good = tmp_path / "good.exr"
+    io_exr.write_exr(str(good), img, compression="zip")
+    exe = _build_asan("exr_main")
+    r = subprocess.run([exe, str(good), str(tmp_path / "o.f32")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "o.f32", np.float32).reshape(24, 20, 4), img)
+    data = good.read_bytes()
+    seen = {0: 0, 1: 0}
+    for k, m in enumerate(_mutations(data, rng, 150)):
+        bad = tmp_path / "bad.exr"
+        bad.write_bytes(m)
+        r = subprocess.run([exe, str(bad), str(tmp_path / "o.f32")], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 1), (k, r.returncode, r.stderr[-1500:])
+        assert r.returncode == 0 or "SkyRenderer ERROR" in r.stderr, r.stderr[-500:]
+        seen[r.returncode] += 1
+    assert seen[1] > 20
+    if not os.path.exists(VDB):
+        return
+    exe = _build_asan("vdb_main")
+    data = open(VDB, "rb").read()
+    seen = {0: 0, 1: 0}
+    for k, m in enumerate(_mutations(data, rng, 40)):
+        bad = tmp_path / "bad.vdb"
+        bad.write_bytes(m)
+        r = subprocess.run([exe, str(bad), str(tmp_path / "o.u8")], capture_output=True, text=True, timeout=120)
+        assert r.returncode in (0, 1), (k, r.returncode, r.stderr[-1500:])
+        assert r.returncode == 0 or "SkyRenderer ERROR" in r.stderr, r.stderr[-500:]
+        seen[r.returncode] += 1
+    assert seen[1] > 10
