@@ -33,7 +33,7 @@ const char* nrc_version(void);
  * en::AppConfig (include/engine/AppConfig.hpp:9-66; 17 positional CLI args src/AppConfig.cpp:154-182,
  * defaults src/main.cu:429-440).  Scene preset values (src/AppConfig.cpp:93-150) are carried explicitly. */
 /* The reference passes lossFn / optimizer through to tiny-cuda-nn unchecked (src/NeuralRadianceCache.cu:17-26); this build implements a
- * CLOSED set -- the seven losses and two optimizers named below -- and nrc_cache_create fails with NRC_ERR_ARG and a message that lists
+ * CLOSED set -- the seven losses and two optimizers named below -- and nrc_cache_create fails with NRC_ERR_INVALID and a message that lists
  * them for any other tiny-cuda-nn name (Novograd, Shampoo, ...: update rules that could not be restated without the absent submodule;
  * CrossEntropy, Variance: they need a sample pdf the NRC path does not have). */
 typedef struct nrc_config {
