@@ -1608,6 +1608,17 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
 #pragma unroll
         for (int k = 0; k < 5; k++) out_store(&qo[k], q[k]);
     }
+    if (fr.live_list != nullptr) {      // the frame's live queries, for an encoder that gathers (DevFrame::live_list): one atomic per wave
+        const bool live = inside && entered && did_scatter;
+        const unsigned long long lm = __ballot(live);
+        if (lm != 0ull) {
+            uint32_t base = 0;
+            if ((threadIdx.x & 63u) == 0u) base = atomicAdd(fr.live_count, (uint32_t)__popcll(lm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+            if (live) fr.live_list[base + rank] = (uint32_t)query_index(fr.w, lx, y);
+        }
+    }
 #ifdef NRC_LOOP_PROFILE
     // per-pixel look-up count in the w component of the origin image (tools/lane_model.py)
     if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = (float)c.fetches;

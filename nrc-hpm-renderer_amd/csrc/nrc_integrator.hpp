@@ -78,6 +78,11 @@ struct DevFrame {
     uint32_t* hot_next;
     uint32_t* hot_reset;
     float random_next[4];
+    // the frame's LIVE queries (pixels that scattered: 22 % on the bench view): k_gen_rays appends their query indices to live_list
+    // and counts them in *live_count (zeroed by the caller in front of the launch); nullptr: no list.  The order of the
+    // list is whatever the waves' atomics made it; its only reader (the HashGrid encoder, Mlp::launch_features) writes by query index.
+    uint32_t* live_list;
+    uint32_t* live_count;
 };
 constexpr uint32_t kOrderSlotMask = 0x00ffffffu, kOrderPartShift = 28u, kOrderNone = 0xffffffffu;
 constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front

@@ -902,6 +902,57 @@ __global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict_
     feat_lm[(size_t)slot * n + sample] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2v));
 }
 
+// The same over a LIST of live queries (renderer inference: k_gen_rays lists the pixels that scattered, DevFrame::live_list).  The
+// one-thread-per-(query, slot) launch above starts 41 M threads for a 1080p frame of which 78 % read a 20-byte query, find it all zero
+// and leave -- 650 k waves and 0.8 GB of query reads beside gen_rays, whose launch went from 0.24 to 0.6 ms with them in the way.  Here a
+// fixed grid of workgroups per slot strides over the list; dead pixels cost nothing.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_encode_hash_list(const float* __restrict__ in, const uint32_t* __restrict__ table16,
+                                                         uint32_t* __restrict__ feat_lm, uint32_t n, HashLevels lv,
+                                                         const uint32_t* __restrict__ live_list, const uint32_t* __restrict__ live_count)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    constexpr int ND = DIR == 1 ? 2 : 8;
+    const uint32_t slot = blockIdx.y;
+    const uint32_t count = min(*live_count, n);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t sample = live_list[i];
+        if (sample >= n) continue;           // (a list of another launch: never written here)
+        const float* p = in + (size_t)sample * 5u;
+        float r0 = 1.0f, r1 = 1.0f;          // padding slots hold ones
+        if (slot < HG_LEVELS) {
+            const float x[3] = {p[0], p[1], p[2]};
+            uint32_t idx[8];
+            float w8[8];
+            hg_corners(lv, slot, x, idx, w8);
+            r0 = 0.0f; r1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const half2v hv = __builtin_bit_cast(half2v, table16[idx[c]]);
+                r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
+                r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
+            }
+        } else {
+            const float d0 = p[3], d1 = p[4];
+            const int k0 = 2 * ((int)slot - (int)HG_LEVELS);         // direction feature index of r0 (r1 = k0 + 1)
+            if (k0 < ND) {
+                if (DIR == 0) {
+                    float b[4];
+                    oneblob4(k0 < 4 ? d0 : d1, b);
+                    r0 = b[k0 & 3]; r1 = b[(k0 & 3) + 1];
+                } else if (DIR == 1) {
+                    r0 = d0; r1 = d1;
+                } else {
+                    const float v = k0 < 4 ? d0 : d1;
+                    r0 = tri_wave(v, k0 & 3); r1 = tri_wave(v, (k0 & 3) + 1);
+                }
+            }
+        }
+        float2v f = {r0, r1};
+        feat_lm[(size_t)slot * n + sample] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2v));
+    }
+}
+
 // dL/d(table): every (sample, level) scatters weight * dL/d(feature) to its 8 corners with one packed fp16 atomic per corner
 // (global_atomic_pk_add_f16 on a half2-per-entry table: tiny-cuda-nn does the same for 2 features per level; the values carry
 // the loss scale).  The sum order, hence the last bits, vary from run to run -- unlike the MLP's slab reduction.
@@ -1935,7 +1986,8 @@ void Mlp::repack(hipStream_t s)
 
 // generic-path encoding launch: HashGrid gathers from the fp16 table copy that belongs to the weight set in use
 // `slot` 0 = inference, 1 = training: the two may run concurrently on different streams and own separate feature buffers
-void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero)
+void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero, const uint32_t* live_list,
+                          const uint32_t* live_count)
 {
     ensure_features(n, slot);
     half_t* feat = (half_t*)d_feat_[slot];
@@ -1946,6 +1998,13 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     HashLevels lv;
     for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
     const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_[infer_set_] : d_t16_train_);
+    if (slot == 0 && live_list != nullptr && skip_zero) {      // renderer inference with the frame's live-query list
+        const dim3 g((uint32_t)num_cus() * 2u, enc_dims_ / 2);
+        if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash_list<0>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count);
+        else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash_list<1>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count);
+        else hipLaunchKernelGGL(k_encode_hash_list<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count);
+        return;
+    }
     if (slot == 0) {         // inference: level-major gathers and feature layout (k_encode_hash_lm / k_infer_gen<..., true>)
         const dim3 g(ceil_div(n, 256), enc_dims_ / 2);
         const int sk = skip_zero ? 1 : 0;
@@ -1999,7 +2058,8 @@ void Mlp::ensure_features(uint32_t n, int slot)
     feat_n_[slot] = n;
 }
 
-void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries, const CompositeArgs* composite)
+void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries, const CompositeArgs* composite,
+                const uint32_t* live_list, const uint32_t* live_count)
 {
     if (n == 0) return;
     if (composite != nullptr && !fused_) throw std::logic_error("SkyRenderer ERROR: compositing epilogue asked of a generic model");
@@ -2008,7 +2068,7 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
         // EMA inference of a Frequency(12) + OneBlob(4) model encodes inside the MLP kernel (image in the encoder's input order);
         // everything else runs the encoding kernel first
         const bool enc80 = enc80_generic_ && use_ema;
-        if (!enc80) launch_features(d_in, n, use_ema, 0, s, skip_zero_queries);
+        if (!enc80) launch_features(d_in, n, use_ema, 0, s, skip_zero_queries, live_list, live_count);
         const float* skip_in = skip_zero_queries ? d_in : nullptr;
         const half_t* feat = enc80 ? nullptr : (const half_t*)d_feat_[0];
         const int ks0 = (int)enc_dims_ / 16;

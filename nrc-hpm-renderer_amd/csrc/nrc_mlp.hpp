@@ -34,8 +34,10 @@ public:
 
     // network->inference: y = MLP_ema(encode(x)); in [n][5], out [n][3] (device, fp32)
     // skip_zero_queries (renderer only): 32-sample tiles whose queries are all exactly zero store 0 without running the network
+    // live_list / live_count (renderer only, with skip_zero_queries): the indices of the queries that are not all zero, in any order
+    // (k_gen_rays writes them); a model whose encoder gathers from a table walks the list instead of testing every query
     void infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipStream_t s, bool skip_zero_queries = false,
-               const CompositeArgs* composite = nullptr);
+               const CompositeArgs* composite = nullptr, const uint32_t* live_list = nullptr, const uint32_t* live_count = nullptr);
     // the fused 6x64 inference kernel can composite in its epilogue (nrc/render.comp); the generic kernels cannot
     bool can_composite() const { return fused_; }
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
@@ -73,7 +75,8 @@ private:
     bool attr_infer_set_ = false, attr_infer4_set_ = false, attr_train_set_ = false;     // hipFuncSetAttribute done on this instance's device
     void ensure_train_workspace(uint32_t n);
     void ensure_features(uint32_t n, int slot);
-    void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero);
+    void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero, const uint32_t* live_list = nullptr,
+                         const uint32_t* live_count = nullptr);
 #ifdef NRC_DIAG
     void infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n,
                           const void* image);

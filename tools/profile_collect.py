@@ -65,6 +65,11 @@ def main():
     summary([os.path.join(src, "pmc_sq")], "pmc_sq_counters.txt")
     summary([os.path.join(src, "pmc_mlp_mfma"), os.path.join(src, "pmc_mlp_sq")], "mlp_pmc_mfma.txt")
     put(os.path.join(src, "valu_rate.txt"), "micro_valu_rate.txt")
+    put(os.path.join(src, "issue_mix.txt"), "micro_issue_mix.txt")
+    last_json_line(os.path.join(src, "hashgrid_bench.json"), "hashgrid_bench.json")
+    put(first(src + "/prof_hash/**/*kernel_stats.csv"), "hashgrid_kernel_stats.csv")
+    last_json_line(os.path.join(src, "c4_bench.json"), "c4_bench.json")
+    put(os.path.join(src, "c4_rank_emulation.txt"), "c4_rank_emulation.txt")
     print("profiles/%s_*: %s" % (rnd, ", ".join(copied) if copied else "nothing found under " + src))
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU session's worth of measurements for profiles/rNN_* (run on the MI355X box from the repo root):
-#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin c5   (default: all but c5)
+#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin c5 hash issue c4   (default: micro mlp bench pmc pin)
 # Output goes to gpurun_out/<tag>/ ; then: python tools/profile_collect.py gpurun_out/<tag> rNN   (copies the summaries the documents quote into profiles/).
 # rocprofv3 is always given the interpreter binary itself after `--` (no env / bash -c / shebang hop) and counters are
 # collected in passes of their own (no trace domains beside --pmc).
@@ -48,6 +48,18 @@ if has c5; then
   echo "== dense 8x128 inference kernel trace"
   (cd /tmp && timeout -k 10 300 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_mlp128" -o mlp128 -- "$PY" "$REPO/tools/bench_mlp.py" 2073600 20 128 8) > "$OUT/prof_mlp128.log" 2>&1 || exit 1
   python3 tools/trace_tail.py "$(find "$OUT/prof_mlp128" -name "*kernel_trace.csv" | head -1)" k_infer_gen 100 > "$OUT/mlp128_trace_tail.txt" 2>&1
+fi
+if has hash; then
+  echo "== HashGrid model (the reference's default posID 0) bench (plain)" && timeout -k 10 400 "$PY" bench.py --pos-id 0 --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/hashgrid_bench.json" 2> "$OUT/hashgrid_bench.err" || exit 1
+  echo "== HashGrid kernel trace"
+  (cd /tmp && timeout -k 10 400 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/prof_hash" -o hash -- "$PY" "$REPO/bench.py" --pos-id 0 --steps 12 --warmup 2 --no-cpu-baseline) > "$OUT/prof_hash.log" 2>&1 || exit 1
+fi
+if has issue; then
+  echo "== issue-mix micro" && timeout -k 10 60 tools/_build/issue_mix > "$OUT/issue_mix.txt" 2>&1 || exit 1
+fi
+if has c4; then
+  echo "== configs[3]: one rank's share of the 4K frame" && timeout -k 10 300 "$PY" tools/c4_rank_emulation.py > "$OUT/c4_rank_emulation.txt" 2>&1 || exit 1
+  echo "== configs[3] on one GPU" && timeout -k 10 400 "$PY" bench.py --config c4 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/c4_bench.json" 2> "$OUT/c4_bench.err" || exit 1
 fi
 if has pin; then
   echo "== exr pin calibration" && timeout -k 10 600 "$PY" tests/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
