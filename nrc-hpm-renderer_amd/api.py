@@ -91,7 +91,8 @@ _lib = None
 
 def build_id():
     """the hash of sources + compiler + flags the loaded library was built from (csrc/Makefile: NRC_BUILD_ID, the tail of nrc_version())"""
-    return load_library().nrc_version().decode().rsplit("build ", 1)[1]
+    v = load_library().nrc_version().decode()
+    return v.rsplit("build ", 1)[1] if "build " in v else "unknown (a library older than the build id, loaded through NRC_HPM_LIB)"
 
 
 def load_library():

@@ -20,6 +20,19 @@
 
 #include "nrc_math.h"
 
+// 1: the tracking loops carry their predicates as uniform 64-bit lane masks (round 4); 0: as per-lane bools (round 3)
+#ifndef NRC_TRACK_MASKS
+#define NRC_TRACK_MASKS 1
+#endif
+// 1: every look-up tests the LDS occupancy bits unconditionally; 0 (product): behind a wave-uniform test for the table, as in round 3.
+// Round 4 measured both: without the test k_gen_rays is 1 % faster alone (0.2092 against 0.2117 ms: one branch and four mask merges
+// fewer per trip) and 12 % faster inside the configs[4] frame (0.283 against 0.318 ms) -- and the FRAMES are slower, 7 730 against 7 850
+// Msamples/s on the default preset and 4 160 against 4 810 on configs[4]: a camera kernel that issues more densely leaves the
+// inference / training kernels beside it fewer issue slots (train stage 0.18 -> 0.23 ms, configs[4] train rays 0.53 -> 0.98 ms), and
+// those set the frame rate wherever they are the longer chain.  (tools/ab_config.sh, same box, lib / lib_o0 / lib_m0o0 / round 3's.)
+#ifndef NRC_OCC_ALWAYS
+#define NRC_OCC_ALWAYS 0
+#endif
 // 1 (product): software-pipelined, predicated tracking loops; 0 (diagnostic A/B build): the plain two-collision loops
 #ifndef NRC_TRACK_PIPELINE
 #define NRC_TRACK_PIPELINE 1
@@ -335,9 +348,11 @@ __device__ __forceinline__ Addr2 fetch2_addr(const C& c, V3 dir, V3 start, float
     const uint32_t x1 = (uint32_t)fx.y, y1 = (uint32_t)fy.y, z1 = (uint32_t)fz.y;
     const uint32_t idx0 = index24(z0, s.ny, y0, s.nx, x0);
     const uint32_t idx1 = index24(z1, s.ny, y1, s.nx, x1);
+#if !NRC_OCC_ALWAYS
+    if (c.occ != nullptr)
+#endif
     {      // occupancy bit of the voxel's cell from LDS: an empty cell's byte is 0 without asking memory.  (The table always exists --
-           // Scene::build_occupancy_bits; all ones under NRC_NO_OCCUPANCY --: a test for it here is a branch and four mask merges in
-           // every tracking loop, and scalar instructions cost a SIMD as much issue time as vector ones: tools/issue_mix.hip)
+           // Scene::build_occupancy_bits; all ones under NRC_NO_OCCUPANCY.)
         const uint32_t sh = s.occ_shift;
         uint32_t c0 = index24(z0 >> sh, s.occ_gy, y0 >> sh, s.occ_gx, x0 >> sh);
         uint32_t c1 = index24(z1 >> sh, s.occ_gy, y1 >> sh, s.occ_gx, x1 >> sh);
@@ -676,6 +691,7 @@ __device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool al
 __device__ __forceinline__ bool lane_bool(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ unsigned long long lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
+#if NRC_TRACK_MASKS
 template <bool UNI = false, class C>
 __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
 {
@@ -734,6 +750,62 @@ __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid 
     c.rng = rng;
     return tr;
 }
+#else      // round 3's loops: per-lane bools as the loop-carried predicates
+template <bool UNI = false, class C>
+__device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
+{
+    V3 d = sub(end, start);
+    const V3 dir = normalize(d);
+    const float t_max = length(d);
+    const float inv = c.sc.inv_max_density;
+    float tr = 1.0f;
+    float rng = c.rng;
+    bool alive = valid;
+    RatioTrip a = ratio_trip(rng, 0.0f, t_max, inv);
+    Addr2 ia = fetch2_addr(c, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
+    float bs = rng, bt = 0.0f;                 // base of the located trip `a`: chain value and position before its first draw
+    for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
+        rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
+        alive &= a.live1;
+#ifdef NRC_DIAG_CUT_TAIL
+        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
+#else
+        if (__ballot(alive) == 0ull) break;
+#endif
+#if NRC_PAIR_TAIL
+        if constexpr (UNI) {
+            const unsigned long long am = __ballot(alive);
+            if (__popcll(am) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
+                ratio_pairs(c, am, alive, start, dir, t_max, inv, bs, bt, i, tr, rng);
+                break;
+            }
+        }
+#endif
+        if (alive) NRC_PROF(c, 3);
+        NRC_PROF_LIVE(0, __ballot(alive));
+        const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
+        __builtin_amdgcn_sched_barrier(0);
+        const bool last = i + 2 >= 128;
+        const bool more = alive & a.second & !last;
+        const RatioTrip b = ratio_trip(a.s2, a.t2, t_max, inv);      // ... fly while the next trip is located
+        const Addr2 ib = fetch2_addr(c, dir, start, b.t1, b.t2, more & b.live1, more & b.live1 & b.second);
+        __builtin_amdgcn_sched_barrier(0);
+        const f2 dens = fetch2_density(c.sc, fa);
+        const bool two = alive & a.second;
+        c.count(alive ? (a.second ? 2u : 1u) : 0u);
+        tr = alive ? tr * nrc_fmaf_(-dens.x, inv, 1.0f) : tr;
+        tr = two ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
+        rng = (alive & (!a.second | last)) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
+        alive = more;
+        bs = a.s2;
+        bt = a.t2;
+        a = b;
+        ia = ib;
+    }
+    c.rng = rng;
+    return tr;
+}
+#endif
 #else
 // reference form of the loop (diagnostic build -DNRC_TRACK_PIPELINE=0): two collisions per trip, gathers awaited in the trip
 // get_density at start + dir*t1 and start + dir*t2 (second fetch masked unless `second`); returns densities
@@ -994,6 +1066,7 @@ __device__ __forceinline__ void delta_pairs(C& c, unsigned long long am, bool al
 }
 
 #if NRC_TRACK_PIPELINE
+#if NRC_TRACK_MASKS
 template <bool UNI = false, class C>
 __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
 {
@@ -1078,6 +1151,83 @@ __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit,
     }
     return madd(rd, c.rand(t_max), ro);
 }
+#else
+template <bool UNI = false, class C>
+__device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
+{
+    V3 en, ex;
+    if constexpr (UNI) {      // lanes without a walk march a harmless ray (from the centre along +z): the march must end for them too
+        find_entry_exit(c, sel(valid, ro, v3(0.0f, 0.0f, 0.0f)), sel(valid, rd, v3(0.0f, 0.0f, 1.0f)), &en, &ex);
+    } else {
+        find_entry_exit(c, ro, rd, &en, &ex);
+    }
+    const float t_max = length(sub(ex, ro));
+    const float inv = c.sc.inv_max_density;
+    float rng = c.rng;
+    bool alive = valid, hit = false, vexit = false;
+    float t_hit = 0.0f;
+    DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
+    Addr2 ia = fetch2_addr(c, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
+    float bs = rng, bt = 0.0f;                 // base of the located trip `a`
+    for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:161); predicated like ratio_track
+        const bool out1 = alive & !a.live1;                          // collision 1 beyond the exit point
+        rng = out1 ? a.s1 : rng;
+        vexit |= out1;
+        alive &= a.live1;
+#ifdef NRC_DIAG_CUT_TAIL
+        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
+#else
+        if (__ballot(alive) == 0ull) break;
+#endif
+#if NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
+        if constexpr (UNI) {
+            const unsigned long long am = __ballot(alive);
+            if (__popcll(am) <= 31) {        // few walks left: two lanes each (delta_pairs)
+                delta_pairs(c, am, alive, ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
+                break;
+            }
+        }
+#endif
+        if (alive) NRC_PROF(c, 2);
+        NRC_PROF_LIVE(2, __ballot(alive));
+        const Fetch2 fa = fetch2_load(c, ia);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool last = i + 2 >= 128;
+        const DeltaTrip b = delta_trip(a.a2, a.t2, t_max, inv);      // located ahead; used only if this trip accepts nothing
+        const bool maybe = alive & a.second & !last;
+        const Addr2 ib = fetch2_addr(c, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
+        __builtin_amdgcn_sched_barrier(0);
+        const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
+        c.count(alive ? 1u : 0u);
+        const bool acc1 = alive & (dens.x > a.a1);
+        const bool alive2 = alive & !acc1;
+        const bool out2 = alive2 & !a.second;                        // collision 2 beyond the exit point
+        const bool alive3 = alive2 & a.second;
+        c.count(alive3 ? 1u : 0u);
+        const bool acc2 = alive3 & (dens.y > a.a2);
+        hit |= acc1 | acc2;
+        t_hit = acc1 ? a.t1 : (acc2 ? a.t2 : t_hit);
+        vexit |= out2;
+        // RNG state of the event that ended the walk: accept 1 -> a1, exit 2 -> s2, accept 2 or the 128-collision cap -> a2
+        rng = acc1 ? a.a1 : rng;
+        rng = out2 ? a.s2 : rng;
+        rng = (alive3 & (acc2 | last)) ? a.a2 : rng;
+        alive = alive3 & !acc2 & !last;
+        bs = a.a2;
+        bt = a.t2;
+        a = b;
+        ia.i0 = alive ? ib.i0 : 0x80000000u;                         // a lane that has just finished fetches nothing next trip
+        ia.i1 = alive ? ib.i1 : 0x80000000u;
+    }
+    c.rng = rng;
+    *volume_exit = vexit;
+    if (hit) return madd(rd, t_hit, ro);
+    if constexpr (UNI) {
+        if (!valid) return ro;          // no walk: no draw
+    }
+    return madd(rd, c.rand(t_max), ro);
+}
+#endif
 #else
 template <bool UNI = false, class C>
 __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
