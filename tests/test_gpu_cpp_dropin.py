@@ -74,3 +74,56 @@ def test_cpp_host_program_matches_python_mirror(api, sc, torch_gpu, tmp_path):
     assert img[..., 3].min() == 1.0 and np.isfinite(img).all() and img[..., :3].max() > 0
     ren.Destroy()
     nrc.Destroy()
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_reference_and_gather_over_host_hooks(api, sc, torch_gpu, tmp_path):
+    """tests/cpp/sharded_main.cpp: two host threads as two ranks of a 200x64 frame (strips of 8 columns: 104 / 96 columns) over a
+    host-staged transport installed with NeuralRadianceCache::SetCollectiveHooks -- en::Reference(..., &tile, &nrc)::CompareNrc gives
+    both ranks the WHOLE frame's Result (== nrc_compare_images of the single-GPU frame up to the rounding of the fp64 sums),
+    NrcHpmRenderer::GatherFrame gives both ranks the single-GPU frame bit for bit, and the collective ExportOutputImageToFile writes it"""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    from nrc_hpm_renderer_amd import io_exr
+    exe = entry.build_cpp_sharded()
+    W, H = 200, 64
+    vol = sc.quantize_density(sc.sphere_volume(32))
+    scene = sc.make_scene(vol, scene_id=4, env=sc.white_env())
+    with open(tmp_path / "scene.bin", "wb") as f:
+        f.write(struct.pack("5I", W, H, *scene["dims"]))
+        f.write(np.asarray(scene["env"], np.float32).reshape(-1)[:4].tobytes())
+        f.write(np.ascontiguousarray(scene["density"], np.uint8).tobytes())
+    # a ground-truth image of the GLOBAL size where Reference expects it: <root>/<scene id>/0.exr
+    rng = np.random.default_rng(17)
+    ref = rng.random((H, W, 4), dtype=np.float32)
+    ref[..., 3] = (rng.random((H, W)) < 0.6).astype(np.float32)
+    ref_root = str(tmp_path / "reference") + "/"
+    os.makedirs(os.path.join(ref_root, "4"))
+    io_exr.write_exr(os.path.join(ref_root, "4", "0.exr"), ref, compression="zip")
+    exr_out = str(tmp_path / "whole.exr")
+    r = subprocess.run([exe, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), ref_root, exr_out] + ARGS, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "sharded ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    raw = np.fromfile(tmp_path / "out.bin", np.float32)
+    cam = dict(inv_proj_view=raw[:16].copy(), pos=raw[16:19].copy())      # en::Camera's fp32 matrices: the counterpart uses exactly these
+    scene = dict(scene, dir_light_dir=raw[19:22].copy())
+    res = raw[22:32].reshape(2, 5)
+    frames = raw[32:].reshape(2, H, W, 4)
+    # the single-GPU counterpart through the Python mirror: the frame CompareNrc renders is the renderer's first unpinned frame from
+    # the reference camera (same seed, same draw on every tile); the gathered frame was rendered with the pinned random
+    cfg = api.AppConfig(["NRC-HPM-Renderer"] + ARGS)
+    nrc = api.NeuralRadianceCache(cfg)
+    ren = api.NrcHpmRenderer(W, H, False, cam, cfg, scene, nrc)
+    ren.Render(None, False)
+    want = api.CompareImages(torch_gpu.from_numpy(ref).cuda(), ren.GetImage())
+    want5 = np.asarray([want[k] for k in ("mse", "ref_mean", "own_mean", "own_var", "valid")], np.float32)
+    assert np.array_equal(res[0], res[1]) and res[0][4] == want5[4] == (ref[..., 3] != 0).sum()
+    assert np.allclose(res[0], want5, rtol=3e-7, atol=0.0), (res[0], want5)
+    ren.SetCamera(None, cam)
+    ren.SetFrameRandom([0.6180339887, 0.4142135623, 0.7320508075, 0.2360679775])
+    ren.Render(None, False)
+    img = ren.GetImage().cpu().numpy()
+    assert np.array_equal(frames[0].view(np.uint32), img.view(np.uint32)) and np.array_equal(frames[1].view(np.uint32), img.view(np.uint32))
+    assert np.array_equal(io_exr.read_exr(exr_out).view(np.uint32), img.view(np.uint32))
+    assert np.isfinite(img).all() and (np.abs(img[..., :3]).sum(axis=(0, 2)) > 0).all()
+    ren.Destroy()
+    nrc.Destroy()
