@@ -557,6 +557,10 @@ __device__ __forceinline__ void loss_terms(uint32_t loss_id, const float (&y)[3]
     }
 }
 
+// 1: the fused training step runs k_train_fwd_bwd_light (round 4: two phases, 54 KB of LDS, <= 128 registers); 0: k_train_fwd_bwd (round 3)
+#ifndef NRC_TRAIN_LIGHT
+#define NRC_TRAIN_LIGHT 1
+#endif
 struct TrainArgs {
     const float* in;
     const float* target;
@@ -669,6 +673,157 @@ __global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const ui
                 for (int s = 0; s < KSH; s++) {
                     d0 = mfma(ld_frag(lb, base + s, lane), dl[s], d0);
                     d1 = mfma(ld_frag(lb, base + KSH + s, lane), dl[s], d1);
+                }
+            }
+        }
+    }
+}
+
+// Round 4: the same arithmetic in two phases per round of tiles, so that the workgroup needs ONE weight image in LDS at a time
+// (54 KB instead of 98: a CU that holds a k_infer workgroup beside gen_rays' five has 66 KB free) and 128 registers instead of 272:
+//   phase 1 (forward image staged): encode, forward chain -- every layer's activations go to HBM the moment they exist and ONE BIT per
+//           activation (is it positive: all the dgrad chain needs of it) stays in registers --, loss and dL/dy;
+//   phase 2 (W^T image staged over the forward image): the dgrad chain from dL/dy and the bits.
+// Bit-identical to k_train_fwd_bwd (NRC_TRAIN_LIGHT=0 selects it; tests/test_gpu_mlp.py compares both with the oracle).
+template <int DEPTH, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_train_fwd_bwd_light(TrainArgs a, const uint4* __restrict__ img_fwd,
+                                                                   const uint4* __restrict__ img_bwd)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* lw = reinterpret_cast<uint4*>(smem);      // the forward image, then the W^T image
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = a.n >> 5;               // host guarantees n % 32 == 0
+    constexpr uint32_t WAVES = THREADS / 64;
+    const uint32_t stride = gridDim.x * WAVES;
+    constexpr int ROWS_A = ENC + DEPTH * WIDTH;
+    constexpr int ROWS_D = DEPTH * WIDTH + 8;
+    for (uint32_t t0 = blockIdx.x * WAVES; t0 < n_tiles; t0 += stride) {      // a round: one tile per wave; uniform over the workgroup
+        const uint32_t tile = t0 + (uint32_t)wave;
+        const bool active = tile < n_tiles;
+        if (t0 != blockIdx.x * WAVES) __syncthreads();                       // (the previous round's dgrad chains have read the W^T image)
+        stage_lds(lw, img_fwd, n_frag_fwd(DEPTH) * 64, threadIdx.x, THREADS);
+        __syncthreads();
+        const uint32_t sidx = tile * 32u + r;
+        uint32_t relu_bits[DEPTH];
+        half8 bo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
+#pragma unroll
+        for (int l = 0; l < DEPTH; l++) relu_bits[l] = 0u;
+        half_t* const pd = a.deltas + ((size_t)(sidx >> 3) * ROWS_D) * 8 + (sidx & 7u);
+        half_t* const pd4 = pd + 32 * h;
+        if (active) {
+            const float* p = a.in + (size_t)sidx * 5u;
+            float x[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) x[i] = p[i];
+            half8 enc[KS0];
+            encode80(x, h, enc);
+            // ---- activations -> HBM in [sample/8][row][8] order: the 16-byte k-groups the weight-gradient GEMM reads; row offsets are
+            //      compile-time immediates on two per-lane bases (+8h / +4h rows)
+            half_t* const pa = a.acts + ((size_t)(sidx >> 3) * ROWS_A) * 8 + (sidx & 7u);
+            half_t* const pa8 = pa + 64 * h;      // rows + 8h
+            half_t* const pa4 = pa + 32 * h;      // rows + 4h
+#pragma unroll
+            for (int s = 0; s < KS0; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (s < 4) pa8[(16 * s + j) * 8] = enc[s][j];
+                    else pa4[(j < 4 ? 64 + j : 72 + (j - 4)) * 8] = enc[s][j];
+                }
+            f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+            for (int s = 0; s < KS0; s++) {
+                acc0 = mfma(ld_frag(lw, FRAG_L0 + 0 * KS0 + s, lane), enc[s], acc0);
+                acc1 = mfma(ld_frag(lw, FRAG_L0 + 1 * KS0 + s, lane), enc[s], acc1);
+            }
+            half8 b[KSH];
+#pragma unroll
+            for (int l = 0; l < DEPTH; l++) {
+                asm volatile("" ::: "memory");      // a layer's LDS fragment reads stay in the layer (hoisted, they cost 4 VGPRs each)
+                if (l > 0) {
+                    acc0 = zero16();
+                    acc1 = zero16();
+                    const int base = FRAG_HID + (l - 1) * MT * KSH;
+#pragma unroll
+                    for (int s = 0; s < KSH; s++) {
+                        acc0 = mfma(ld_frag(lw, base + s, lane), b[s], acc0);
+                        acc1 = mfma(ld_frag(lw, base + KSH + s, lane), b[s], acc1);
+                    }
+                }
+                relu_pack(acc0, b[0], b[1]);
+                relu_pack(acc1, b[2], b[3]);
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int s = 0; s < KSH; s++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        pa4[(ENC + WIDTH * l + kperm(s, 0, j)) * 8] = b[s][j];
+                        bits |= (b[s][j] > (half_t)0.0f) ? (1u << (8 * s + j)) : 0u;
+                    }
+                // computed HERE: sunk to its use in the dgrad chain (where the scheduler puts it), the word keeps the layer's 16 VGPRs of
+                // activations alive -- 305 VGPRs instead of 140
+                asm volatile("" : "+v"(bits));
+                relu_bits[l] = bits;
+            }
+            f32x16 y = zero16();
+#pragma unroll
+            for (int s = 0; s < KSH; s++) y = mfma(ld_frag(lw, frag_out(DEPTH) + s, lane), b[s], y);
+
+            // ---- loss + dL/dy (lanes h==0 hold y)
+            float loss_v = 0.0f;
+            if (h == 0) {
+                const float* t = a.target + (size_t)sidx * 3u;
+                const float yv[3] = {y[0], y[1], y[2]};
+                float dy[3];
+                loss_terms(a.loss_id, yv, t, a.inv_n_total, loss_v, dy);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    bo[c] = (half_t)dy[c];
+                    pd[(DEPTH * WIDTH + c) * 8] = bo[c];
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
+            if (lane == 0) a.loss_part[tile] = loss_v;
+        }
+        __syncthreads();                                                     // every forward chain has read the forward image
+        stage_lds(lw, img_bwd, n_frag_bwd(DEPTH) * 64, threadIdx.x, THREADS);
+        __syncthreads();
+        if (active) {
+            // ---- dgrad chain: delta_{l-1} = relu'(a_{l-1}) * (W_l^T delta_l)
+            const int bout = (DEPTH - 1) * MT * KSH;
+            f32x16 d0 = mfma(ld_frag(lw, bout + 0, lane), bo, zero16());
+            f32x16 d1 = mfma(ld_frag(lw, bout + 1, lane), bo, zero16());
+#pragma unroll
+            for (int l = DEPTH - 1; l >= 0; l--) {
+                half8 dl[KSH];
+                const uint32_t bits = relu_bits[l];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    dl[0][j] = ((bits >> j) & 1u) ? (half_t)d0[j] : (half_t)0.0f;
+                    dl[1][j] = ((bits >> (8 + j)) & 1u) ? (half_t)d0[8 + j] : (half_t)0.0f;
+                    dl[2][j] = ((bits >> (16 + j)) & 1u) ? (half_t)d1[j] : (half_t)0.0f;
+                    dl[3][j] = ((bits >> (24 + j)) & 1u) ? (half_t)d1[8 + j] : (half_t)0.0f;
+                }
+#pragma unroll
+                for (int s = 0; s < KSH; s++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        pd4[(WIDTH * l + kperm(s, 0, j)) * 8] = dl[s][j];
+                if (l > 0) {
+                    asm volatile("" ::: "memory");
+                    d0 = zero16();
+                    d1 = zero16();
+                    const int base = (l - 1) * MT * KSH;
+#pragma unroll
+                    for (int s = 0; s < KSH; s++) {
+                        d0 = mfma(ld_frag(lw, base + s, lane), dl[s], d0);
+                        d1 = mfma(ld_frag(lw, base + KSH + s, lane), dl[s], d1);
+                    }
                 }
             }
         }
@@ -2155,6 +2310,22 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
     else if (threads == 256 && nt == 4) launch_infer<256, 4>(blocks, lds, s, d_in, d_out, n, img, sz);
     else
 #endif
+    // Renderer-mode launches (skip_zero_queries: the launch runs BESIDE gen_rays) of up to a 1080p frame's worth of queries use 4-wave
+    // workgroups -- one 116-register wave per SIMD instead of two: a workgroup finds room once ONE of a SIMD's five camera waves has
+    // retired (the same reason the 128-wide kernel does it, above).  Same box, default preset: 7 890-7 940 -> 7 990-8 020 Msamples/s;
+    // 2-wave workgroups lose (7 500: twice the weight-image traffic), and the 8.3 M queries of a whole 4K frame on one GPU prefer the
+    // 8-wave form (7 970 against 7 820).  NRC_INFER_RENDER_THREADS=512 restores it everywhere.
+#ifndef NRC_INFER_RENDER_THREADS
+#define NRC_INFER_RENDER_THREADS 256
+#endif
+    if (NRC_INFER_RENDER_THREADS != 512 && skip_zero_queries && composite == nullptr && n <= (3u << 20)) {
+        constexpr int T = NRC_INFER_RENDER_THREADS;
+        uint32_t b2 = ceil_div(n_tiles, (uint32_t)(T / 64) * 2u);
+        const uint32_t cap = (uint32_t)num_cus() * 2u;
+        launch_infer<T, 2>(b2 > cap ? cap : b2, lds, s, d_in, d_out, n, img, sz);
+        NRC_HIP(hipGetLastError());
+        return;
+    }
     launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz, composite);
     NRC_HIP(hipGetLastError());
 }
@@ -2284,14 +2455,18 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.deltas = (half_t*)d_deltas_;
         a.loss_part = d_loss_part_;
         if (blocks > (uint32_t)num_cus()) blocks = (uint32_t)num_cus();
+#if NRC_TRAIN_LIGHT
+        const size_t lds = (size_t)std::max(n_frag_fwd_, n_frag_bwd_) * 1024;      // one image at a time
+        auto kernel = k_train_fwd_bwd_light<6, THREADS>;
+#else
         const size_t lds = ((size_t)n_frag_fwd_ + n_frag_bwd_) * 1024;
+        auto kernel = k_train_fwd_bwd<6, THREADS>;
+#endif
         if (!attr_train_set_) {
-            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_fwd_bwd<6, THREADS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_train_set_ = true;
         }
-        hipLaunchKernelGGL((k_train_fwd_bwd<6, THREADS>), dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_,
-                           (const uint4*)d_pk_bwd_);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
     } else {
         launch_features(d_in, n, false, 1, s, false);
         if (hash_) NRC_HIP(hipMemsetAsync(d_grad16_, 0, (size_t)n_grid_entries_ * 4, s));
