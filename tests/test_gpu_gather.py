@@ -112,3 +112,31 @@ def test_gather_of_ragged_column_tiles_and_sharded_metrics(api, sc, torch_gpu):
         x.Destroy()
     for c in caches + [nrc1]:
         c.Destroy()
+
+
+def test_unsharded_renderer_and_single_rank_cache_take_the_trivial_paths(api, sc, torch_gpu):
+    """one rank: nrc_renderer_gather_frame copies the framebuffer, nrc_compare_images_sharded needs no communicator and equals
+    nrc_compare_images up to the rounding of its fp64 folds"""
+    torch = torch_gpu
+    W, H = 128, 64
+    vol = sc.quantize_density(sc.fbm_cloud_volume(32, seed=3))
+    scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky(32, 16))
+    cam = sc.make_camera(aspect=W / H)
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=13)
+    nrc = api.NeuralRadianceCache(cfg)
+    ren = api.NrcHpmRenderer(W, H, False, cam, cfg, scene, nrc)
+    ren.Render(None, True)
+    img = ren.GetImage().clone()
+    got = ren.GatherFrame()
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), img.view(torch.int32))
+    rng = np.random.default_rng(9)
+    ref = rng.random((H, W, 4), dtype=np.float32)
+    ref[..., 3] = (rng.random((H, W)) < 0.5).astype(np.float32)
+    ref = torch.from_numpy(ref).cuda()
+    a, b = api.CompareImages(ref, img), api.CompareImagesSharded(nrc, ref, img)
+    assert a["valid"] == b["valid"] > 1000
+    for k in ("mse", "ref_mean", "own_mean", "own_var"):
+        assert abs(a[k] - b[k]) <= 3e-7 * abs(a[k]), (k, a[k], b[k])
+    ren.Destroy()
+    nrc.Destroy()
