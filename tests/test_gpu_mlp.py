@@ -134,6 +134,29 @@ def test_backward_matches_oracle(api, orc, torch_gpu, loss_fn, loss_id):
     c.Destroy()
 
 
+def test_backward_of_a_batch_longer_than_one_round_of_workgroups(api, torch_gpu):
+    """k_train_fwd_bwd_light alternates its two weight images in ONE LDS buffer per round of tiles (a workgroup per four 32-ray tiles,
+    at most one workgroup per CU): a batch of 40 992 rays = 1 281 tiles takes two rounds on 256 CUs, the last one ragged (one tile in a
+    workgroup of four waves).  Its gradient is the sum of its parts' gradients -- each part small enough for one round -- against the same
+    normaliser, and the run is bitwise reproducible"""
+    c = api.NeuralRadianceCache(api.AppConfig())
+    n = 40992
+    x = torch_gpu.from_numpy(queries(n, seed=51, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((n, 3), device="cuda")
+    c.Backward(x, t)
+    full, loss_full = c.GetParams(4), c.GetLoss()
+    c.Backward(x, t)
+    assert np.array_equal(full, c.GetParams(4))
+    parts, loss = np.zeros_like(full, np.float64), 0.0
+    for a in range(0, n, 8192):
+        b = min(a + 8192, n)
+        c.Backward(x[a:b].contiguous(), t[a:b].contiguous(), nNorm=n)
+        parts += c.GetParams(4)
+        loss += c.GetLoss()
+    assert rel(parts.astype(np.float32), full) < 1e-5 and abs(loss - loss_full) < 1e-5 * abs(loss_full)
+    c.Destroy()
+
+
 def test_backward_is_bitwise_reproducible(cache, torch_gpu):
     x = torch_gpu.from_numpy(queries(4096, seed=4, nan_frac=0.0)).cuda()
     t = torch_gpu.rand((4096, 3), device="cuda")
