@@ -247,6 +247,8 @@ class Job:
                 print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
                 parallel.attach_gradient_allreduce(self.nrc, world, native=False)
                 self.exchange = dict(path="torch.distributed hook (%s)" % dist.get_backend(), rccl_rank=rank, rccl_ranks=world)
+                if world > 1:
+                    self.nrc.SetCollectiveHooks(rank, world)      # frame gather / metric reduction over the same transport
         self.randoms = None
         self.ri = 0
 
@@ -295,6 +297,27 @@ class Job:
         if self.exchange["path"].startswith("native"):
             return self.nrc.CommTimeExchange(100)
         return None
+
+    def frame_assembly_ms(self, reps=5):
+        """what the product's own multi-GPU frame assembly costs (collective calls, every rank): nrc_renderer_gather_frame -- one
+        all-gather of the ranks' column strips + a de-interleave -- and nrc_compare_images_sharded -- five local fp64 sums, two tiny
+        all-reduces -- each averaged over `reps` calls behind one warm-up call; None where the frame is not sharded"""
+        if self.world <= 1 or not (self.use_dist and self.args.train):
+            return None
+        torch = self.torch
+        ref = torch.rand((self.gh, self.local_w, 4), device="cuda")
+        own = self.ren.GetImage().contiguous()
+        out = {}
+        for name, fn in (("gather_frame_ms", lambda: self.ren.GatherFrame()),
+                         ("compare_sharded_ms", lambda: self.api.CompareImagesSharded(self.nrc, ref, own))):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / reps * 1e3
+        return out
 
     def close(self):
         self.ren.Destroy()
@@ -366,6 +389,7 @@ def main():
     torch.cuda.synchronize()
     ren.StageStats(reset=True)
     allreduce_us = job.allreduce_us() if use_dist and args.train else None
+    assembly = job.frame_assembly_ms()
 
     # ---- integrator traffic model: density look-ups counted on the device for extra (untimed) sub-frames of the same seed --
     # n_fetch: the ALGORITHM's look-ups (every camera ray walked, as the reference and the oracle do; empty-space early-out off),
@@ -521,7 +545,7 @@ def main():
             workload = ("%s: %dx%d per GPU (global %dx%d, tiles of interleaved 8-column strips), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
                         "train=%d (%d train rays + 1 Adam step per sub-frame)"
                         % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", W, H, gw, gh, volume, spp, model, args.train, train_rays))
-        exchange = dict(exchange, allreduce_us_per_step=allreduce_us)
+        exchange = dict(exchange, allreduce_us_per_step=allreduce_us, frame_assembly=assembly)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

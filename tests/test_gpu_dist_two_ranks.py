@@ -102,11 +102,15 @@ def test_bench_self_launches_its_ranks(torch_gpu):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["value"] > 100
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["value"] > 1
     assert d["exchange"]["rccl_ranks"] == 2 and "hook" in d["exchange"]["path"]
+    fa = d["exchange"]["frame_assembly"]                                # the product's own gather + metric reduction, timed
+    assert fa["gather_frame_ms"] > 0 and fa["compare_sharded_ms"] > 0 and d["cpu_baseline"] is None and d["cpu_baseline_reason"]
     assert "3840x1080" in d["config"]["workload"]
     c4 = d["strong_scaling_c4"]
-    assert c4["scaling"] == "strong" and c4["value"] > 100 and "1920 columns per rank" in c4["workload"] and "8192 per rank" in c4["workload"]
+    # (the rehearsal's RATES mean nothing -- two ranks share one GPU and every gradient exchange is a host-side gloo all-reduce, tens to
+    # hundreds of milliseconds when the host is busy --: the line's arithmetic and labels are what is checked)
+    assert c4["scaling"] == "strong" and c4["value"] > 1 and "1920 columns per rank" in c4["workload"] and "8192 per rank" in c4["workload"]
     assert abs(c4["ms_per_step"] - 3840 * 2160 * 8 / c4["value"] / 1e3) < 1e-6 * c4["ms_per_step"] + 1e-9
 
 
