@@ -14,14 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_json_line(torch_gpu):
     env = dict(os.environ, NRC_BENCH_CPU_BUDGET_S="2")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
                        capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["unit"] == "Msamples/s" and d["value"] > 100 and d["higher_is_better"] is True
-    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "1920x1080" in d["config"]["workload"] and "model" not in d["config"]
     assert abs(d["ms_per_step"] - 1920 * 1080 * 4 / d["value"] / 1e3) < 1e-6 * d["ms_per_step"] + 1e-9
     roof = d["roofline"]
