@@ -269,6 +269,11 @@ float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
 /* the same stage times averaged over every frame rendered since the last reset (HIP events on the renderer's streams);
  * *frames = number of frames covered.  avg_ms == NULL with reset != 0 only forgets the frames so far, without reading an event */
 int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frames, int reset);
+/* the same events as a timeline (the reference's per-frame timestamp queries, src/NrcHpmRenderer.cu:495-515, kept for every frame since
+ * the last reset): times_ms[f * 6 + k] = milliseconds from the first frame's start to event k of frame f -- 0 gen_rays starts, 1 gen_rays
+ * done, 2 train rays done, 3 inference done, 4 compositing done, 5 training done -- for the first min(*frames, max_frames) frames;
+ * synchronises, resets nothing.  Shows which stream a pipelined frame waits for (tools/frame_timeline.py). */
+int nrc_renderer_frame_timeline(nrc_renderer_t* r, float* times_ms, uint32_t max_frames, uint32_t* frames);
 /* NrcHpmRenderer::Destroy */
 int nrc_renderer_destroy(nrc_renderer_t* r);
 /* intermediate device buffers of the most recent frame, after synchronising all of the renderer's streams (tests /

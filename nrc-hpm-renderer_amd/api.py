@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_framebuffer_on",
     "nrc_renderer_export_exr",
-    "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
+    "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_frame_timeline", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
     "nrc_renderer_train_grid",
     "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
     "nrc_mc_renderer_set_frame_random", "nrc_mc_renderer_framebuffer", "nrc_mc_renderer_export_exr",
@@ -562,6 +562,15 @@ class NrcHpmRenderer:
         d = dict(zip(names, [float(x) for x in st]))
         d["frames"] = n.value
         return d
+
+    def FrameTimeline(self, max_frames=4096):
+        """[frames, 6] ms from the first frame's start (since the last reset) to each frame's events: gen_rays start / done, train rays
+        done, inference done, compositing done, training done (nrc_renderer_frame_timeline)"""
+        import numpy as np
+        buf = (C.c_float * (6 * max_frames))()
+        n = C.c_uint32(0)
+        _check(self.L.nrc_renderer_frame_timeline(self.h, buf, C.c_uint32(max_frames), C.byref(n)))
+        return np.ctypeslib.as_array(buf)[:6 * n.value].reshape(n.value, 6).copy()
 
     def ResetStageStats(self):
         """forget the frames rendered so far without reading their events (StageStats(reset=True) reads every one of them first)"""

@@ -1477,6 +1477,7 @@ struct TrainArgsGen {
     float* loss_part;
     int depth, ks0;
     half_t* d_enc;        // [n][32] dL/d(first 32 encoded dims) for a trainable encoding (HashGrid), or nullptr
+    int diag_no_store;    // DIAGNOSTIC (NRC_DIAG_SKIP & 16, k_train_gen2): activations and deltas are not written
 };
 
 // Generic training forward + loss + dgrad (any encoding, width 32 / 64 / 128, any depth).  Like k_infer_gen the workgroup streams the
@@ -1688,6 +1689,231 @@ __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const 
     }
 }
 
+// ---- round 4: the same training step with every layer's ROWS split over the waves of a workgroup (k_train_gen2).
+// k_train_gen costs configs[4]'s frame a fifth of its rate (tools/ab_skip.sh: 4 720 -> 5 740 Msamples/s without it) although it
+// runs only 51 us alone: a wave carries a whole 32-sample tile through every layer -- MTG accumulators, the layer's operand and two
+// staged weight images: 219 + 64 registers and 80 KB of LDS per workgroup --, so a workgroup needs a CU that gen_rays has all but
+// left, and holds it for 17 barrier-to-barrier stages of 32 dependent MFMAs.  Here wave w of a sample group computes rows
+// 32w .. 32w+31 of the layer for NT tiles: it reads ITS weight fragments straight from L2 into registers one stage ahead (a fragment
+// has exactly one reader: no weight staging in LDS at all), the layer's input arrives as MFMA B operands through a 2 x 16 KB
+// ping-pong in LDS that the waves fill with their own row blocks of the previous layer (one barrier per stage), and the epilogue
+// work (ReLU / mask / fp16 pack, the k-group stores of activations and deltas) is split the same way.  ~145 registers, 53 KB of LDS
+// for an 8-layer net.  Every output element is the same sequence of MFMAs as in k_train_gen: activations, deltas and loss are
+// bit-identical (tests/test_gpu_mlp.py::test_training_kernels_agree).
+template <int WIDTH, int NT>
+__global__ __launch_bounds__(256) void k_train_gen2(TrainArgsGen a, const uint4* __restrict__ img_fwd, const uint4* __restrict__ img_bwd)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = 4, SG = WAVES / MTG;      // SG sample groups of MTG waves
+    constexpr int KA = KSG > 5 ? KSG : 5;                                               // weight fragments a wave holds per stage
+    constexpr int BBUF = SG * NT * KSG * 64;                                            // uint4 per B-operand buffer
+    extern __shared__ uint4 lds2[];      // B operands [2][SG][NT][KSG][64] | k-group scratch per wave | ReLU masks [WAVES][depth][NT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int sg = wave / MTG, w = wave % MTG;
+    const int depth = a.depth, ks0 = a.ks0;
+    const uint32_t e16 = (uint32_t)ks0 * 16u;
+    const uint32_t rows_a = e16 + (uint32_t)depth * WIDTH, rows_d = (uint32_t)depth * WIDTH + 8u;
+    const uint32_t n_tiles = a.n >> 5;
+    const uint32_t n_groups = (n_tiles + SG * NT - 1u) / (SG * NT);
+    uint4* const bbuf = lds2 + (size_t)sg * NT * KSG * 64;
+    half_t* const kg = reinterpret_cast<half_t*>(lds2 + 2 * BBUF) + wave * (KG_SCRATCH / 2);
+    uint32_t* const masks = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds2 + 2 * BBUF) + WAVES * KG_SCRATCH) +
+                            (size_t)wave * depth * NT * 64 + lane;
+    const int hid_base = MTG * ks0;
+    const int n_stages = 2 * depth + 1 + (a.d_enc != nullptr ? 1 : 0);
+    // stage st: this wave's run of fragments in the images (first fragment, count) -- see k_train_gen for the stages
+    auto stage_frags = [&](int st, const uint4*& src, int& cnt) {
+        if (st == 0) { src = img_fwd + (size_t)(w * ks0) * 64; cnt = ks0; }
+        else if (st < depth) { src = img_fwd + (size_t)(hid_base + (st - 1) * MTG * KSG + w * KSG) * 64; cnt = KSG; }
+        else if (st == depth) { src = img_fwd + (size_t)(hid_base + (depth - 1) * MTG * KSG) * 64; cnt = KSG; }      // (wave 0 uses it)
+        else {
+            const int j = st - depth - 1;
+            if (j == 0) { src = img_bwd + (size_t)((depth - 1) * MTG * KSG + w) * 64; cnt = 1; }
+            else if (j < depth) { src = img_bwd + (size_t)((depth - j - 1) * MTG * KSG + w * KSG) * 64; cnt = KSG; }
+            else { src = img_bwd + (size_t)((depth - 1) * MTG * KSG + MTG) * 64; cnt = KSG; }                        // (wave 0 uses it)
+        }
+    };
+    // branch-free: slots beyond the run load its last fragment again (in bounds, never multiplied with a non-zero operand)
+    half8 cur[KA], nxt[KA];
+    auto load_frags = [&](int st, half8 (&dst)[KA]) {
+        const uint4* src;
+        int cnt;
+        stage_frags(st, src, cnt);
+#pragma unroll
+        for (int s = 0; s < KA; s++) dst[s] = ld_frag_g(src, s < cnt ? s : cnt - 1, lane);
+    };
+    load_frags(0, nxt);
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        uint32_t tile[NT], sidx[NT];
+        bool act[NT];
+        half_t *ta[NT], *td[NT], *pd[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            tile[t] = (group * SG + (uint32_t)sg) * NT + (uint32_t)t;
+            act[t] = tile[t] < n_tiles;                              // wave-uniform
+            const uint32_t tl = act[t] ? tile[t] : 0u;
+            sidx[t] = tl * 32u + (uint32_t)r;
+            ta[t] = a.acts + (size_t)tl * 4u * rows_a * 8;           // the tile's four sample groups, row 0
+            td[t] = a.deltas + (size_t)tl * 4u * rows_d * 8;
+            pd[t] = a.deltas + ((size_t)(sidx[t] >> 3) * rows_d) * 8 + (sidx[t] & 7u);
+        }
+        f32x16 acc[NT];
+        // forward epilogue of layer st: this wave's 32 rows as the next layer's k-steps 2w, 2w+1 (LDS), as activations (HBM), as mask bits
+        auto fwd_epilogue = [&](int st, uint4* bn) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (!act[t]) continue;
+                half8 lo, hi;
+                relu_pack(acc[t], lo, hi);
+                bn[(t * KSG + 2 * w) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+                bn[(t * KSG + 2 * w + 1) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+                half_t* const tl = ta[t] + (size_t)(e16 + (uint32_t)st * WIDTH) * 8;
+                if (!a.diag_no_store) store_kgroups<true>(kg, lo, lane, tl + (size_t)(16 * (2 * w)) * 8, rows_a);
+                if (!a.diag_no_store) store_kgroups<true>(kg, hi, lane, tl + (size_t)(16 * (2 * w + 1)) * 8, rows_a);
+                const uint4v wl = __builtin_bit_cast(uint4v, lo), wh = __builtin_bit_cast(uint4v, hi);
+                uint32_t mk = 0u;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {      // ReLU output > 0 <=> its fp16 bits are non-zero; dword i: bit i low half, bit 16+i high half
+                    const uint32_t wi = i < 4 ? wl[i] : wh[i - 4];
+                    mk |= (((wi & 0x0000ffffu) != 0u ? 1u : 0u) | ((wi & 0xffff0000u) != 0u ? 0x10000u : 0u)) << i;
+                }
+                masks[(size_t)(st * NT + t) * 64] = mk;
+            }
+        };
+        // ---- stage 0: layer 0 on the encoded features (B operands straight from memory, every wave its own copy)
+        {
+#pragma unroll
+            for (int s = 0; s < KA; s++) cur[s] = nxt[s];
+            load_frags(1, nxt);
+            __syncthreads();                       // the previous group's last stage has read its B operands
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                acc[t] = zero16();
+                if (!act[t]) continue;
+                const half_t* fq = a.feat + (size_t)sidx[t] * e16 + 8 * h;
+                half8 f0[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {      // k-steps beyond ks0: load the last one again, use zeros -- no branches
+                    f0[k] = *reinterpret_cast<const half8*>(fq + 16 * (k < ks0 ? k : ks0 - 1));
+                    if (k >= ks0) f0[k] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    if (k < ks0 && (k % MTG) == w && !a.diag_no_store) store_kgroups<false>(kg, f0[k], lane, ta[t] + (size_t)(16 * k) * 8, rows_a);
+                    acc[t] = mfma(cur[k], f0[k], acc[t]);
+                }
+            }
+            fwd_epilogue(0, bbuf + BBUF);
+        }
+#pragma unroll 1
+        for (int st = 1; st < n_stages; st++) {
+            const bool last = st == n_stages - 1;
+            const bool more = !last || group + gridDim.x < n_groups;
+#pragma unroll
+            for (int s = 0; s < KA; s++) cur[s] = nxt[s];
+            if (more) load_frags(last ? 0 : st + 1, nxt);
+            __syncthreads();                       // B(st), written by the stage before, is complete
+            const uint4* bc = bbuf + (st & 1) * BBUF;
+            uint4* bn = bbuf + ((st + 1) & 1) * BBUF;
+            if (st < depth) {
+                // ---- forward layer st
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = zero16();
+#pragma unroll
+                for (int s = 0; s < KSG; s++) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        if (act[t]) acc[t] = mfma(cur[s], ld_frag(bc, t * KSG + s, lane), acc[t]);
+                }
+                fwd_epilogue(st, bn);
+            } else if (st == depth) {
+                // ---- output layer, loss, dL/dy: one row block, wave 0 of the sample group
+                if (w == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        if (!act[t]) continue;
+                        f32x16 y = zero16();
+#pragma unroll
+                        for (int s = 0; s < KSG; s++) y = mfma(cur[s], ld_frag(bc, t * KSG + s, lane), y);
+                        float loss_v = 0.0f;
+                        half8 bo;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
+                        if (h == 0) {
+                            const float* tg = a.target + (size_t)sidx[t] * 3u;
+                            const float yv[3] = {y[0], y[1], y[2]};
+                            float dy[3];
+                            loss_terms(a.loss_id, yv, tg, a.inv_n_total, loss_v, dy);
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                bo[c] = (half_t)dy[c];
+                                pd[t][(size_t)((uint32_t)depth * WIDTH + c) * 8] = bo[c];
+                            }
+                        }
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
+                        if (lane == 0) a.loss_part[tile[t]] = loss_v;
+                        bn[(t * KSG) * 64 + lane] = __builtin_bit_cast(uint4, bo);      // k-step 0 of the next stage's operand
+                    }
+                }
+            } else if (st <= 2 * depth) {
+                // ---- dgrad: W_{l+1}^T delta_{l+1} (the output layer's W^T first), then delta_l = relu'(a_l) * that
+                const int l = 2 * depth - st;      // the layer whose delta this stage produces: depth-1 ... 0
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = zero16();
+                if (st == depth + 1) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        if (act[t]) acc[t] = mfma(cur[0], ld_frag(bc, t * KSG, lane), acc[t]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KSG; s++) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            if (act[t]) acc[t] = mfma(cur[s], ld_frag(bc, t * KSG + s, lane), acc[t]);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (!act[t]) continue;
+                    const uint32_t mk = masks[(size_t)(l * NT + t) * 64];
+                    half_t* const tdl = td[t] + (size_t)((uint32_t)l * WIDTH) * 8;
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        uint4v wv;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t bits = mk >> (4 * hf + i);
+                            const short2v keep = -__builtin_bit_cast(short2v, bits & 0x00010001u);      // 0xffff where the ReLU passed
+                            const float2v dv = {acc[t][8 * hf + 2 * i], acc[t][8 * hf + 2 * i + 1]};
+                            const half2v dh = __builtin_convertvector(dv, half2v);
+                            wv[i] = __builtin_bit_cast(uint32_t, dh) & __builtin_bit_cast(uint32_t, keep);
+                        }
+                        const half8 bd = __builtin_bit_cast(half8, wv);
+                        bn[(t * KSG + 2 * w + hf) * 64 + lane] = __builtin_bit_cast(uint4, wv);
+                        if (!a.diag_no_store) store_kgroups<true>(kg, bd, lane, tdl + (size_t)(16 * (2 * w + hf)) * 8, rows_d);
+                    }
+                }
+            } else {
+                // ---- dL/d(encoded input rows 0..31) = W0^T delta_0 for a trainable encoding: one row block, wave 0
+                if (w == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        if (!act[t]) continue;
+                        f32x16 de = zero16();
+#pragma unroll
+                        for (int s = 0; s < KSG; s++) de = mfma(cur[s], ld_frag(bc, t * KSG + s, lane), de);
+                        half_t* const po = a.d_enc + (size_t)sidx[t] * 32u + 4 * h;
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) po[(reg & 3) + 8 * (reg >> 2)] = (half_t)de[reg];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ training: weight gradients
 // dW_l = delta_l (rows: out neurons, k: samples) * a_{l-1}^T.  One workgroup per K-chunk of samples, one 32x32
 // output tile per wave iteration, partial result to this chunk's slab (fixed-order reduction afterwards).
@@ -1733,6 +1959,110 @@ __global__ __launch_bounds__(WGRAD_WAVES * 64) void k_wgrad(const half_t* __rest
         for (int reg = 0; reg < 16; reg++) {
             const uint32_t row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (row < T.m_valid && bv) slab[T.param_off + row * T.in_dim + r] = acc[reg];
+        }
+    }
+}
+
+// ---- round 4: one workgroup per (K-chunk, four row-block tasks) instead of one per K-chunk with every tile of the network.
+// k_wgrad above is latency-bound: its 896 waves walk ~19 output tiles each, every tile two dependent rounds of global loads in
+// front of 8 MFMAs, every operand block fetched once per tile that uses it (61 us stand-alone for an 8x128 net, 183 us beside
+// gen_rays -- the longest kernel of configs[4]'s training stream).  Here a wave owns ONE 32-row block of a layer's delta (the A
+// operand) and up to four 32-column blocks of the layer's input (B): every k-step is one A load + NTL B loads for NTL MFMAs into
+// NTL live accumulators, the loads of the next two k-steps in flight behind the current two.  The K range of a workgroup (`chunk`
+// samples) is chosen by the host so that the launch is ~2 workgroups per CU; the partial sums go to the chunk's slab and are added
+// in the fixed order of k_reduce_grads as before (bitwise reproducible; for a 6x64 net the chunk is the old 128 samples and the
+// gradient is bit-identical to k_wgrad's).
+struct WgradTask {
+    uint32_t a_row0, b_row0, m_valid, n_tiles, n_valid_last, param_off, in_dim, pad;
+};
+#ifndef NRC_WGRAD2_NTL
+#define NRC_WGRAD2_NTL 4            // 32-column blocks (accumulators) per task, at most 4
+#endif
+#ifndef NRC_WGRAD2_U
+#define NRC_WGRAD2_U 2              // k-steps per pipeline stage
+#endif
+constexpr int WGRAD2_WAVES = 4;
+constexpr int WGRAD2_NTL = NRC_WGRAD2_NTL;
+constexpr int WGRAD2_U = NRC_WGRAD2_U;
+template <int NTL>
+__device__ __forceinline__ void wgrad_task(const WgradTask& T, const half_t* __restrict__ deltas, const half_t* __restrict__ acts, uint32_t k0,
+                                           int ksteps, uint32_t rows_d, uint32_t rows_a, float* __restrict__ slab, int lane)
+{
+    constexpr int U = WGRAD2_U;
+    const int r = lane & 31, h = lane >> 5;
+    const bool av = (uint32_t)r < T.m_valid;
+    // operand k-groups: [sample/8][rows][8]; lane (r,h) reads row r of group 2s+h -> 512 contiguous bytes per half wave
+    const half_t* ap = deltas + ((size_t)((k0 >> 3) + h) * rows_d + T.a_row0 + (av ? r : 0)) * 8;
+    const half_t* bp[NTL];
+    bool bv[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; t++) {
+        bv[t] = (uint32_t)r < (t == NTL - 1 ? T.n_valid_last : 32u);
+        bp[t] = acts + ((size_t)((k0 >> 3) + h) * rows_a + T.b_row0 + 32u * (uint32_t)t + (bv[t] ? r : 0)) * 8;
+    }
+    const size_t a_step = (size_t)16 * rows_d, b_step = (size_t)16 * rows_a;
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; t++) acc[t] = zero16();
+    half8 a0[U], b0[U][NTL], a1[U], b1[U][NTL];
+    // rows / columns beyond the tile's valid ones read row 0 of the block and are never stored; k-steps beyond the chunk's end load the
+    // last valid step again (in bounds) and are not multiplied
+#define NRC_WG_LOAD(A, B, S0)                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; u++) {                                                               \
+        const int sc = (S0) + u < ksteps ? (S0) + u : ksteps - 1;                                                  \
+        A[u] = *reinterpret_cast<const half8*>(ap + (size_t)sc * a_step);                                          \
+        _Pragma("unroll") for (int t = 0; t < NTL; t++) B[u][t] = *reinterpret_cast<const half8*>(bp[t] + (size_t)sc * b_step); \
+    }
+#define NRC_WG_MMA(A, B, S0)                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < U; u++) {                                                               \
+        if ((S0) + u < ksteps) {                                                                                   \
+            _Pragma("unroll") for (int t = 0; t < NTL; t++) acc[t] = mfma(A[u], B[u][t], acc[t]);                  \
+        }                                                                                                          \
+    }
+    NRC_WG_LOAD(a0, b0, 0)
+    for (int s = 0; s < ksteps; s += 2 * U) {
+        NRC_WG_LOAD(a1, b1, s + U)
+        NRC_WG_MMA(a0, b0, s)
+        NRC_WG_LOAD(a0, b0, s + 2 * U)
+        NRC_WG_MMA(a1, b1, s + U)
+    }
+#undef NRC_WG_LOAD
+#undef NRC_WG_MMA
+#pragma unroll
+    for (int t = 0; t < NTL; t++) {
+        float* o = slab + T.param_off + 32u * (uint32_t)t + (uint32_t)r;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const uint32_t row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < T.m_valid && bv[t]) o[(size_t)row * T.in_dim] = acc[t][reg];
+        }
+    }
+}
+__global__ __launch_bounds__(WGRAD2_WAVES * 64) void k_wgrad2(const half_t* __restrict__ deltas, const half_t* __restrict__ acts, uint32_t n,
+                                                             uint32_t chunk, uint32_t rows_d, uint32_t rows_a,
+                                                             const WgradTask* __restrict__ tasks, int n_tasks, float* __restrict__ slabs,
+                                                             uint32_t n_params)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = __builtin_amdgcn_readfirstlane((int)blockIdx.y * WGRAD2_WAVES + wave);
+    if (task >= n_tasks) return;
+    const WgradTask T = tasks[task];
+    const uint32_t k0 = blockIdx.x * chunk;
+    const uint32_t left = n - k0;
+    const int ksteps = (int)((left < chunk ? left : chunk) >> 4);
+    float* slab = slabs + (size_t)blockIdx.x * n_params;
+    if constexpr (WGRAD2_NTL == 1) {
+        wgrad_task<1>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane);
+    } else if constexpr (WGRAD2_NTL == 2) {
+        if (T.n_tiles == 1) wgrad_task<1>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane);
+        else wgrad_task<2>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane);
+    } else {
+        switch (T.n_tiles) {
+        case 1: wgrad_task<1>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane); break;
+        case 2: wgrad_task<2>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane); break;
+        case 3: wgrad_task<3>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane); break;
+        default: wgrad_task<4>(T, deltas, acts, k0, ksteps, rows_d, rows_a, slab, lane); break;
         }
     }
 }
@@ -2104,7 +2434,7 @@ Mlp::~Mlp()
     if (d_src_inf_ != d_src_fwd_ && d_src_inf_) dev_free(d_src_inf_);
     if (d_dst_) dev_free(d_dst_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
-                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_feat_[0], d_feat_[1], d_t16_train_,
+                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_tasks_, d_feat_[0], d_feat_[1], d_t16_train_,
                     d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_};
     for (void* p : ptrs)
         if (p) dev_free(p);
@@ -2391,6 +2721,47 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
 }
 #endif
 
+// the row-block tasks of k_wgrad2: one per (layer, 32-row block of its delta, group of up to four 32-column blocks of its input)
+void Mlp::build_wgrad_tasks()
+{
+    if (d_tasks_) return;
+    wgrad_old_ = getenv("NRC_WGRAD_OLD") != nullptr;
+    std::vector<WgradTask> tasks;
+    const uint32_t D = depth_;
+    for (uint32_t l = 0; l <= D; l++) {
+        const MlpLayer& L = layers_[l];
+        const uint32_t a_rows = l == D ? D * kw_ : l * kw_;                       // delta_l rows (kernel width: 32 for width 16)
+        const uint32_t b_rows = l == 0 ? 0 : enc_dims_ + (l - 1) * kw_;           // a_{l-1} rows (enc for l = 0)
+        for (uint32_t mt = 0; mt * 32 < L.out; mt++)
+            for (uint32_t n0 = 0; n0 * 32 < L.in; n0 += WGRAD2_NTL) {
+                WgradTask T;
+                const uint32_t tiles_left = (L.in - 32 * n0 + 31) / 32;
+                T.n_tiles = tiles_left < (uint32_t)WGRAD2_NTL ? tiles_left : (uint32_t)WGRAD2_NTL;
+                T.a_row0 = a_rows + 32 * mt;
+                T.b_row0 = b_rows + 32 * n0;
+                T.m_valid = L.out - 32 * mt < 32 ? L.out - 32 * mt : 32;
+                const uint32_t last0 = 32 * (n0 + T.n_tiles - 1);
+                T.n_valid_last = L.in - last0 < 32 ? L.in - last0 : 32;
+                T.param_off = L.off + 32 * mt * L.in + 32 * n0;
+                T.in_dim = L.in;
+                T.pad = 0;
+                tasks.push_back(T);
+            }
+    }
+    n_wgrad_tasks_ = (int)tasks.size();
+    dev_alloc(&d_tasks_, tasks.size() * sizeof(WgradTask), "d_tasks_");
+    NRC_HIP(hipMemcpy(d_tasks_, tasks.data(), tasks.size() * sizeof(WgradTask), hipMemcpyHostToDevice));
+}
+// samples per K-chunk of the weight-gradient launch: ~2 workgroups per CU, a multiple of 32 samples, at least 64
+uint32_t Mlp::wgrad_chunk(uint32_t n)
+{
+    if (wgrad_old_) return WGRAD_CHUNK;
+    const uint32_t wg_per_chunk = ceil_div((uint32_t)n_wgrad_tasks_, (uint32_t)WGRAD2_WAVES);
+    uint32_t chunks = std::max(1u, 2u * (uint32_t)num_cus() / std::max(1u, wg_per_chunk));
+    uint32_t c = ceil_div(ceil_div(n, chunks), 32u) * 32u;
+    return std::max(c, 64u);
+}
+
 void Mlp::ensure_train_workspace(uint32_t n)
 {
     if (n <= ws_n_) return;
@@ -2404,7 +2775,11 @@ void Mlp::ensure_train_workspace(uint32_t n)
     dev_alloc(&d_acts_, rows_a * n * 2, "d_acts_");
     dev_alloc(&d_deltas_, rows_d * n * 2, "d_deltas_");
     NRC_HIP(hipMemset(d_deltas_, 0, rows_d * n * 2));
-    dev_alloc(&d_slabs_, (size_t)ceil_div(n, WGRAD_CHUNK) * n_mlp_ * 4, "d_slabs_");
+    build_wgrad_tasks();
+    // (k_wgrad2: a smaller batch has a smaller chunk, never more chunks than the launch's target count)
+    const uint32_t max_chunks = wgrad_old_ ? ceil_div(n, WGRAD_CHUNK)
+                                           : std::max(ceil_div(n, wgrad_chunk(n)), std::max(1u, 2u * (uint32_t)num_cus() / std::max(1u, ceil_div((uint32_t)n_wgrad_tasks_, (uint32_t)WGRAD2_WAVES))));
+    dev_alloc(&d_slabs_, (size_t)max_chunks * n_mlp_ * 4, "d_slabs_");
     if (hash_) {
         if (d_denc_) dev_free(d_denc_);
         d_denc_ = nullptr;
@@ -2437,6 +2812,14 @@ void Mlp::ensure_train_workspace(uint32_t n)
     }
 }
 
+// DIAGNOSTIC (wrong results, timing only): NRC_DIAG_SKIP=<mask> leaves launches of the training step out -- 1 encode + forward/backward
+// chain, 2 weight-gradient GEMMs, 4 slab reduction, 8 optimizer -- to measure what each costs the FRAME (tools/ab_skip.sh)
+static int diag_skip()
+{
+    static const int m = getenv("NRC_DIAG_SKIP") ? atoi(getenv("NRC_DIAG_SKIP")) : 0;
+    return m;
+}
+
 void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad)
 {
     if (n == 0 || n % 32 != 0) fail("training batch must be a non-zero multiple of 32 samples");
@@ -2444,7 +2827,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
     const uint32_t n_tiles = n / 32;
     constexpr int THREADS = 256;
     uint32_t blocks = ceil_div(n_tiles, THREADS / 64);
-    if (fused_) {
+    if (diag_skip() & 1) {
+    } else if (fused_) {
         TrainArgs a;
         a.in = d_in;
         a.target = d_target;
@@ -2482,6 +2866,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.depth = (int)depth_;
         a.ks0 = (int)enc_dims_ / 16;
         a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
+        a.diag_no_store = (diag_skip() & 16) ? 1 : 0;
         // a training batch is a few hundred 32-sample tiles (16 384 rays = 512): four-wave workgroups (128 of them) stream each
         // layer once per four tiles; large batches use eight waves, two workgroups per CU
         const bool small = n_tiles <= (uint32_t)num_cus() * 8u;
@@ -2504,7 +2889,41 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             attr_train_set_ = true;
         }
         const uint4 *fw = (const uint4*)d_pk_fwd_, *bw = (const uint4*)d_pk_bwd_;
-        if (kw_ == 32) {
+        // round 4: rows split over the waves (k_train_gen2); NRC_TRAIN_GEN_OLD=1 keeps k_train_gen, NRC_TRAIN_GEN_NT=1|2 sets the tiles
+        // per sample group
+        // (the environment is read per call: a test compares the kernels inside one process)
+        const bool gen_old = getenv("NRC_TRAIN_GEN_OLD") != nullptr;
+        const int gen_nt_env = getenv("NRC_TRAIN_GEN_NT") ? atoi(getenv("NRC_TRAIN_GEN_NT")) : 0;
+        if (!gen_old) {
+            const uint32_t sgn = 4u / (uint32_t)mtg;                 // sample groups per workgroup
+            // (a 16 384-ray batch of an 8x128 net, stand-alone: 29.5 us with one tile per sample group, 39.8 with two; two halve the weight
+            // traffic from L2 -- 33 KB per stage and sample group -- and take over where one tile would put more than four workgroups on a CU)
+            const int nt = gen_nt_env == 1 || gen_nt_env == 2 ? gen_nt_env : (n_tiles > 4u * sgn * (uint32_t)num_cus() ? 2 : 1);
+            uint32_t groups = ceil_div(n_tiles, sgn * (uint32_t)nt);
+            if (groups > cap) groups = cap;
+            const size_t lds2 = (size_t)2 * sgn * nt * ksg * 1024 + 4 * KG_SCRATCH + (size_t)4 * depth_ * nt * 256;
+            if (lds2 > 160 * 1024) fail("network too deep for the training kernel's LDS budget");
+            if (!attr_train2_set_) {
+                const int cap_lds = 160 * 1024;
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen2<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen2<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen2<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen2<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen2<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+                NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_gen2<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_lds));
+                attr_train2_set_ = true;
+            }
+            if (kw_ == 32) {
+                if (nt == 1) hipLaunchKernelGGL((k_train_gen2<32, 1>), dim3(groups), dim3(256), lds2, s, a, fw, bw);
+                else hipLaunchKernelGGL((k_train_gen2<32, 2>), dim3(groups), dim3(256), lds2, s, a, fw, bw);
+            } else if (kw_ == 64) {
+                if (nt == 1) hipLaunchKernelGGL((k_train_gen2<64, 1>), dim3(groups), dim3(256), lds2, s, a, fw, bw);
+                else hipLaunchKernelGGL((k_train_gen2<64, 2>), dim3(groups), dim3(256), lds2, s, a, fw, bw);
+            } else {
+                if (nt == 1) hipLaunchKernelGGL((k_train_gen2<128, 1>), dim3(groups), dim3(256), lds2, s, a, fw, bw);
+                else hipLaunchKernelGGL((k_train_gen2<128, 2>), dim3(groups), dim3(256), lds2, s, a, fw, bw);
+            }
+        } else if (kw_ == 32) {
             if (small) hipLaunchKernelGGL((k_train_gen<32, 4>), dim3(blocks), dim3(256), lds, s, a, fw, bw);
             else hipLaunchKernelGGL((k_train_gen<32, 8>), dim3(blocks), dim3(512), lds, s, a, fw, bw);
         } else if (kw_ == 64) {
@@ -2528,13 +2947,21 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         }
     }
     NRC_HIP(hipGetLastError());
-    const uint32_t n_chunks = ceil_div(n, WGRAD_CHUNK);
-    hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_, (const half_t*)d_acts_, n,
-                       depth_ * kw_ + 8, enc_dims_ + depth_ * kw_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
-                       n_mlp_);
+    const uint32_t chunk = wgrad_chunk(n);
+    const uint32_t n_chunks = ceil_div(n, chunk);
+    if (diag_skip() & 2) {
+    } else if (wgrad_old_)
+        hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_, (const half_t*)d_acts_, n,
+                           depth_ * kw_ + 8, enc_dims_ + depth_ * kw_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
+                           n_mlp_);
+    else
+        hipLaunchKernelGGL(k_wgrad2, dim3(n_chunks, ceil_div((uint32_t)n_wgrad_tasks_, (uint32_t)WGRAD2_WAVES)), dim3(WGRAD2_WAVES * 64), 0, s,
+                           (const half_t*)d_deltas_, (const half_t*)d_acts_, n, chunk, depth_ * kw_ + 8, enc_dims_ + depth_ * kw_,
+                           (const WgradTask*)d_tasks_, n_wgrad_tasks_, d_slabs_, n_mlp_);
     NRC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_mlp_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_mlp_,
-                       d_grad_, d_loss_part_, n_tiles, d_loss_);
+    if (!(diag_skip() & 4))
+        hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_mlp_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_mlp_,
+                           d_grad_, d_loss_part_, n_tiles, d_loss_);
     NRC_HIP(hipGetLastError());
 }
 
@@ -2570,6 +2997,7 @@ void Mlp::grid_grad_apply(const uint32_t* d_lists, uint32_t n_lists, uint32_t ca
 bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* loss_cell)
 {
     step += 1;
+    if (diag_skip() & 8) return false;
     const double b1 = 0.9, b2 = 0.999;
     const double t = (double)step;
     const double d = (double)cfg_.ema_decay;

@@ -72,7 +72,7 @@ public:
 private:
     int num_cus();
     int num_cus_ = 0;
-    bool attr_infer_set_ = false, attr_infer4_set_ = false, attr_train_set_ = false;     // hipFuncSetAttribute done on this instance's device
+    bool attr_infer_set_ = false, attr_infer4_set_ = false, attr_train_set_ = false, attr_train2_set_ = false;     // hipFuncSetAttribute done on this instance's device
     void ensure_train_workspace(uint32_t n);
     void ensure_features(uint32_t n, int slot);
     void launch_features(const float* d_in, uint32_t n, bool use_ema, int slot, hipStream_t s, bool skip_zero, const uint32_t* live_list = nullptr,
@@ -119,6 +119,11 @@ private:
     float* d_loss_part_ = nullptr;
     void* d_tiles_ = nullptr;    // WgradTile[] (output tiles of the weight-gradient GEMMs)
     int n_wgrad_tiles_ = 0;
+    void* d_tasks_ = nullptr;    // WgradTask[] (row-block tasks of k_wgrad2)
+    int n_wgrad_tasks_ = 0;
+    bool wgrad_old_ = false;     // NRC_WGRAD_OLD: round 3's k_wgrad (A/B)
+    void build_wgrad_tasks();
+    uint32_t wgrad_chunk(uint32_t n);
 };
 
 }  // namespace nrc

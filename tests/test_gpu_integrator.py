@@ -467,6 +467,42 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
         assert np.array_equal(base[4].view(np.uint32), other[4].view(np.uint32))
 
 
+@pytest.mark.parametrize("model", [(2, 2, 64, 3), (3, 0, 128, 2), (3, 0, 64, 6)], ids=["generic-64", "generic-128", "fused"])
+def test_deferred_compositing_inside_render_frames_changes_no_pixel(api, sc, cloud16, torch_gpu, model, monkeypatch):
+    """nrc_renderer_render_frames composites every frame but its last on the train-ray stream, one frame late (round 4: stream C --
+    inference, then compositing -- bounds the frame of a heavy model; NRC_COMPOSITE_DEFER=0/1): pure scheduling -- after 3 calls of 4
+    trained, blended frames the framebuffer, the loss, the parameters and the frame timeline's shape equal the undeferred order and the
+    frame-by-frame Render loop bit for bit"""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    frs = sc.frame_randoms(12, seed=27)
+    results = []
+    for mode in ("0", "1", "1", "1", "loop"):
+        monkeypatch.setenv("NRC_COMPOSITE_DEFER", "1" if mode == "loop" else mode)
+        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
+                                        log2_train_batch_size=10)
+        ren.SetBlend(True)
+        if mode == "loop":
+            for f in range(12):
+                ren.SetFrameRandom(frs[f])
+                ren.Render(None, True)
+        else:
+            for k in range(3):
+                ren.RenderFrames(frs[4 * k:4 * k + 4], True)      # no host synchronisation between the calls
+        img = ren.GetImage().cpu().numpy().copy()
+        tl = ren.FrameTimeline()
+        assert tl.shape == (12, 6) and np.isfinite(tl).all() and (tl[:, 4] >= tl[:, 3]).all()      # every frame's compositing was timed
+        results.append((img, nrc.GetLoss(), nrc.GetParams(0).copy()))
+        ren.Destroy()
+        nrc.Destroy()
+    base = results[0]
+    assert np.abs(base[0]).max() > 0.0
+    for other in results[1:]:
+        assert np.array_equal(base[0].view(np.uint32), other[0].view(np.uint32))
+        assert base[1] == other[1]
+        assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
+
+
 def test_framebuffer_on_a_consumer_stream(api, sc, cloud16, torch_gpu):
     """GetImage(stream): a read-back stream of the caller is ordered behind each frame's compositing while the render stream runs
     ahead; the copies it makes equal the frames of a renderer that is read synchronously"""

@@ -439,6 +439,75 @@ def test_generic_models_match_oracle(api, orc, torch_gpu, pos_id, dir_id, width,
     c.Destroy()
 
 
+@pytest.mark.parametrize("pos_id,dir_id,width,depth", [(3, 0, 128, 8), (1, 1, 128, 3), (3, 0, 64, 5), (2, 2, 64, 1), (3, 0, 32, 4), (0, 0, 64, 2),
+                                                       (0, 0, 128, 2), (3, 0, 16, 3)])
+def test_training_kernels_agree(api, torch_gpu, monkeypatch, pos_id, dir_id, width, depth):
+    """k_train_gen2 (round 4: every layer's rows split over the waves of a workgroup, operands exchanged through LDS, weight fragments
+    read straight from L2) against k_train_gen (NRC_TRAIN_GEN_OLD=1): each output element is the same sequence of MFMAs, so loss and
+    gradient agree bit for bit -- one and two tiles per sample group, full and ragged batches (the last workgroup half empty)"""
+    hg = 11 if pos_id == 0 else 0
+    rng = np.random.default_rng(13)
+    for n in (16384, 2048 + 96, 32):
+        xq = queries(n, seed=5, nan_frac=0.0)
+        if pos_id in (0, 1):
+            xq[:, :3] -= 31.0
+        x = torch_gpu.from_numpy(xq).cuda()
+        t = torch_gpu.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
+        got = {}
+        for mode in ("old", "1", "2"):
+            monkeypatch.delenv("NRC_TRAIN_GEN_OLD", raising=False)
+            monkeypatch.delenv("NRC_TRAIN_GEN_NT", raising=False)
+            if mode == "old":
+                monkeypatch.setenv("NRC_TRAIN_GEN_OLD", "1")
+            else:
+                monkeypatch.setenv("NRC_TRAIN_GEN_NT", mode)
+            c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth, hashgrid_log2_size=hg))
+            c.Backward(x, t)
+            got[mode] = (c.GetParams(4).copy(), c.GetLoss())
+            c.Destroy()
+        g_old, l_old = got["old"]
+        assert np.isfinite(g_old).all() and np.abs(g_old).max() > 0.0
+        for mode in ("1", "2"):
+            g, l = got[mode]
+            assert l == l_old, (n, mode)
+            if pos_id == 0:      # the table gradient is summed with fp16 atomics in no fixed order: the MLP part is exact
+                nm = c_mlp_params(width, depth, 48)
+                assert np.array_equal(g[:nm], g_old[:nm]), (n, mode)
+                assert rel(g, g_old) < 2e-2
+            else:
+                assert np.array_equal(g, g_old), (n, mode)
+
+
+def c_mlp_params(width, depth, enc):
+    return enc * width + (depth - 1) * width * width + width * 3
+
+
+@pytest.mark.parametrize("width,depth,exact", [(64, 6, True), (128, 8, False), (32, 3, False)], ids=["6x64", "8x128", "3x32"])
+def test_weight_gradient_kernels_agree_at_full_batch(api, torch_gpu, monkeypatch, width, depth, exact):
+    """k_wgrad2 (round 4: one wave per 32-row block of a layer's delta, up to four accumulators, K-chunks sized for the launch)
+    against round 3's k_wgrad (NRC_WGRAD_OLD=1, 128-sample chunks) on a full 16 384-ray batch and on a ragged one: the same products
+    summed over other chunk boundaries -- fp32 rounding apart; for the 6x64 model the chunks are the same and so is every bit"""
+    rng = np.random.default_rng(11)
+    grads = {}
+    for n in (16384, 4096 + 96):
+        x = torch_gpu.from_numpy(queries(n, seed=3, nan_frac=0.0)).cuda()
+        t = torch_gpu.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("NRC_WGRAD_OLD", "1")
+            else:
+                monkeypatch.delenv("NRC_WGRAD_OLD", raising=False)
+            c = api.NeuralRadianceCache(api.AppConfig(nn_width=width, nn_depth=depth))
+            c.Backward(x, t)
+            grads[old] = c.GetParams(4).copy()
+            c.Destroy()
+        assert np.isfinite(grads[False]).all() and np.abs(grads[False]).max() > 0.0
+        if exact and n == 16384:
+            assert np.array_equal(grads[False], grads[True])
+        else:
+            assert rel(grads[False], grads[True]) < 2e-6
+
+
 def test_random_model_configurations_match_oracle(api, orc, torch_gpu):
     """a seeded sweep over the configuration space the command line spans -- encodings x width {32, 64, 128} x depth 1..9 x
     loss x optimizer: inference, loss, gradients and the first optimizer step against the oracle"""

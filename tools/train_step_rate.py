@@ -1,5 +1,5 @@
-"""Stand-alone rate of the training chain (backward -> optimizer step) on an idle GPU: python3 tools/train_step_rate.py [batch] [steps]
-(NRC_NO_FUSED_OPT=1 for the three-launch optimizer)."""
+"""Stand-alone rate of the training chain (backward -> optimizer step) on an idle GPU:
+python3 tools/train_step_rate.py [batch] [steps] [nn_width] [nn_depth] [pos_id]      (NRC_NO_FUSED_OPT=1 for the three-launch optimizer)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +8,10 @@ from nrc_hpm_renderer_amd import api
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-c = api.NeuralRadianceCache(api.AppConfig())
+width = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+depth = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+pos_id = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+c = api.NeuralRadianceCache(api.AppConfig(nn_width=width, nn_depth=depth, pos_id=pos_id))
 rng = np.random.default_rng(5)
 x = torch.from_numpy(rng.random((n, 5), dtype=np.float32)).cuda()
 t = torch.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
@@ -20,4 +23,5 @@ for _ in range(steps):
     c.Backward(x, t); c.OptimizerStep()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("batch %d: %.1f us per training step (fused optimizer: %s), loss %.5f" % (n, dt * 1e6, os.environ.get("NRC_NO_FUSED_OPT") is None, c.GetLoss()))
+print("batch %d, %dx%d pos_id %d: %.1f us per training step (fused optimizer: %s), loss %.5f"
+      % (n, depth, width, pos_id, dt * 1e6, os.environ.get("NRC_NO_FUSED_OPT") is None, c.GetLoss()))
