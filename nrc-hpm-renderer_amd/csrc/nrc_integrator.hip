@@ -2139,9 +2139,13 @@ __global__ void k_ring_push(DevFrame fr, TrainGrid tg, const float4* __restrict_
 // ------------------------------------------------------------------------------------------------ nrc/render.comp
 __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nrc, float blend_factor,
                                                   const float4* __restrict__ primary, const float* __restrict__ info,
-                                                  const float* __restrict__ infer_out, float4* __restrict__ out_rgba)
+                                                  const float* __restrict__ infer_out, float4* __restrict__ out_rgba,
+                                                  uint32_t* __restrict__ live_count_reset)
 {
     NRC_RAISE_WAVE_PRIORITY(2);
+    // the frame's live-query list (DevFrame::live_list) has had its last reader -- this launch is ordered behind the frame's inference --
+    // and the set's next gen_rays waits for this launch: the count is reset here instead of by a memset on the render stream
+    if (live_count_reset != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *live_count_reset = 0u;
     uint32_t lx, y;
     if (!pixel_of_thread(fr, &lx, &y)) return;
     const size_t pix = (size_t)y * fr.w + lx, lin = query_index(fr.w, lx, y);
@@ -2435,10 +2439,10 @@ void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& 
 }
 
 void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary, const float* info,
-                      const float* infer_out, float* out_rgba, hipStream_t s)
+                      const float* infer_out, float* out_rgba, hipStream_t s, uint32_t* live_count_reset)
 {
     hipLaunchKernelGGL(k_composite, pixel_grid(fr.w, fr.h), dim3(256), 0, s, fr, show_nrc, blend_factor,
-                       (const float4*)primary, info, infer_out, (float4*)out_rgba);
+                       (const float4*)primary, info, infer_out, (float4*)out_rgba, live_count_reset);
     NRC_HIP(hipGetLastError());
 }
 

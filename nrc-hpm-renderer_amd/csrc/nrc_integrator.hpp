@@ -133,7 +133,7 @@ void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& 
                        float* train_target, hipStream_t s);
 
 void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary,
-                      const float* info, const float* infer_out, float* out_rgba, hipStream_t s);
+                      const float* info, const float* infer_out, float* out_rgba, hipStream_t s, uint32_t* live_count_reset = nullptr);
 
 // Reference::Result; d_scratch: double[8 + 2048]
 void launch_compare(const float* ref_rgba, const float* own_rgba, uint32_t n_pixels, double* d_scratch, float* d_result5,

@@ -408,10 +408,12 @@ __device__ __forceinline__ void composite_query(const CompositeArgs& ca, uint32_
                       ca.blend_factor * cb + ib * prev.z, ca.blend_factor * 1.0f + ib * prev.w);
 }
 
-template <int DEPTH, int THREADS, int NT, int ABL = 0, bool FUSE = false>
+template <int DEPTH, int THREADS, int NT, int ABL = 0, bool FUSE = false, bool LISTED = false>
 __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
-                                                  int skip_zero = 0, CompositeArgs ca = CompositeArgs{})
+                                                  int skip_zero = 0, CompositeArgs ca = CompositeArgs{},
+                                                  const uint32_t* __restrict__ live_list = nullptr,
+                                                  const uint32_t* __restrict__ live_count = nullptr)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -426,14 +428,30 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const uint32_t n_tiles = (n + 31u) >> 5;
+    // live_list (renderer inference, round 4): the tiles are 32 entries of the frame's live-query list (DevFrame::live_list: the query index
+    // of every pixel that scattered, appended by k_gen_rays) instead of 32 consecutive queries -- nothing is read, computed or stored for a
+    // pixel that did not scatter (the list-free renderer mode reads all 2 M queries of a 1080p frame and stores zeros for the dead
+    // tiles: 66 MB), and the tiles that run are full (87 % on the bench cloud otherwise, tools/live_tiles.py).  Results are per query.
+    // (LISTED is a template parameter: the list-free instantiations are the code they were)
+    constexpr bool listed = LISTED && !FUSE;
+    uint32_t n_q = n;
+    if constexpr (listed) {
+        n_q = __builtin_amdgcn_readfirstlane((int)*live_count);
+        n_q = n_q < n ? n_q : n;
+    }
+    auto query_of = [&](uint32_t sx) -> uint32_t {      // (slots beyond the end repeat the last query: in bounds, never stored)
+        if constexpr (listed) return live_list[sx < n_q ? sx : (n_q != 0u ? n_q - 1u : 0u)];
+        else return sx < n ? sx : n - 1u;
+    };
+    const uint32_t n_tiles = (n_q + 31u) >> 5;
     const uint32_t stride = gridDim.x * (THREADS / 64) * NT;
     uint32_t tile = (blockIdx.x * (THREADS / 64) + wave) * NT;
     float x[NT][5];
+    uint32_t qi[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        const uint32_t sidx = (tile + t) * 32u + r;
-        const float* p = in + (size_t)(sidx < n ? sidx : n - 1u) * 5u;
+        qi[t] = query_of((tile + t) * 32u + r);
+        const float* p = in + (size_t)qi[t] * 5u;
 #pragma unroll
         for (int i = 0; i < 5; i++) x[t][i] = __builtin_nontemporal_load(p + i);
     }
@@ -445,10 +463,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
         // the tile loop -- fragments are meant to be re-read from LDS, one ds_read_b128 per NT MFMAs
         asm volatile("" ::: "memory");
         float xn[NT][5];
+        uint32_t qn[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            const uint32_t sidx = (tile + stride + t) * 32u + r;
-            const float* p = in + (size_t)(sidx < n ? sidx : n - 1u) * 5u;
+            qn[t] = query_of((tile + stride + t) * 32u + r);
+            const float* p = in + (size_t)qn[t] * 5u;
 #pragma unroll
             for (int i = 0; i < 5; i++) xn[t][i] = __builtin_nontemporal_load(p + i);
         }
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
         // renderer mode: gen_rays writes an all-zero query for every pixel that did not scatter (the reference's zero-filled
         // slots, whose network output render.comp never reads); tiles made only of such queries skip the network and store 0
         bool live = true;
-        if (skip_zero) {
+        if (skip_zero && !listed) {
             bool nz = false;
 #pragma unroll
             for (int t = 0; t < NT; t++)
@@ -473,10 +492,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const uint32_t sidx = (tile + t) * 32u + r;
-            if (sidx < n && h == 0 && ((ABL & 8) == 0 || sidx < 64u)) {
+            if (sidx < n_q && h == 0 && ((ABL & 8) == 0 || sidx < 64u)) {
                 // streamed once: non-temporal, so the 12 B/sample leave the L2 while the kernel runs instead of in the
                 // end-of-kernel write-back
-                float* o = out + (size_t)sidx * 3u;
+                float* o = out + (size_t)(listed ? qi[t] : sidx) * 3u;
                 __builtin_nontemporal_store(y[t][0], o);
                 __builtin_nontemporal_store(y[t][1], o + 1);
                 __builtin_nontemporal_store(y[t][2], o + 2);
@@ -484,6 +503,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_
             }
 #pragma unroll
             for (int i = 0; i < 5; i++) x[t][i] = xn[t][i];
+            qi[t] = qn[t];
         }
     }
     if constexpr ((ABL & 4) != 0) {
@@ -1247,7 +1267,9 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 template <int WIDTH, int THREADS, bool FEAT_LM, int NT = 2, bool ENC80 = false>
 __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                       const uint4* __restrict__ img, int depth, int ks0,
-                                                      const float* __restrict__ skip_in, const float* __restrict__ raw_in = nullptr)
+                                                      const float* __restrict__ skip_in, const float* __restrict__ raw_in = nullptr,
+                                                      const uint32_t* __restrict__ live_list = nullptr,
+                                                      const uint32_t* __restrict__ live_count = nullptr)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = THREADS / 64;
@@ -1256,7 +1278,23 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
     extern __shared__ uint4 lds_w[];                              // [2][STAGE_FRAGS * 64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const uint32_t n_tiles = (n + 31u) >> 5;
+    // live_list (renderer inference, round 4): the frame's live queries as a dense list (k_gen_rays appends the query index of every pixel
+    // that scattered, DevFrame::live_list) -- the tiles are 32 LIST entries, so every tile that runs is full but the last one; without it
+    // a tile is 32 consecutive queries = four rows of eight pixels, computed whole when any of them is live (68 % of the computed
+    // queries are live on configs[4]'s smoke plume, 87 % on the default cloud: tools/live_tiles.py).  Results are per query: the
+    // (unordered) list changes no bit.
+    const bool listed = live_list != nullptr;
+    uint32_t n_q = n;
+    if (listed) {
+        n_q = __builtin_amdgcn_readfirstlane((int)*live_count);
+        n_q = n_q < n ? n_q : n;
+    }
+    const uint32_t n_tiles = (n_q + 31u) >> 5;
+    // the query lane r of tile slot sx works on (slots beyond the end repeat the last one: in bounds, never stored)
+    auto query_of = [&](uint32_t sx) -> uint32_t {
+        const uint32_t c = sx < n_q ? sx : n_q - 1u;
+        return listed ? live_list[c] : c;
+    };
     const uint32_t n_groups = (n_tiles + WAVES * NT - 1u) / (WAVES * NT);
     const uint32_t e16 = (uint32_t)ks0 * 16u;
     const int hid_base = MTG * ks0;
@@ -1294,8 +1332,7 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
     auto load_features = [&](uint32_t g) {
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            const uint32_t sx = ((g * WAVES + (uint32_t)wave) * NT + (uint32_t)t) * 32u + (uint32_t)r;
-            const size_t si = sx < n ? sx : n - 1u;
+            const size_t si = query_of(((g * WAVES + (uint32_t)wave) * NT + (uint32_t)t) * 32u + (uint32_t)r);
             if constexpr (ENC80) {
                 const float* qv = raw_in + si * 5u;
                 const float x[5] = {qv[0], qv[1], qv[2], qv[3], qv[4]};
@@ -1330,10 +1367,10 @@ __global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const uint32_t tile = (group * WAVES + (uint32_t)wave) * NT + (uint32_t)t;
-            sidx[t] = tile * 32u + (uint32_t)r;
-            valid[t] = sidx[t] < n;
+            valid[t] = tile * 32u + (uint32_t)r < n_q;
+            sidx[t] = n_q != 0u ? query_of(tile * 32u + (uint32_t)r) : 0u;
             bool used = valid[t];
-            if (skip_in != nullptr && valid[t]) {
+            if (!listed && skip_in != nullptr && valid[t]) {
                 const float* qv = skip_in + (size_t)sidx[t] * 5u;
                 used = qv[0] != 0.0f || qv[1] != 0.0f || qv[2] != 0.0f || qv[3] != 0.0f || qv[4] != 0.0f;
             }
@@ -2519,15 +2556,20 @@ int Mlp::num_cus()
 
 template <int THREADS, int NT>
 static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float* d_in, float* d_out, uint32_t n, const uint4* img,
-                         int skip_zero, const CompositeArgs* composite = nullptr)
+                         int skip_zero, const CompositeArgs* composite = nullptr, const uint32_t* live_list = nullptr,
+                         const uint32_t* live_count = nullptr)
 {
     if (composite != nullptr) {
         hipLaunchKernelGGL((k_infer<6, THREADS, NT, 0, true>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
                            (unsigned long long*)nullptr, skip_zero, *composite);
         return;
     }
-    hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
-                       (unsigned long long*)nullptr, skip_zero, CompositeArgs{});
+    if (live_list != nullptr)
+        hipLaunchKernelGGL((k_infer<6, THREADS, NT, 0, false, true>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
+                           (unsigned long long*)nullptr, skip_zero, CompositeArgs{}, live_list, live_count);
+    else
+        hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
+                           (unsigned long long*)nullptr, skip_zero, CompositeArgs{}, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 }
 
 // fp16 feature buffer of the generic path ([n][E16]); grows on demand (never inside a captured region: first use sizes it)
@@ -2555,12 +2597,14 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
         const bool enc80 = enc80_generic_ && use_ema;
         if (!enc80) launch_features(d_in, n, use_ema, 0, s, skip_zero_queries, live_list, live_count);
         const float* skip_in = skip_zero_queries ? d_in : nullptr;
+        const uint32_t* list = skip_zero_queries ? live_list : nullptr;      // renderer inference with the frame's live-query list (k_infer_gen)
         const half_t* feat = enc80 ? nullptr : (const half_t*)d_feat_[0];
         const int ks0 = (int)enc_dims_ / 16;
         uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
         auto launch = [&](auto kernel, uint32_t threads, size_t lds, uint32_t per_cu) {
             const uint32_t cap = (uint32_t)num_cus() * per_cu;
-            hipLaunchKernelGGL(kernel, dim3(blocks > cap ? cap : blocks), dim3(threads), lds, s, feat, d_out, n, img, (int)depth_, ks0, skip_in, d_in);
+            hipLaunchKernelGGL(kernel, dim3(blocks > cap ? cap : blocks), dim3(threads), lds, s, feat, d_out, n, img, (int)depth_, ks0, skip_in, d_in,
+                               list, list != nullptr ? live_count : nullptr);
         };
         if (kw_ == 32) {
             if (enc80) launch(k_infer_gen<32, 256, false, 2, true>, 256, 2 * 5 * 1024, 4);
@@ -2652,11 +2696,11 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
         constexpr int T = NRC_INFER_RENDER_THREADS;
         uint32_t b2 = ceil_div(n_tiles, (uint32_t)(T / 64) * 2u);
         const uint32_t cap = (uint32_t)num_cus() * 2u;
-        launch_infer<T, 2>(b2 > cap ? cap : b2, lds, s, d_in, d_out, n, img, sz);
+        launch_infer<T, 2>(b2 > cap ? cap : b2, lds, s, d_in, d_out, n, img, sz, nullptr, live_list, live_count);
         NRC_HIP(hipGetLastError());
         return;
     }
-    launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz, composite);
+    launch_infer<512, 2>(blocks, lds, s, d_in, d_out, n, img, sz, composite, skip_zero_queries && composite == nullptr ? live_list : nullptr, live_count);
     NRC_HIP(hipGetLastError());
 }
 

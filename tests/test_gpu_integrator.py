@@ -503,6 +503,46 @@ def test_deferred_compositing_inside_render_frames_changes_no_pixel(api, sc, clo
         assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
 
 
+@pytest.mark.parametrize("model", [(2, 0, 64, 3, 0), (3, 0, 128, 2, 0), (1, 0, 32, 2, 0), (0, 0, 64, 2, 11), (3, 0, 64, 6, 0), (2, 2, 64, 3, 0)],
+                         ids=["triwave-64", "enc80-128", "identity-32", "hashgrid-64", "fused", "triwave-dir-64"])
+def test_live_query_list_changes_no_pixel(api, sc, cloud16, torch_gpu, model, monkeypatch):
+    """renderer inference builds its 32-query tiles from the frame's live-query list (k_gen_rays appends the query index of every
+    pixel that scattered; k_infer, k_infer_gen, k_encode_hash_list) instead of computing every tile of four pixel rows that holds a
+    live query: results are per query, so framebuffer, loss and parameters after 6 trained frames equal the list-free path
+    (NRC_NO_LIVE_LIST=1) bit for bit, and so does the radiance of every scattered pixel of the last frame"""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    frs = sc.frame_randoms(6, seed=29)
+    results = []
+    for no_list in ("1", None, None):
+        if no_list:
+            monkeypatch.setenv("NRC_NO_LIVE_LIST", no_list)
+        else:
+            monkeypatch.delenv("NRC_NO_LIVE_LIST", raising=False)
+        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
+                                        hashgrid_log2_size=model[4], log2_infer_batch_size=21)      # ONE inference batch: the list is used
+        ren.SetBlend(True)
+        # (a HashGrid model's table gradient is summed with fp16 atomics in no fixed order -- its training is not bitwise repeatable: untrained)
+        ren.RenderFrames(frs, model[0] != 0)
+        img = ren.GetImage().cpu().numpy().copy()
+        info = ren.Buffer("info").cpu().numpy().reshape(-1).copy()
+        rad = ren.Buffer("infer_output").cpu().numpy().reshape(-1, 3).copy()
+        results.append((img, nrc.GetLoss(), nrc.GetParams(0).copy(), info, rad))
+        ren.Destroy()
+        nrc.Destroy()
+    base = results[0]
+    live = base[3].reshape(H, W).T.reshape(-1) == 1.0      # the radiance buffer is handed out in the reference's x * H + y order
+    assert live.sum() > 1000 and np.isfinite(base[4][live]).all()
+    if model[1] == 0:      # (only the OneBlob direction encoding absorbs the NaN angle of quirk Q5: the other models' training batches carry it into
+        assert np.abs(base[4][live]).max() > 0.0      # the weights, and their radiance is 0 with and without the list)
+    for other in results[1:]:
+        assert np.array_equal(base[0].view(np.uint32), other[0].view(np.uint32))
+        assert base[1] == other[1]
+        assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
+        assert np.array_equal(base[3], other[3])
+        assert np.array_equal(base[4][live].view(np.uint32), other[4][live].view(np.uint32))
+
+
 def test_framebuffer_on_a_consumer_stream(api, sc, cloud16, torch_gpu):
     """GetImage(stream): a read-back stream of the caller is ordered behind each frame's compositing while the render stream runs
     ahead; the copies it makes equal the frames of a renderer that is read synchronously"""

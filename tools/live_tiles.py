@@ -1,8 +1,13 @@
+"""How full are the inference tiles of a frame?  python3 tools/live_tiles.py [cloud|smoke] [volume size]
+The renderer's queries are tile-major (query_index: 8x8-pixel tiles, an inference tile = 32 queries = four rows of eight pixels); the
+renderer-mode inference kernels skip a tile whose 32 queries are all zero and compute every query of any other tile."""
 import sys, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nrc_hpm_renderer_amd import api, scene as sc
 W, H = 1920, 1080
-vol = sc.cached_volume("cloud", 256, seed=1337)
+kind = sys.argv[1] if len(sys.argv) > 1 else "cloud"
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+vol = sc.cached_volume(kind, size, seed=1337)
 scene = sc.make_scene(vol, scene_id=4, env=sc.procedural_sky(64, 32))
 cam = sc.make_camera(aspect=W / H)
 cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=14, log2_infer_batch_size=21)
@@ -11,9 +16,11 @@ ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
 ren.Render(None, True)
 info = ren.Buffer("info").cpu().numpy().reshape(H, W)      # [y][x]
 live = info > 0
-print("scattered pixels %d (%.1f %%)" % (live.sum(), 100 * live.mean()))
-col = live.T.reshape(-1)          # x*H + y order
-n = col.size // 32
-t = col[:n * 32].reshape(n, 32)
-lt = t.any(axis=1)
-print("32-query tiles: %d, live %d (%.1f %%), ideal %d, live/ideal %.2f, mean fill of live tiles %.1f %%" % (n, lt.sum(), 100 * lt.mean(), int(np.ceil(live.sum() / 32)), lt.sum() / np.ceil(live.sum() / 32), 100 * t[lt].mean()))
+print("%s %d^3: scattered pixels %d (%.1f %%)" % (kind, size, live.sum(), 100 * live.mean()))
+# tile-major: (ty, tx, half, 4 rows, 8 columns)
+t = live.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 2, 32)
+for name, tiles in (("32-query inference tiles", t.reshape(-1, 32)), ("64-pixel gen_rays tiles", t.reshape(-1, 64))):
+    lt = tiles.any(axis=1)
+    ideal = int(np.ceil(live.sum() / tiles.shape[1]))
+    print("%s: %d, live %d (%.1f %%), dense list would need %d, live / dense %.2f, mean fill of live tiles %.1f %%"
+          % (name, len(tiles), lt.sum(), 100 * lt.mean(), ideal, lt.sum() / ideal, 100 * tiles[lt].mean()))
