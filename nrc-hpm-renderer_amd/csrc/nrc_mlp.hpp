@@ -40,6 +40,8 @@ public:
                const CompositeArgs* composite = nullptr, const uint32_t* live_list = nullptr, const uint32_t* live_count = nullptr);
     // the fused 6x64 inference kernel can composite in its epilogue (nrc/render.comp); the generic kernels cannot
     bool can_composite() const { return fused_; }
+    // EMA inference encodes the raw queries inside the MLP kernel (no feature buffer sized by the launch)
+    bool encodes_in_kernel() const { return fused_ || enc80_generic_; }
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
     // widen_grid_grad (models with a trainable table): also write the table gradient into the fp32 gradient vector -- needed only
     // by readers of the vector (dense exchange, gradient hook, debug read-back); the optimizer reads the packed fp16 table itself

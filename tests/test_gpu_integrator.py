@@ -873,8 +873,12 @@ def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, tor
         nrc = api.NeuralRadianceCache(cfg)
         ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
         ren.RenderFrames(frs, True)
-        out[fused] = (ren.GetImage().cpu().numpy().copy(), ren.Buffer("infer_output").cpu().numpy().copy(),
+        # the radiance buffer is defined where render.comp reads it, at the pixels that scattered (the list-driven inference of the separate
+        # pass touches nothing else; x * H + y order)
+        live = ren.Buffer("info").cpu().numpy().reshape(H, W).T.reshape(-1) == 1.0
+        out[fused] = (ren.GetImage().cpu().numpy().copy(), ren.Buffer("infer_output").cpu().numpy()[live].copy(),
                       ren.Buffer("infer_input").cpu().numpy().copy(), nrc.GetLoss(), ren.StageStats()["render"])
+        assert live.sum() > 1000
         ren.Destroy()
         nrc.Destroy()
     for k in range(3):
