@@ -54,6 +54,9 @@ def main():
     put(first(src + "/prof_c5/**/*kernel_stats.csv"), "c5_kernel_stats.csv")
     put(first(src + "/prof_mlp/**/*kernel_stats.csv"), "mlp_kernel_stats.csv")
     put(first(src + "/prof_mlp128/**/*kernel_stats.csv"), "mlp128_kernel_stats.csv")
+    put(os.path.join(src, "train_6x64.txt"), "train_6x64_kernel_trace.txt")
+    put(os.path.join(src, "train_8x128.txt"), "train_8x128_kernel_trace.txt")
+    put(os.path.join(src, "frame_timeline.txt"), "frame_timeline.txt")
     put(os.path.join(src, "mlp_trace_tail.txt"), "mlp_kernel_trace_tail.txt")
     put(os.path.join(src, "mlp128_trace_tail.txt"), "mlp128_kernel_trace_tail.txt")
     put(first(src + "/pmc_fetch/**/*counter_collection.csv"), "pmc_fetch_size.csv")

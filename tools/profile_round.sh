@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU session's worth of measurements for profiles/rNN_* (run on the MI355X box from the repo root):
-#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin c5 hash issue c4   (default: micro mlp bench pmc pin)
+#   tools/profile_round.sh r02 [steps...]      steps: micro mlp bench pmc pin c5 hash issue c4 train timeline   (default: micro mlp bench pmc pin)
 # Output goes to gpurun_out/<tag>/ ; then: python tools/profile_collect.py gpurun_out/<tag> rNN   (copies the summaries the documents quote into profiles/).
 # rocprofv3 is always given the interpreter binary itself after `--` (no env / bash -c / shebang hop) and counters are
 # collected in passes of their own (no trace domains beside --pmc).
@@ -60,6 +60,16 @@ fi
 if has c4; then
   echo "== configs[3]: one rank's share of the 4K frame" && timeout -k 10 300 "$PY" tools/c4_rank_emulation.py > "$OUT/c4_rank_emulation.txt" 2>&1 || exit 1
   echo "== configs[3] on one GPU" && timeout -k 10 400 "$PY" bench.py --config c4 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/c4_bench.json" 2> "$OUT/c4_bench.err" || exit 1
+fi
+if has train; then
+  echo "== training step alone, kernel traces (6x64, 8x128)"
+  bash tools/trace_train.sh "$TAG/train64" 64 6 > "$OUT/train_6x64.txt" 2>&1 || exit 1
+  bash tools/trace_train.sh "$TAG/train128" 128 8 > "$OUT/train_8x128.txt" 2>&1 || exit 1
+fi
+if has timeline; then
+  echo "== frame timelines (default preset, configs[4], HashGrid)"
+  { echo "# default preset"; timeout -k 10 200 "$PY" tools/frame_timeline.py --frames 8; echo "# configs[4]"; timeout -k 10 200 "$PY" tools/frame_timeline.py --config c5 --frames 8;
+    echo "# HashGrid model"; timeout -k 10 200 "$PY" tools/frame_timeline.py --pos-id 0 --frames 8; } > "$OUT/frame_timeline.txt" 2>&1 || exit 1
 fi
 if has pin; then
   echo "== exr pin calibration" && timeout -k 10 600 "$PY" tests/exr_pin_calibrate.py --backend gpu --frames 8192 --variant-frames 2048 --out "$OUT/exr_pin_gpu.json" > "$OUT/exr_pin_gpu.log" 2>&1 || exit 1
