@@ -1133,12 +1133,13 @@ __global__ __launch_bounds__(256) void k_encode_hash_list(const float* __restric
 // the loss scale).  The sum order, hence the last bits, vary from run to run -- unlike the MLP's slab reduction.
 // k_grid_grad_f32 then widens the table into the fp32 gradient vector (what the all-reduce and the optimizer read).
 __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
-                                                      uint32_t* __restrict__ grad16, uint32_t n, HashLevels lv)
+                                                      uint32_t* __restrict__ grad16, uint32_t n, HashLevels lv, uint32_t diag_skip_levels)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sample = gid >> 4, level = gid & 15u;
     if (sample >= n) return;
+    if ((diag_skip_levels >> level) & 1u) return;      // DIAGNOSTIC (NRC_DIAG_GRID_SKIP_LEVELS, wrong gradients): what a level's atomics cost
     const float de0 = (float)d_enc[(size_t)sample * 32u + 2u * level], de1 = (float)d_enc[(size_t)sample * 32u + 2u * level + 1u];
     if (de0 == 0.0f && de1 == 0.0f) return;
     const float* p = in + (size_t)sample * 5u;
@@ -2240,7 +2241,7 @@ __global__ __launch_bounds__(256) void k_opt_pack(float* __restrict__ w, float* 
 template <bool SGD, bool FROM16>
 __global__ __launch_bounds__(256) void k_grid_opt(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
                                                  float* __restrict__ v, const float* __restrict__ grad,
-                                                 const uint32_t* __restrict__ grad16, uint32_t n_matrix, uint32_t n_entries, float lr,
+                                                 uint32_t* __restrict__ grad16, uint32_t n_matrix, uint32_t n_entries, float lr,
                                                  AdamArgs a, uint32_t* __restrict__ t_train, uint32_t* __restrict__ t_ema)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
@@ -2249,8 +2250,13 @@ __global__ __launch_bounds__(256) void k_grid_opt(float* __restrict__ w, float* 
     const uint32_t i0 = n_matrix + 2u * e;
     float g0, g1;
     if (FROM16) {
-        const half2v h = __builtin_bit_cast(half2v, grad16[e]);
+        const uint32_t word = grad16[e];
+        const half2v h = __builtin_bit_cast(half2v, word);
         g0 = (float)h[0]; g1 = (float)h[1];
+        // the table the atomics of the next step accumulate into is cleared here, entry by touched entry, instead of by a 28 MB memset in
+        // front of every backward pass (the runtime's fill kernel runs at wave priority 0 beside this library's kernels at 3: ~170 us in
+        // the frame for 7 us of work)
+        if (word != 0u) grad16[e] = 0u;
     } else {
         g0 = grad[i0]; g1 = grad[i0 + 1u];
     }
@@ -2897,7 +2903,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
     } else {
         launch_features(d_in, n, false, 1, s, false);
-        if (hash_) NRC_HIP(hipMemsetAsync(d_grad16_, 0, (size_t)n_grid_entries_ * 4, s));
+        if (hash_ && !grad16_clean_) NRC_HIP(hipMemsetAsync(d_grad16_, 0, (size_t)n_grid_entries_ * 4, s));      // (k_grid_opt leaves it clean)
+        grad16_clean_ = false;
         TrainArgsGen a;
         a.feat = (const half_t*)d_feat_[1];
         a.target = d_target;
@@ -2980,8 +2987,9 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         if (hash_) {
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
+            static const uint32_t skip_levels = getenv("NRC_DIAG_GRID_SKIP_LEVELS") ? (uint32_t)strtoul(getenv("NRC_DIAG_GRID_SKIP_LEVELS"), nullptr, 0) : 0u;
             hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
-                               (uint32_t*)d_grad16_, n, lv);
+                               (uint32_t*)d_grad16_, n, lv, skip_levels);
             // the fp32 copy in the gradient vector is for whoever reads the vector (exchange, hook, debug read-back): the
             // optimizer takes the table gradient from grad16 itself (k_grid_opt)
             grid16_valid_ = fused_opt_;
@@ -3063,7 +3071,8 @@ bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* l
         if (hash_) {
             const dim3 g(ceil_div(n_grid_entries_, 256));
             uint32_t *tt = (uint32_t*)d_t16_train_, *te = (uint32_t*)d_t16_ema_[next];
-            const uint32_t* g16 = (const uint32_t*)d_grad16_;
+            uint32_t* g16 = (uint32_t*)d_grad16_;
+            if (grid16_valid_) grad16_clean_ = true;      // k_grid_opt<., true> clears the entries it reads
             if (sgd_ && grid16_valid_)
                 hipLaunchKernelGGL((k_grid_opt<true, true>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
             else if (sgd_)

@@ -108,6 +108,7 @@ private:
     int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)
     int32_t* d_dst_ = nullptr;           // [3][n_mlp_] parameter -> slot in the forward / EMA inference / backward image (k_opt_pack)
     bool fused_opt_ = false;
+    bool grad16_clean_ = false;          // d_grad16_ is all zero (the optimizer cleared what the last backward() touched)
     bool grid16_valid_ = false;          // the packed fp16 table gradient of the last backward() is what the optimizer should read
     int32_t* d_src_inf_ = nullptr;       // the same for the EMA inference image (= d_src_fwd_ unless enc80_generic_)
     bool enc80_generic_ = false;         // generic model whose EMA inference encodes Frequency(12)+OneBlob(4) inside k_infer_gen
