@@ -247,6 +247,8 @@ class Job:
                 print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
                 parallel.attach_gradient_allreduce(self.nrc, world, native=False)
                 self.exchange = dict(path="torch.distributed hook (%s)" % dist.get_backend(), rccl_rank=rank, rccl_ranks=world)
+                if world > 1 and dist.get_backend() == "nccl":
+                    api.set_wave_priority_raise(False)      # torch's RCCL kernels run beside the library's: one priority for all (nrc_hpm.h)
                 if world > 1:
                     self.nrc.SetCollectiveHooks(rank, world)      # frame gather / metric reduction over the same transport
         self.randoms = None

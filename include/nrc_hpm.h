@@ -269,6 +269,12 @@ float nrc_renderer_frame_time_ms(nrc_renderer_t* r, float* stage_ms);
 /* the same stage times averaged over every frame rendered since the last reset (HIP events on the renderer's streams);
  * *frames = number of frames covered.  avg_ms == NULL with reset != 0 only forgets the frames so far, without reading an event */
 int nrc_renderer_stage_stats(nrc_renderer_t* r, float avg_ms[8], uint32_t* frames, int reset);
+/* Wave issue priority of the library's kernels (process-wide, current device): 1 (default) raises every kernel to s_setprio 3 -- no kernel of
+ * the host can then outrank a path-integrator wave (the second guard behind the compiler flag) --, 0 leaves them all at
+ * the hardware default.  Either way the whole library runs at ONE priority and the frame rate is the same; 0 is for a process whose
+ * foreign kernels run beside the renderer (RCCL's all-reduce, the runtime's fills and copies): at priority 0 under waves at 3 a 28 MB
+ * hipMemsetAsync took 184 us inside a frame, 65 us among equals.  nrc_cache_comm_init selects 0 for world > 1. */
+int nrc_set_wave_priority_raise(int on);
 /* the same events as a timeline (the reference's per-frame timestamp queries, src/NrcHpmRenderer.cu:495-515, kept for every frame since
  * the last reset): times_ms[f * 6 + k] = milliseconds from the first frame's start to event k of frame f -- 0 gen_rays starts, 1 gen_rays
  * done, 2 train rays done, 3 inference done, 4 compositing done, 5 training done -- for the first min(*frames, max_frames) frames;

@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_framebuffer_on",
     "nrc_renderer_export_exr",
-    "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_frame_timeline", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
+    "nrc_renderer_frame_time_ms", "nrc_renderer_stage_stats", "nrc_renderer_frame_timeline", "nrc_set_wave_priority_raise", "nrc_renderer_destroy", "nrc_renderer_buffer", "nrc_renderer_count_fetches",
     "nrc_renderer_train_grid",
     "nrc_mc_renderer_create", "nrc_mc_renderer_render", "nrc_mc_renderer_set_camera", "nrc_mc_renderer_set_blend",
     "nrc_mc_renderer_set_frame_random", "nrc_mc_renderer_framebuffer", "nrc_mc_renderer_export_exr",
@@ -87,6 +87,12 @@ ABI_SYMBOLS = [
 ]
 
 _lib = None
+
+
+def set_wave_priority_raise(on=True):
+    """nrc_set_wave_priority_raise: 1 (default) every kernel of the library at s_setprio 3, 0 at the hardware default (a process whose foreign
+    kernels -- torch's NCCL all-reduce, fills, copies -- run beside the renderer)"""
+    _check(load_library().nrc_set_wave_priority_raise(C.c_int(int(bool(on)))))
 
 
 def build_id():

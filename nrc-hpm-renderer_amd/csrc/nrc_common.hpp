@@ -76,4 +76,18 @@ struct Pcg32 {
 #ifndef NRC_DIAG_LOWPRIO
 #define NRC_DIAG_LOWPRIO 0
 #endif
-#define NRC_RAISE_WAVE_PRIORITY(bit) do { if (!((NRC_DIAG_LOWPRIO) & (bit))) __builtin_amdgcn_s_setprio(NRC_WAVE_PRIORITY); } while (0)
+// The run-time side of the guard (round 4): 1 = raise (default); 0 = every kernel of the library stays at the default priority -- still
+// ONE priority for the whole library -- for a process whose FOREIGN kernels run beside it (RCCL's all-reduce on the training stream of a
+// multi-GPU job, the runtime's fill and copy kernels): those cannot be raised, and at priority 0 under waves at 3 a 28 MB hipMemsetAsync
+// took 184 us in the frame against 65 among equals (7 alone), while the frame rate of every preset is the same either way (8 008-8 039
+// against 7 980 Msamples/s on the default one).  Set by nrc_set_wave_priority_raise; nrc_cache_comm_init lowers it for world > 1.
+// One copy per translation unit (each .hip file is its own code object): mlp_ / integrator_set_wave_priority_raise write them.
+#if defined(__HIPCC__)
+namespace nrc {
+static __device__ int g_raise_wave_priority = 1;
+}
+#define NRC_RAISE_WAVE_PRIORITY(bit)                                                                    \
+    do {                                                                                                \
+        if (!((NRC_DIAG_LOWPRIO) & (bit)) && nrc::g_raise_wave_priority != 0) __builtin_amdgcn_s_setprio(NRC_WAVE_PRIORITY); \
+    } while (0)
+#endif

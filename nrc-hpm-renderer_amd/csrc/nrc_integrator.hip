@@ -1326,7 +1326,10 @@ __device__ __forceinline__ bool pixel_of_thread(const DevFrame& fr, uint32_t* lx
 #endif
 constexpr uint32_t CAMERA_WAVES_PER_BLOCK = NRC_CAMERA_WAVES_PER_BLOCK;
 // (wave priority of the camera kernels: NRC_RAISE_WAVE_PRIORITY in nrc_common.hpp)
-__device__ __forceinline__ void camera_wave_priority() { NRC_RAISE_WAVE_PRIORITY(8); }
+__device__ __forceinline__ void camera_wave_priority(const DevFrame& fr)
+{
+    if (!((NRC_DIAG_LOWPRIO) & 8) && fr.raise_priority != 0u) __builtin_amdgcn_s_setprio(NRC_WAVE_PRIORITY);
+}
 __host__ __device__ inline uint32_t camera_row_blocks(uint32_t w)
 {
     const uint32_t blocks_x = (((w + 7u) >> 3) + CAMERA_WAVES_PER_BLOCK - 1u) / CAMERA_WAVES_PER_BLOCK;
@@ -1590,7 +1593,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                                                  float4* __restrict__ dirs, float* __restrict__ infer_in,
                                                  unsigned long long* fetch_counter, TrainGrid tg, int full_vertex_images)
 {
-    camera_wave_priority();
+    camera_wave_priority(fr);
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     uint32_t lx = 0, y = 0, slot = 0;
@@ -1791,7 +1794,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
                                                   float blend_factor, float4* __restrict__ out_rgba,
                                                   float* __restrict__ info, unsigned long long* fetch_counter)
 {
-    camera_wave_priority();
+    camera_wave_priority(fr);
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
@@ -2356,6 +2359,8 @@ static dim3 pixel_grid(uint32_t w, uint32_t h) { return dim3(ceil_div(w, 16), ce
 // k_gen_rays / k_mc_render: one 8x8 pixel tile per wave, see pixel_of_wave_tile
 static dim3 wave_tile_grid(uint32_t w, uint32_t h) { return dim3(camera_row_blocks(w) * ceil_div(h, 8)); }
 
+static int g_host_raise_wave_priority = 1;      // (integrator_set_wave_priority_raise)
+
 void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t primary_ray_length,
                      float primary_ray_prob, float* primary, float* info, float* origin, float* dir, float* infer_in,
                      unsigned long long* fetch_counter, const TrainGrid& tg, bool full_vertex_images, hipStream_t s)
@@ -2367,7 +2372,9 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     dim3 grid = wave_tile_grid(fr.w, fr.h);
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
     if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fr,
+    DevFrame fa = fr;
+    fa.raise_priority = (uint32_t)g_host_raise_wave_priority;
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fa,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
                        fetch_counter, tg, full_vertex_images ? 1 : 0);
     NRC_HIP(hipGetLastError());
@@ -2418,8 +2425,10 @@ void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& 
     dim3 grid = wave_tile_grid(fr.w, fr.h);
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
     if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
+    DevFrame fa = fr;
+    fa.raise_priority = (uint32_t)g_host_raise_wave_priority;
     hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,
-                       cam, fr, path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
+                       cam, fa, path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
     NRC_HIP(hipGetLastError());
 }
 
@@ -2436,6 +2445,14 @@ void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& 
     hipLaunchKernelGGL(k_ring_push, dim3(ceil_div(T, 256)), dim3(256), 0, s, fr, tg, (const float4*)origin,
                        (const float4*)dir, ring, (const uint32_t*)scratch);
     NRC_HIP(hipGetLastError());
+}
+
+// this translation unit's copy of the run-time priority switch (nrc_common.hpp), and the host-side value the camera kernels' launchers
+// hand over as a kernel argument (DevFrame::raise_priority)
+void integrator_set_wave_priority_raise(int on)
+{
+    NRC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_raise_wave_priority), &on, sizeof(int)));
+    g_host_raise_wave_priority = on;
 }
 
 void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary, const float* info,

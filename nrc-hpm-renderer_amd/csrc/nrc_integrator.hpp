@@ -83,6 +83,9 @@ struct DevFrame {
     // list is whatever the waves' atomics made it; its only reader (the HashGrid encoder, Mlp::launch_features) writes by query index.
     uint32_t* live_list;
     uint32_t* live_count;
+    // nrc_common.hpp's run-time priority switch as a kernel argument of the camera kernels (set by their launchers): their 32 400 waves
+    // would each pay two dependent scalar loads for the device-side copy (0.7 % of a launch)
+    uint32_t raise_priority;
 };
 constexpr uint32_t kOrderSlotMask = 0x00ffffffu, kOrderPartShift = 28u, kOrderNone = 0xffffffffu;
 constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front
@@ -132,6 +135,7 @@ void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& 
                        const float* origin, const float* dir, uint32_t* ring, uint32_t* scratch, float* train_in,
                        float* train_target, hipStream_t s);
 
+void integrator_set_wave_priority_raise(int on);      // nrc_common.hpp: NRC_RAISE_WAVE_PRIORITY's run-time switch, this file's kernels
 void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary,
                       const float* info, const float* infer_out, float* out_rgba, hipStream_t s, uint32_t* live_count_reset = nullptr);
 

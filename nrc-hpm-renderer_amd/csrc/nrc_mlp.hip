@@ -2547,6 +2547,12 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
 }
 
+// this translation unit's copy of the run-time priority switch (nrc_common.hpp)
+void mlp_set_wave_priority_raise(int on)
+{
+    NRC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_raise_wave_priority), &on, sizeof(int)));
+}
+
 // CU count of the device this Mlp lives on (one instance per GPU: no process-wide cache)
 int Mlp::num_cus()
 {

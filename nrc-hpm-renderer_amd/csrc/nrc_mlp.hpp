@@ -25,6 +25,8 @@ struct CompositeArgs {
     float blend_factor;
 };
 
+void mlp_set_wave_priority_raise(int on);      // nrc_common.hpp: NRC_RAISE_WAVE_PRIORITY's run-time switch, nrc_mlp.hip's kernels
+
 class Mlp {
 public:
     explicit Mlp(const nrc_config& cfg);

@@ -543,6 +543,31 @@ def test_live_query_list_changes_no_pixel(api, sc, cloud16, torch_gpu, model, mo
         assert np.array_equal(base[4][live].view(np.uint32), other[4][live].view(np.uint32))
 
 
+def test_wave_priority_switch_changes_no_pixel(api, sc, cloud16, torch_gpu):
+    """nrc_set_wave_priority_raise(0) leaves every kernel of the library at the hardware's default issue priority instead of s_setprio 3
+    (for a process whose foreign kernels -- RCCL's all-reduce -- run beside the renderer; nrc_cache_comm_init selects it for world > 1):
+    one priority for the whole library either way, so 8 trained, blended frames agree bit for bit"""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    frs = sc.frame_randoms(8, seed=31)
+    results = []
+    try:
+        for raise_ in (True, False, False, True):
+            api.set_wave_priority_raise(raise_)
+            cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+            ren.SetBlend(True)
+            ren.RenderFrames(frs, True)
+            results.append((ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy()))
+            ren.Destroy()
+            nrc.Destroy()
+    finally:
+        api.set_wave_priority_raise(True)
+    for other in results[1:]:
+        assert np.array_equal(results[0][0].view(np.uint32), other[0].view(np.uint32))
+        assert results[0][1] == other[1]
+        assert np.array_equal(results[0][2].view(np.uint32), other[2].view(np.uint32))
+
+
 def test_framebuffer_on_a_consumer_stream(api, sc, cloud16, torch_gpu):
     """GetImage(stream): a read-back stream of the caller is ordered behind each frame's compositing while the render stream runs
     ahead; the copies it makes equal the frames of a renderer that is read synchronously"""
