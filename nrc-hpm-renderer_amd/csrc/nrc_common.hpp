@@ -86,8 +86,12 @@ struct Pcg32 {
 namespace nrc {
 static __device__ int g_raise_wave_priority = 1;
 }
+#ifdef NRC_NO_PRIORITY_SWITCH      // A/B build: the raise unconditional, as before the switch
+#define NRC_RAISE_WAVE_PRIORITY(bit) do { if (!((NRC_DIAG_LOWPRIO) & (bit))) __builtin_amdgcn_s_setprio(NRC_WAVE_PRIORITY); } while (0)
+#else
 #define NRC_RAISE_WAVE_PRIORITY(bit)                                                                    \
     do {                                                                                                \
         if (!((NRC_DIAG_LOWPRIO) & (bit)) && nrc::g_raise_wave_priority != 0) __builtin_amdgcn_s_setprio(NRC_WAVE_PRIORITY); \
     } while (0)
+#endif
 #endif
