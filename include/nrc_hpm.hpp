@@ -34,6 +34,9 @@ inline void nrc_check(int status)
 {
     if (status != NRC_OK) throw std::runtime_error(nrc_last_error());
 }
+// nrc_set_wave_priority_raise: false puts every kernel of the library at the hardware's default issue priority (a host whose own kernels --
+// RCCL's, the runtime's fills -- run beside the renderer); NeuralRadianceCache::CommInit does it for more than one rank
+inline void SetWavePriorityRaise(bool raise) { nrc_check(nrc_set_wave_priority_raise(raise ? 1 : 0)); }
 
 // glm::vec3 stand-in for the few host-side values the path takes (camera pose, light angles)
 struct vec3 {
@@ -385,6 +388,16 @@ public:
     bool IsBlending() const { return nrc_renderer_is_blending(h_) != 0; }
     float GetFrameTimeMS() const { return nrc_renderer_frame_time_ms(h_, nullptr); }
     const float* GetStageTimesMS() const { return stage_ms_; }
+    // the timestamp queries of every frame since the last statistics reset as a timeline: [frames][6] ms from the first frame's start
+    // (gen_rays start / done, train rays done, inference done, compositing done, training done); nrc_renderer_frame_timeline
+    std::vector<float> FrameTimeline(uint32_t maxFrames = 4096) const
+    {
+        std::vector<float> t((size_t)maxFrames * 6);
+        uint32_t n = 0;
+        nrc_check(nrc_renderer_frame_timeline(h_, t.data(), maxFrames, &n));
+        t.resize((size_t)n * 6);
+        return t;
+    }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_renderer_set_camera(h_, camera)); }
     void SetCamera(void* queue, const Camera* camera) { SetCamera(queue, camera->Matrices()); }
     void SetBlend(bool blend) { nrc_check(nrc_renderer_set_blend(h_, blend ? 1 : 0)); }
