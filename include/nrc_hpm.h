@@ -288,9 +288,9 @@ int nrc_renderer_destroy(nrc_renderer_t* r);
  * 6 train input [T][5], 7 train target [T][3], 8 train ring {head, tail, RayInfo[ring]}.  Buffers 4 and 5 are handed out in the
  * reference's order, query x*H+y (nrc/prep_infer_rays.comp:31), as a COPY made by this call: inside the renderer they are
  * tile-major (the 64 queries of an 8x8 pixel tile contiguous), and the cache's own API (nrc_cache_init / infer) speaks x*H+y
- * whatever its caller's order is.  Buffer 5 is defined where nrc/render.comp:19-27 reads it -- at the pixels that scattered (info == 1):
- * the renderer's inference walks the frame's list of those pixels and writes nothing for the others (the reference's network output
- * for a zero-filled query has no reader either). */
+ * whatever its caller's order is.  Entries of pixels that did not scatter (info != 1) are zeros in both copies: the reference's zero-filled
+ * query slots (src/NrcHpmRenderer.cu:1996), and a radiance nrc/render.comp:19-27 never reads -- the renderer's gen_rays and inference walk
+ * the frame's list of scattered pixels and write nothing for the others. */
 void* nrc_renderer_buffer(nrc_renderer_t* r, int which, size_t* bytes);
 /* Empty-space early-out (on by default): camera rays that provably cannot come within a voxel of non-empty density skip their
  * delta-tracking walk -- the walk could only reject every tentative collision, leave the volume unscattered and produce env(rd),

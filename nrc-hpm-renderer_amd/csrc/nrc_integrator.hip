@@ -1640,9 +1640,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 const size_t pix = (size_t)y * fr.w + lx;
                 out_store(&primary[pix], make_float4(e.x, e.y, e.z, 1.0f));
                 out_store(&info[pix], 0.0f);
-                float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
+                if (fr.skip_dead_queries == 0u) {
+                    float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
-                for (int k = 0; k < 5; k++) out_store(&qo[k], 0.0f);
+                    for (int k = 0; k < 5; k++) out_store(&qo[k], 0.0f);
+                }
             }
             if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start, part);
 #ifdef NRC_LOOP_PROFILE
@@ -1757,9 +1759,11 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         out_store(&info[pix], did_scatter ? 1.0f : 0.0f);
         // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
         // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
-        float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
+        if (fr.skip_dead_queries == 0u || (entered && did_scatter)) {
+            float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
-        for (int k = 0; k < 5; k++) out_store(&qo[k], q[k]);
+            for (int k = 0; k < 5; k++) out_store(&qo[k], q[k]);
+        }
     }
     if (fr.live_list != nullptr) {      // the frame's live queries, for an encoder that gathers (DevFrame::live_list): one atomic per wave
         const bool live = inside && entered && did_scatter;
@@ -2166,12 +2170,17 @@ __global__ __launch_bounds__(256) void k_composite(DevFrame fr, uint32_t show_nr
 }
 
 // tile-major (query_index) -> the reference's x * H + y order, C floats per query: what nrc_renderer_buffer hands out
-__global__ __launch_bounds__(256) void k_query_layout(DevFrame fr, uint32_t C, const float* __restrict__ tiled, float* __restrict__ linear)
+// info (the frame's didScatter image, or nullptr): the entries of pixels that did not scatter are handed out as zeros -- the reference's
+// zero-filled query buffer (NrcHpmRenderer.cu:1996); inside the renderer those slots are not written at all (DevFrame::skip_dead_queries,
+// the live-query list)
+__global__ __launch_bounds__(256) void k_query_layout(DevFrame fr, uint32_t C, const float* __restrict__ tiled, float* __restrict__ linear,
+                                                     const float* __restrict__ info)
 {
     uint32_t lx, y;
     if (!pixel_of_thread(fr, &lx, &y)) return;
     const size_t q = query_index(fr.w, lx, y), lin = (size_t)lx * fr.h + y;
-    for (uint32_t c = 0; c < C; c++) linear[lin * C + c] = tiled[q * C + c];
+    const bool dead = info != nullptr && info[(size_t)y * fr.w + lx] != 1.0f;
+    for (uint32_t c = 0; c < C; c++) linear[lin * C + c] = dead ? 0.0f : tiled[q * C + c];
 }
 
 // ------------------------------------------------------------------------------------------------ ref/cmp1, norm, cmp2
@@ -2463,9 +2472,9 @@ void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor,
     NRC_HIP(hipGetLastError());
 }
 
-void launch_query_layout(const DevFrame& fr, uint32_t floats_per_query, const float* tiled, float* linear, hipStream_t s)
+void launch_query_layout(const DevFrame& fr, uint32_t floats_per_query, const float* tiled, float* linear, hipStream_t s, const float* info)
 {
-    hipLaunchKernelGGL(k_query_layout, pixel_grid(fr.w, fr.h), dim3(256), 0, s, fr, floats_per_query, tiled, linear);
+    hipLaunchKernelGGL(k_query_layout, pixel_grid(fr.w, fr.h), dim3(256), 0, s, fr, floats_per_query, tiled, linear, info);
     NRC_HIP(hipGetLastError());
 }
 uint32_t query_count(uint32_t w, uint32_t h) { return ceil_div(w, 8) * ceil_div(h, 8) * 64u; }

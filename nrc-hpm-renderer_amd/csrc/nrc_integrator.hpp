@@ -86,6 +86,9 @@ struct DevFrame {
     // nrc_common.hpp's run-time priority switch as a kernel argument of the camera kernels (set by their launchers): their 32 400 waves
     // would each pay two dependent scalar loads for the device-side copy (0.7 % of a launch)
     uint32_t raise_priority;
+    // the queries of pixels that did not scatter are not written (nobody reads them: the inference walks live_list and encodes inside its
+    // kernel or from the list).  0: every slot of the query buffer is written, dead pixels with zeros (the reference's zero-filled buffer)
+    uint32_t skip_dead_queries;
 };
 constexpr uint32_t kOrderSlotMask = 0x00ffffffu, kOrderPartShift = 28u, kOrderNone = 0xffffffffu;
 constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front
@@ -109,7 +112,8 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 // finds the pixels of the frame whose RNG state is in fr.flight_list (flight_mode 1) and appends their tiles to hot (count zeroed by the caller: hot[kHotTilesMax])
 void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s);
 // tile-major query order of the renderer's inference buffers (see query_index in nrc_integrator.hip) -> x * H + y
-void launch_query_layout(const DevFrame& fr, uint32_t floats_per_query, const float* tiled, float* linear, hipStream_t s);
+void launch_query_layout(const DevFrame& fr, uint32_t floats_per_query, const float* tiled, float* linear, hipStream_t s,
+                         const float* info = nullptr);
 uint32_t query_count(uint32_t w, uint32_t h);      // queries in tile-major order: whole 8x8 tiles
 void launch_tile_mask(const float* boxes, uint32_t n_boxes, const DevProjView& pv, const DevFrame& fr, uint32_t* mask, hipStream_t s);
 uint32_t tile_mask_words(uint32_t w, uint32_t h);

@@ -514,11 +514,13 @@ def test_live_query_list_changes_no_pixel(api, sc, cloud16, torch_gpu, model, mo
     scene = sc.make_scene(cloud16, scene_id=4)
     frs = sc.frame_randoms(6, seed=29)
     results = []
-    for no_list in ("1", None, None):
-        if no_list:
+    for no_list in ("1", None, None, "zero-dead"):      # ("zero-dead": the list, with gen_rays writing the zero queries of unscattered pixels)
+        monkeypatch.delenv("NRC_NO_LIVE_LIST", raising=False)
+        monkeypatch.delenv("NRC_ZERO_DEAD_QUERIES", raising=False)
+        if no_list == "1":
             monkeypatch.setenv("NRC_NO_LIVE_LIST", no_list)
-        else:
-            monkeypatch.delenv("NRC_NO_LIVE_LIST", raising=False)
+        elif no_list == "zero-dead":
+            monkeypatch.setenv("NRC_ZERO_DEAD_QUERIES", "1")
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
                                         hashgrid_log2_size=model[4], log2_infer_batch_size=21)      # ONE inference batch: the list is used
         ren.SetBlend(True)
@@ -527,7 +529,8 @@ def test_live_query_list_changes_no_pixel(api, sc, cloud16, torch_gpu, model, mo
         img = ren.GetImage().cpu().numpy().copy()
         info = ren.Buffer("info").cpu().numpy().reshape(-1).copy()
         rad = ren.Buffer("infer_output").cpu().numpy().reshape(-1, 3).copy()
-        results.append((img, nrc.GetLoss(), nrc.GetParams(0).copy(), info, rad))
+        qry = ren.Buffer("infer_input").cpu().numpy().reshape(-1, 5).copy()
+        results.append((img, nrc.GetLoss(), nrc.GetParams(0).copy(), info, rad, qry))
         ren.Destroy()
         nrc.Destroy()
     base = results[0]
@@ -541,6 +544,8 @@ def test_live_query_list_changes_no_pixel(api, sc, cloud16, torch_gpu, model, mo
         assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
         assert np.array_equal(base[3], other[3])
         assert np.array_equal(base[4][live].view(np.uint32), other[4][live].view(np.uint32))
+        # the query buffer as it is handed out: bit-identical, zeros where the pixel did not scatter (the reference's zero-filled slots)
+        assert np.array_equal(base[5].view(np.uint32), other[5].view(np.uint32)) and not base[5][~live].any() and not other[4][~live].any()
 
 
 def test_wave_priority_switch_changes_no_pixel(api, sc, cloud16, torch_gpu):
