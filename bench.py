@@ -452,7 +452,9 @@ def main():
         # framebuffer write + 32 B NRC query I/O per pixel.  What the kernel stores today on top of that (primary colour, info,
         # vertex images for the train rays) is reported separately and is not credited.
         gen_bytes = n_fetch * 1.0 + n_px * (16.0 + 32.0)
-        gen_store_bytes = n_px * (16 + 4 + 20) + ren.VertexImageBytes()
+        # (the query of a pixel that did not scatter is not written since round 4: the inference walks the frame's live-query list)
+        n_live = int((ren.Buffer("info") == 1.0).sum().item())
+        gen_store_bytes = n_px * (16 + 4) + n_live * (20 + 4) + ren.VertexImageBytes()
         # `traffic`: HBM-side bytes per launch from the rocprofv3 PMC passes of the SAME command, committed under profiles/
         # (FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 corrections of MI355X_MICROARCH.md) -- a constant read from that
         # file, not measured in this run; quoted only when this run is the profiled workload, and labelled with its source.
