@@ -573,6 +573,30 @@ def test_wave_priority_switch_changes_no_pixel(api, sc, cloud16, torch_gpu):
         assert np.array_equal(results[0][2].view(np.uint32), other[2].view(np.uint32))
 
 
+@pytest.mark.parametrize("model", [(3, 0, 64, 6, 0), (3, 0, 128, 2, 0), (0, 0, 64, 2, 11), (2, 1, 64, 2, 0)], ids=["fused", "enc80-128", "hashgrid", "generic"])
+def test_a_view_without_a_scattering_pixel_renders_the_environment(api, orc, sc, cloud16, torch_gpu, model):
+    """the camera looks away from the medium: no pixel scatters, the frame's live-query list stays empty (a list-driven inference launch
+    with nothing to do, a training step on a ring buffer without a hit) -- four trained frames equal the oracle's gen_rays primary colour"""
+    W, H = 128, 80
+    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
+    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=10, log2_infer_batch_size=21, pos_id=model[0], dir_id=model[1], nn_width=model[2],
+                        nn_depth=model[3], hashgrid_log2_size=model[4])
+    nrc = api.NeuralRadianceCache(cfg)
+    cam = sc.make_camera(pos=(64.0, 0.0, 0.0), view_dir=(1.0, 0.0, 0.0), aspect=W / H)      # the medium is behind the camera
+    ren = api.NrcHpmRenderer(W, H, False, cam, cfg, scene, nrc)
+    frs = sc.frame_randoms(4, seed=5)
+    ren.RenderFrames(frs, True)
+    img = ren.GetImage().cpu().numpy().reshape(H, W, 4)
+    info = ren.Buffer("info").cpu().numpy()
+    assert not info.any()
+    assert not ren.Buffer("infer_input").cpu().numpy().any() and not ren.Buffer("infer_output").cpu().numpy().any()
+    o = orc.nrc_gen_rays(scene, cam, W, H, 1, 0.0, frs[3], threads=8)
+    assert not o["info"].any()
+    assert same_bits(img[..., :3], o["primary"][..., :3]) and (img[..., 3] == 1.0).all() and img[..., :3].std() > 0.0
+    ren.Destroy()
+    nrc.Destroy()
+
+
 def test_framebuffer_on_a_consumer_stream(api, sc, cloud16, torch_gpu):
     """GetImage(stream): a read-back stream of the caller is ordered behind each frame's compositing while the render stream runs
     ahead; the copies it makes equal the frames of a renderer that is read synchronously"""
