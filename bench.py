@@ -14,7 +14,7 @@ runs fewer ranks than it was asked for.  The frame is sharded by interleaved str
 all-reduced over RCCL each training step (by the library itself: nrc_cache_comm_init).  Rank 0 prints ONE JSON line.
 
   --config c2 (default)  configs[1]+[2]: 1920x1080 per GPU, 256^3 cloud, 4 spp, 6x64; N > 1 is WEAK scaling (every rank keeps a
-                         1920x1080-pixel tile of a larger frame, 16 384 train rays per rank).  With N > 1 the line also carries
+                         ~1920x1080-pixel share of the same view at sqrt(N) x the resolution, 16 384 train rays per rank).  With N > 1 the line also carries
                          `strong_scaling_c4` (the configs[3] figure below, measured after the timed region) and the per-step
                          all-reduce time.
   --config c4            configs[3]: ONE 3840x2160 frame, 8 spp, sharded over the N ranks; STRONG scaling (the global frame and the
@@ -132,13 +132,15 @@ def self_launch(args):
 
 # ---------------------------------------------------------------------------------------------------------------- workloads
 def global_frame(n_gpus, w, h, strong=False):
-    """weak scaling: every rank renders w*h pixels (interleaved column strips) of a larger frame; strong: w x h IS the global frame"""
-    if strong:
+    """weak scaling: every rank renders ~w*h pixels (interleaved column strips) of the SAME VIEW at sqrt(N) times the resolution -- the
+    aspect ratio, hence the share of the frame the medium covers and the work per pixel, stay those of the one-GPU frame (a 2w x h or
+    4w x 2h frame at the same vertical field of view would halve the medium's share: the per-rank work would not be fixed); both sides
+    are multiples of the 8-pixel tile, the pixel count is within 0.1 % of N*w*h (N = 2: 2712x1528, 4: 3840x2160, 8: 5432x3056 for
+    1920x1080).  strong: w x h IS the global frame"""
+    if strong or n_gpus == 1:
         return (w, h)
-    table = {1: (w, h), 2: (2 * w, h), 4: (2 * w, 2 * h), 8: (4 * w, 2 * h)}
-    if n_gpus in table:
-        return table[n_gpus]
-    return (n_gpus * w, h)
+    r = float(n_gpus) ** 0.5
+    return (max(8, int(round(w * r / 8.0)) * 8), max(8, int(round(h * r / 8.0)) * 8))
 
 
 def gpu_mc_baseline(api, sc, scene, W, H, frames=20, keep_warm_ms=0.0):
@@ -546,9 +548,10 @@ def main():
                         "env map, scene preset 4, train=%d (global batch 16384 rays = %d per rank + 1 Adam step per sub-frame)"
                         % (gw, gh, world, local_w, volume, spp, model, args.train, train_rays))
         else:
-            workload = ("%s: %dx%d per GPU (global %dx%d, tiles of interleaved 8-column strips), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
+            per_gpu = "%dx%d per GPU" % (W, H) if world == 1 else "1/%d of the same view at %dx%d (%d x %d pixels on rank 0; %dx%d on one GPU)" % (world, gw, gh, local_w, gh, W, H)
+            workload = ("%s: %s (global %dx%d, tiles of interleaved 8-column strips), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
                         "train=%d (%d train rays + 1 Adam step per sub-frame)"
-                        % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", W, H, gw, gh, volume, spp, model, args.train, train_rays))
+                        % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", per_gpu, gw, gh, volume, spp, model, args.train, train_rays))
         exchange = dict(exchange, allreduce_us_per_step=allreduce_us, frame_assembly=assembly)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
