@@ -409,7 +409,17 @@ __device__ __forceinline__ void composite_query(const CompositeArgs& ca, uint32_
 }
 
 template <int DEPTH, int THREADS, int NT, int ABL = 0, bool FUSE = false, bool LISTED = false>
-__global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : 1) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
+// (second launch bound.  With ONE wave per SIMD the compiler assumes the 512-register budget is split into 256 architectural + 256
+// accumulation registers, puts the MFMA accumulators into AGPRs and copies every one of them out with v_accvgpr_read_b32 before the
+// ReLU / pack: 384 of the 1 346 instructions of the renderer-mode loop of the 4-wave form.  Two waves per SIMD = 256 registers, all
+// architectural on this target: 122 of them, no copies, 29 % fewer instructions -- and the default preset's frame 1.9 % SLOWER (8 125 ->
+// 7 980 Msamples/s, three alternating runs: gen_rays 0.234 -> 0.238 ms beside the denser kernel; the frame is a balance, DESIGN.md
+// section 4).  NRC_INFER_MIN_WAVES=2 builds it.  The generic kernels -- k_infer_gen, k_train_gen2, k_wgrad2 -- do ask for two: configs[4]
+// + 1 %, HashGrid + 0.6 %.)
+#ifndef NRC_INFER_MIN_WAVES
+#define NRC_INFER_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : NRC_INFER_MIN_WAVES) void k_infer(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
                                                   const uint4* __restrict__ image, unsigned long long* __restrict__ stamps = nullptr,
                                                   int skip_zero = 0, CompositeArgs ca = CompositeArgs{},
                                                   const uint32_t* __restrict__ live_list = nullptr,
@@ -1266,7 +1276,7 @@ __device__ __forceinline__ half8 ld_frag_g(const uint4* __restrict__ img, int fr
 // ENC80: the input is the raw 5-float query and the Frequency(12) + OneBlob(4) encoding is computed here, k-step by k-step, as
 // k_infer does (no k_encode pass, no 160 B/sample feature buffer); feat is unused, raw_in required, the image is in fmap80 order.
 template <int WIDTH, int THREADS, bool FEAT_LM, int NT = 2, bool ENC80 = false>
-__global__ __launch_bounds__(THREADS, WIDTH == 128 ? NRC_GEN128_WPS : 1) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
+__global__ __launch_bounds__(THREADS, WIDTH == 128 && NRC_GEN128_WPS > 2 ? NRC_GEN128_WPS : 2) void k_infer_gen(const half_t* __restrict__ feat, float* __restrict__ out, uint32_t n,
                                                       const uint4* __restrict__ img, int depth, int ks0,
                                                       const float* __restrict__ skip_in, const float* __restrict__ raw_in = nullptr,
                                                       const uint32_t* __restrict__ live_list = nullptr,
@@ -1739,7 +1749,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const 
 // for an 8-layer net.  Every output element is the same sequence of MFMAs as in k_train_gen: activations, deltas and loss are
 // bit-identical (tests/test_gpu_mlp.py::test_training_kernels_agree).
 template <int WIDTH, int NT>
-__global__ __launch_bounds__(256) void k_train_gen2(TrainArgsGen a, const uint4* __restrict__ img_fwd, const uint4* __restrict__ img_bwd)
+__global__ __launch_bounds__(256, 2) void k_train_gen2(TrainArgsGen a, const uint4* __restrict__ img_fwd, const uint4* __restrict__ img_bwd)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = 4, SG = WAVES / MTG;      // SG sample groups of MTG waves
@@ -2076,7 +2086,10 @@ __device__ __forceinline__ void wgrad_task(const WgradTask& T, const half_t* __r
         }
     }
 }
-__global__ __launch_bounds__(WGRAD2_WAVES * 64) void k_wgrad2(const half_t* __restrict__ deltas, const half_t* __restrict__ acts, uint32_t n,
+#ifndef NRC_WGRAD2_MIN_WAVES
+#define NRC_WGRAD2_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(WGRAD2_WAVES * 64, NRC_WGRAD2_MIN_WAVES) void k_wgrad2(const half_t* __restrict__ deltas, const half_t* __restrict__ acts, uint32_t n,
                                                              uint32_t chunk, uint32_t rows_d, uint32_t rows_a,
                                                              const WgradTask* __restrict__ tasks, int n_tasks, float* __restrict__ slabs,
                                                              uint32_t n_params)
