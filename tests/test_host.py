@@ -120,3 +120,21 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
     src = open(os.path.join(root, "bench.py")).read()
     launcher = src[src.index("def visible_gpus"):src.index("# ---------------------------------------------------------------------------------------------------------------- workloads")]
     assert "import torch" not in launcher and "torch.cuda" not in launcher
+
+
+def test_weak_scaling_frames_keep_the_one_gpu_view():
+    """bench.py --gpus N (default preset): the global frame is the one-GPU view at sqrt(N) x the resolution -- same aspect ratio (the medium
+    covers the same share of every rank's pixels), whole 8-pixel tiles, N x 1080p pixels within 0.2 % -- and the ranks' interleaved strips
+    add up to it; strong scaling (configs[3]) keeps the frame it was given"""
+    import bench
+    from nrc_hpm_renderer_amd import parallel
+    assert bench.global_frame(1, 1920, 1080) == (1920, 1080) and bench.global_frame(4, 1920, 1080) == (3840, 2160)
+    assert bench.global_frame(8, 3840, 2160, strong=True) == (3840, 2160)
+    for n in (2, 3, 4, 6, 8):
+        gw, gh = bench.global_frame(n, 1920, 1080)
+        assert gw % 8 == 0 and gh % 8 == 0
+        assert abs(gw / gh - 16.0 / 9.0) < 0.01 * 16.0 / 9.0
+        assert abs(gw * gh / (n * 1920.0 * 1080.0) - 1.0) < 2e-3
+        widths = [parallel.local_width(r, n, gw) for r in range(n)]
+        assert sum(widths) == gw and max(widths) - min(widths) <= parallel.DEFAULT_BLOCK
+
