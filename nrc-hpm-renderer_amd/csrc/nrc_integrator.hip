@@ -1757,15 +1757,16 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         }
 #endif
         out_store(&info[pix], did_scatter ? 1.0f : 0.0f);
-        // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and
-        // prep_infer_rays writes only scattered pixels: every slot is written here instead (no memset)
+        // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and prep_infer_rays writes only
+        // scattered pixels.  Here: no memset; without the live-query list every slot is written (zeros for the others: the list-free
+        // inference recognises them), with it only the scattered pixels' (DevFrame::skip_dead_queries: nobody reads the rest)
         if (fr.skip_dead_queries == 0u || (entered && did_scatter)) {
             float* qo = infer_in + query_index(fr.w, lx, y) * 5u;
 #pragma unroll
             for (int k = 0; k < 5; k++) out_store(&qo[k], q[k]);
         }
     }
-    if (fr.live_list != nullptr) {      // the frame's live queries, for an encoder that gathers (DevFrame::live_list): one atomic per wave
+    if (fr.live_list != nullptr) {      // the frame's live queries, which the renderer's inference walks (DevFrame::live_list): one atomic per wave
         const bool live = inside && entered && did_scatter;
         const unsigned long long lm = __ballot(live);
         if (lm != 0ull) {

@@ -482,8 +482,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 && NT == 2 ? 4 : NRC_INFER_
             for (int i = 0; i < 5; i++) xn[t][i] = __builtin_nontemporal_load(p + i);
         }
         f32x16 y[NT];
-        // renderer mode: gen_rays writes an all-zero query for every pixel that did not scatter (the reference's zero-filled
-        // slots, whose network output render.comp never reads); tiles made only of such queries skip the network and store 0
+        // renderer mode WITHOUT the live-query list: gen_rays writes an all-zero query for every pixel that did not scatter (the reference's
+        // zero-filled slots, whose network output render.comp never reads); tiles made only of such queries skip the network and store 0
         bool live = true;
         if (skip_zero && !listed) {
             bool nz = false;
@@ -1743,10 +1743,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const 
 // staged weight images: 219 + 64 registers and 80 KB of LDS per workgroup --, so a workgroup needs a CU that gen_rays has all but
 // left, and holds it for 17 barrier-to-barrier stages of 32 dependent MFMAs.  Here wave w of a sample group computes rows
 // 32w .. 32w+31 of the layer for NT tiles: it reads ITS weight fragments straight from L2 into registers one stage ahead (a fragment
-// has exactly one reader: no weight staging in LDS at all), the layer's input arrives as MFMA B operands through a 2 x 16 KB
+// has exactly one reader: no weight staging in LDS at all), the layer's input arrives as MFMA B operands through a 2 x 8 KB (per tile)
 // ping-pong in LDS that the waves fill with their own row blocks of the previous layer (one barrier per stage), and the epilogue
-// work (ReLU / mask / fp16 pack, the k-group stores of activations and deltas) is split the same way.  ~145 registers, 53 KB of LDS
-// for an 8-layer net.  Every output element is the same sequence of MFMAs as in k_train_gen: activations, deltas and loss are
+// work (ReLU / mask / fp16 pack, the k-group stores of activations and deltas) is split the same way.  152 registers and 37 KB of LDS
+// (one tile per sample group; 179 and 53 KB with two) for an 8-layer net.  Every output element is the same sequence of MFMAs as in k_train_gen: activations, deltas and loss are
 // bit-identical (tests/test_gpu_mlp.py::test_training_kernels_agree).
 template <int WIDTH, int NT>
 __global__ __launch_bounds__(256, 2) void k_train_gen2(TrainArgsGen a, const uint4* __restrict__ img_fwd, const uint4* __restrict__ img_bwd)
