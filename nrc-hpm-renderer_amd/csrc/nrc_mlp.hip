@@ -1165,6 +1165,103 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
     }
 }
 
+// ---- round 4: the table gradient of the large levels without memory-side atomics (k_grid_scatter + k_grid_gather).
+// k_grid_backward's 2.1 M packed-fp16 atomics per step execute at the memory side -- 112 us alone, and beside the frame they cost it 41 %
+// (NRC_DIAG_GRID_SKIP_LEVELS=0xffff: 3 060 -> 4 320 Msamples/s; gen_rays 0.62 -> 0.46 ms).  A level of at least 8 x 16 384 entries is cut
+// into BINS of 16 384 entries: pass 1 (one level and 256 samples per workgroup) appends its (entry, value) pairs to the level's bin
+// lists -- a per-workgroup LDS histogram, ONE global atomic per (workgroup, bin) to reserve the run --, pass 2 (one workgroup per bin) adds
+// a bin's pairs into 128 KB of fp32 accumulators in LDS and stores the entries that were touched.  The coarse levels (fewer than 8 bins)
+// and whatever does not fit a bin's list keep the atomics.  Values are the same fp16-rounded products; they are summed in fp32 and
+// rounded once (the atomics round every partial sum to fp16).
+constexpr uint32_t GB_BIN_LOG2 = 14, GB_BIN = 1u << GB_BIN_LOG2, GB_MAX_BINS = 64, GB_MIN_BINS = 8;
+struct GridBins {
+    uint32_t first[HG_LEVELS], count[HG_LEVELS];      // per level: index of its first bin, number of bins (0: the level keeps the atomics)
+    uint32_t cap;                                     // pairs a bin's list holds
+};
+__global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ in, const half_t* __restrict__ d_enc, uint32_t* __restrict__ grad16,
+                                                     uint32_t n, HashLevels lv, GridBins gb, uint32_t* __restrict__ counters,
+                                                     uint2* __restrict__ lists, uint32_t diag_skip_levels)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    __shared__ uint32_t s_cnt[GB_MAX_BINS], s_base[GB_MAX_BINS];
+    const uint32_t level = blockIdx.y, sample = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nb = gb.count[level];              // (workgroup-uniform)
+    if (threadIdx.x < GB_MAX_BINS) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    bool act = sample < n && ((diag_skip_levels >> level) & 1u) == 0u;
+    float de0 = 0.0f, de1 = 0.0f;
+    if (act) {
+        de0 = (float)d_enc[(size_t)sample * 32u + 2u * level];
+        de1 = (float)d_enc[(size_t)sample * 32u + 2u * level + 1u];
+        act = !(de0 == 0.0f && de1 == 0.0f);
+    }
+    uint32_t idx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (act) {
+        const float* p = in + (size_t)sample * 5u;
+        const float x[3] = {p[0], p[1], p[2]};
+        hg_corners(lv, level, x, idx, w8);
+    }
+    if (nb != 0u) {
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) slot[c] = atomicAdd(&s_cnt[(idx[c] - lv.off[level]) >> GB_BIN_LOG2], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < nb) {
+            const uint32_t k = s_cnt[threadIdx.x];
+            s_base[threadIdx.x] = k != 0u ? atomicAdd(&counters[gb.first[level] + threadIdx.x], k) : 0u;
+        }
+        __syncthreads();
+    }
+    if (!act) return;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float2v g = {w8[c] * de0, w8[c] * de1};
+        const half2v gh = __builtin_convertvector(g, half2v);
+        if (nb != 0u) {
+            const uint32_t bin = (idx[c] - lv.off[level]) >> GB_BIN_LOG2;
+            const uint32_t pos = s_base[bin] + slot[c];
+            if (pos < gb.cap) {
+                lists[(size_t)(gb.first[level] + bin) * gb.cap + pos] = make_uint2(idx[c], __builtin_bit_cast(uint32_t, gh));
+                continue;
+            }
+        }
+        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(grad16 + idx[c]), gh);
+    }
+}
+// pass 2: one workgroup per bin; bin_entry0[b] = table entry of the bin's first slot; resets the bin's counter for the next step
+__global__ __launch_bounds__(512) void k_grid_gather(uint32_t* __restrict__ grad16, uint32_t cap, const uint32_t* __restrict__ bin_entry0,
+                                                    uint32_t* __restrict__ counters, const uint2* __restrict__ lists)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    extern __shared__ float s_acc[];      // [GB_BIN][2]
+    const uint32_t b = blockIdx.x;
+    const uint32_t total = counters[b];
+    if (total == 0u) return;              // (workgroup-uniform)
+    for (uint32_t i = threadIdx.x; i < GB_BIN * 2u; i += 512u) s_acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t cnt = total < cap ? total : cap, e0 = bin_entry0[b];
+    const uint2* L = lists + (size_t)b * cap;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 512u) {
+        const uint2 pr = L[i];
+        const half2v h = __builtin_bit_cast(half2v, pr.y);
+        const uint32_t local = (pr.x - e0) & (GB_BIN - 1u);
+        atomicAdd(&s_acc[2u * local], (float)h[0]);
+        atomicAdd(&s_acc[2u * local + 1u], (float)h[1]);
+    }
+    __syncthreads();
+    const bool overflow = total > cap;    // some of the bin's pairs went to the table with atomics: add, do not store
+    for (uint32_t i = threadIdx.x; i < GB_BIN; i += 512u) {
+        const float2v a = {s_acc[2u * i], s_acc[2u * i + 1u]};
+        if (a[0] == 0.0f && a[1] == 0.0f) continue;
+        const half2v gh = __builtin_convertvector(a, half2v);
+        if (overflow) __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(grad16 + e0 + i), gh);
+        else grad16[e0 + i] = __builtin_bit_cast(uint32_t, gh);
+    }
+    if (threadIdx.x == 0u) counters[b] = 0u;
+}
+
 __global__ void k_grid_grad_f32(const uint32_t* __restrict__ grad16, float* __restrict__ grad, uint32_t n_entries)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
@@ -2491,7 +2588,7 @@ Mlp::~Mlp()
     if (d_dst_) dev_free(d_dst_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_tasks_, d_feat_[0], d_feat_[1], d_t16_train_,
-                    d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_};
+                    d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_, d_grid_lists_, d_grid_counters_, d_grid_bin_entry0_};
     for (void* p : ptrs)
         if (p) dev_free(p);
 }
@@ -2853,6 +2950,30 @@ void Mlp::ensure_train_workspace(uint32_t n)
         if (d_denc_) dev_free(d_denc_);
         d_denc_ = nullptr;
         dev_alloc(&d_denc_, (size_t)n * 32 * 2, "d_denc_");
+        // bin lists of the table gradient (k_grid_scatter): levels of at least GB_MIN_BINS bins of 16 384 entries; a list holds twice what a
+        // uniformly hashed level of 32 bins sends a bin (n * 8 / 32 pairs), the rest -- a dense level's crowded bins -- goes on with atomics
+        if (d_grid_lists_) dev_free(d_grid_lists_);
+        d_grid_lists_ = nullptr;
+        grid_bins_total_ = 0;
+        std::vector<uint32_t> entry0;
+        for (uint32_t l = 0; l < HG_LEVELS; l++) {
+            const uint32_t cnt = hg_off_[l + 1] - hg_off_[l];
+            const uint32_t bins = (cnt % GB_BIN == 0u) ? cnt / GB_BIN : 0u;
+            grid_bin_first_[l] = grid_bins_total_;
+            grid_bin_count_[l] = (bins >= GB_MIN_BINS && bins <= GB_MAX_BINS) ? bins : 0u;
+            for (uint32_t b = 0; b < grid_bin_count_[l]; b++) entry0.push_back(hg_off_[l] + b * GB_BIN);
+            grid_bins_total_ += grid_bin_count_[l];
+        }
+        grid_bin_cap_ = std::max(1024u, n / 2u);
+        if (grid_bins_total_ != 0u) {
+            dev_alloc(&d_grid_lists_, (size_t)grid_bins_total_ * grid_bin_cap_ * 8, "d_grid_lists_");
+            if (!d_grid_counters_) {
+                dev_alloc(&d_grid_counters_, (size_t)grid_bins_total_ * 4, "d_grid_counters_");
+                NRC_HIP(hipMemset(d_grid_counters_, 0, (size_t)grid_bins_total_ * 4));
+                dev_alloc(&d_grid_bin_entry0_, entry0.size() * 4, "d_grid_bin_entry0_");
+                NRC_HIP(hipMemcpy(d_grid_bin_entry0_, entry0.data(), entry0.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
     }
     dev_alloc(&d_loss_part_, (size_t)(n / 32) * 4, "d_loss_part_");
     ws_n_ = n;
@@ -3007,6 +3128,20 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
             static const uint32_t skip_levels = getenv("NRC_DIAG_GRID_SKIP_LEVELS") ? (uint32_t)strtoul(getenv("NRC_DIAG_GRID_SKIP_LEVELS"), nullptr, 0) : 0u;
+            if (grid_bins_total_ != 0u && getenv("NRC_GRID_BACKWARD_ATOMICS") == nullptr) {
+                // the large levels through bin lists and LDS accumulators, the coarse ones with atomics (k_grid_scatter / k_grid_gather)
+                GridBins gb;
+                for (uint32_t l = 0; l < HG_LEVELS; l++) { gb.first[l] = grid_bin_first_[l]; gb.count[l] = grid_bin_count_[l]; }
+                gb.cap = grid_bin_cap_;
+                if (!attr_gather_set_) {
+                    NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB_BIN * 8u)));
+                    attr_gather_set_ = true;
+                }
+                hipLaunchKernelGGL(k_grid_scatter, dim3(ceil_div(n, 256), HG_LEVELS), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (uint32_t*)d_grad16_, n, lv,
+                                   gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_, skip_levels);
+                hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_), dim3(512), GB_BIN * 8u, s, (uint32_t*)d_grad16_, grid_bin_cap_,
+                                   (const uint32_t*)d_grid_bin_entry0_, (uint32_t*)d_grid_counters_, (const uint2*)d_grid_lists_);
+            } else
             hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
                                (uint32_t*)d_grad16_, n, lv, skip_levels);
             // the fp32 copy in the gradient vector is for whoever reads the vector (exchange, hook, debug read-back): the

@@ -595,6 +595,36 @@ def test_hashgrid_model_matches_oracle(api, orc, torch_gpu, dir_id, width, depth
     c.Destroy()
 
 
+@pytest.mark.parametrize("log2", [19, 16], ids=["2^19", "2^16"])
+def test_table_gradient_through_bin_lists_equals_the_atomics(api, torch_gpu, monkeypatch, log2):
+    """k_grid_scatter + k_grid_gather (round 4: the pairs of the levels with at least 8 bins of 16 384 entries go to per-bin lists and are
+    summed in fp32 in LDS; the coarse levels and what overflows a list keep the packed-fp16 atomics) against k_grid_backward
+    (NRC_GRID_BACKWARD_ATOMICS=1): the same fp16-rounded products, summed in another order and precision -- within fp16 rounding of each other,
+    on a full batch (every list far from full) and on a batch whose samples sit in one corner of the volume (lists overflow into atomics)"""
+    rng = np.random.default_rng(17)
+    for n, spread in ((16384, 1.0), (8192, 0.02)):
+        xq = queries(n, seed=9, nan_frac=0.0)
+        xq[:, :3] = (xq[:, :3] - 31.0) * spread
+        x = torch_gpu.from_numpy(xq).cuda()
+        t = torch_gpu.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
+        g = {}
+        for atomics in (False, True):
+            if atomics:
+                monkeypatch.setenv("NRC_GRID_BACKWARD_ATOMICS", "1")
+            else:
+                monkeypatch.delenv("NRC_GRID_BACKWARD_ATOMICS", raising=False)
+            c = api.NeuralRadianceCache(api.AppConfig(pos_id=0, dir_id=0, nn_width=64, nn_depth=2, hashgrid_log2_size=log2))
+            c.Backward(x, t)
+            g[atomics] = c.GetParams(4).copy()
+            c.Destroy()
+        nm = c_mlp_params(64, 2, 48)
+        assert np.array_equal(g[False][:nm], g[True][:nm])            # the MLP part does not depend on the table's path
+        tab, ref = g[False][nm:], g[True][nm:]
+        assert np.isfinite(tab).all() and np.abs(tab).max() > 0.0
+        assert np.array_equal(tab != 0.0, ref != 0.0) or rel(tab, ref) < 1e-2      # the same entries are touched ...
+        assert rel(tab, ref) < 1e-2                                  # ... with the same sums up to fp16 rounding of the partial sums
+
+
 @pytest.mark.parametrize("log2", [12, 19], ids=["2^12", "reference-default-2^19"])
 def test_hashgrid_sparse_exchange_lists_add_up_in_rank_order(api, torch_gpu, log2):
     """the multi-GPU exchange of the table gradient on one device: three ranks' backward passes (their shard of the batch against
