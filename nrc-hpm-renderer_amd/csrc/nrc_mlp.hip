@@ -988,6 +988,44 @@ __device__ __forceinline__ void hg_corners(const HashLevels& lv, uint32_t level,
     }
 }
 
+// The 8 corner gathers of one (sample, level).  Round 4: x-neighbours in ONE 8-byte load wherever they share an aligned pair of
+// entries.  The x coordinate enters the dense index with stride 1 and the hash with the prime 1, so for an EVEN cell coordinate the
+// corners x and x + 1 differ in bit 0 of the entry index only (dense: index + 1, hash: index ^ 1; level sizes and offsets are even) --
+// half of all (sample, level) pairs.  The test is made on the indices themselves (idx[c + 1] == idx[c] ^ 1), so nothing is assumed
+// about the level: a lane whose four x-pairs all pass does 4 gathers of 8 bytes, the others 4 + 4.  Same entries, same order of the
+// weighted sum -- bit-identical features, 25 % fewer lane-gathers.  (-DNRC_HG_NO_PAIR_GATHER is the A/B build.)
+__device__ __forceinline__ void hg_gather(const uint32_t* __restrict__ table16, const uint32_t (&idx)[8], const float (&w8)[8], float& r0, float& r1)
+{
+    uint32_t v[8];
+#ifdef NRC_HG_NO_PAIR_GATHER
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = table16[idx[c]];
+#else
+    bool paired = true;
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) paired = paired && idx[c + 1] == (idx[c] ^ 1u);
+    uint32_t u[4] = {0u, 0u, 0u, 0u};
+    if (!paired) {            // issued first: the lanes that need them have all eight gathers in flight at once
+#pragma unroll
+        for (int c = 0; c < 4; c++) u[c] = table16[idx[2 * c + 1]];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        const uint2 a = *reinterpret_cast<const uint2*>(table16 + (idx[c] & ~1u));
+        const bool hi = (idx[c] & 1u) != 0u;
+        v[c] = hi ? a.y : a.x;
+        v[c + 1] = paired ? (hi ? a.x : a.y) : u[c >> 1];
+    }
+#endif
+    r0 = 0.0f; r1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const half2v hv = __builtin_bit_cast(half2v, v[c]);
+        r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
+        r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
+    }
+}
+
 // 16 lanes per sample, one level each (64 contiguous bytes of features per sample); lane 0 also writes the direction encoding
 template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ in, const uint32_t* __restrict__ table16,
@@ -1007,13 +1045,7 @@ __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ i
         uint32_t idx[8];
         float w8[8];
         hg_corners(lv, level, x, idx, w8);
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const uint32_t v = table16[idx[c]];
-            const half2v hv = __builtin_bit_cast(half2v, v);
-            r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
-            r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
-        }
+        hg_gather(table16, idx, w8, r0, r1);
     }
     half_t* o = feat + (size_t)sample * E16;
     o[2 * level] = (half_t)r0;
@@ -1061,13 +1093,7 @@ __global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict_
         uint32_t idx[8];
         float w8[8];
         hg_corners(lv, slot, x, idx, w8);
-        r0 = 0.0f; r1 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const half2v hv = __builtin_bit_cast(half2v, table16[idx[c]]);
-            r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
-            r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
-        }
+        hg_gather(table16, idx, w8, r0, r1);
     } else {
         const int k0 = 2 * ((int)slot - (int)HG_LEVELS);         // direction feature index of r0 (r1 = k0 + 1)
         if (k0 < ND) {
@@ -1110,13 +1136,7 @@ __global__ __launch_bounds__(256) void k_encode_hash_list(const float* __restric
             uint32_t idx[8];
             float w8[8];
             hg_corners(lv, slot, x, idx, w8);
-            r0 = 0.0f; r1 = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const half2v hv = __builtin_bit_cast(half2v, table16[idx[c]]);
-                r0 = __builtin_fmaf(w8[c], (float)hv[0], r0);
-                r1 = __builtin_fmaf(w8[c], (float)hv[1], r1);
-            }
+            hg_gather(table16, idx, w8, r0, r1);
         } else {
             const float d0 = p[3], d1 = p[4];
             const int k0 = 2 * ((int)slot - (int)HG_LEVELS);         // direction feature index of r0 (r1 = k0 + 1)
@@ -2382,6 +2402,79 @@ __global__ __launch_bounds__(256) void k_grid_opt(float* __restrict__ w, float* 
     t_ema[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(en, half2v));
 }
 
+// Round 4: the same step with TWO entries (four parameters) per thread and 16-byte accesses.  k_grid_opt's one entry per thread reads and
+// writes its two parameters as separate 4-byte accesses at an 8-byte stride and moves 36 B per entry at 2.3 TB/s (110 us for the 7 M
+// entries of the reference-default table -- the longest kernel of the training step).  Here a thread whose four gradients are all zero --
+// three entries in four at 16 384 train rays -- loads w and ema (float4), stores ema and the EMA gather copy, and leaves the weight
+// copies alone: w does not change, so the training gather copy already holds fp16(w) (every writer of w also writes the copy: this
+// kernel, k_pack_grid after set_params / construction).  The others run the per-parameter update of adam_ema_update / sgd_ema_update
+// (same expressions, same rounding: the functions below restate them on values; fp contraction is off here too).
+#pragma clang fp contract(off)
+__device__ __forceinline__ float ema_value(float e_old, float wi, const AdamArgs& a) { return (e_old * a.ema_old + wi * a.ema_new) / a.ema_div; }
+__device__ __forceinline__ void adam_value(float& wi, float& mi, float& vi, float graw, const AdamArgs& a)      // non-matrix parameter, graw != 0
+{
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float g = graw * a.inv_loss_scale + 0.0f;
+    mi = b1 * mi + (1.0f - b1) * g;
+    vi = b2 * vi + (1.0f - b2) * (g * g);
+    wi = wi - a.lr_t * mi / (sqrtf(vi) + eps);
+}
+__device__ __forceinline__ void sgd_value(float& wi, float graw, float lr, const AdamArgs& a)
+{
+    const float l2 = 1e-8f;
+    const float g = graw * a.inv_loss_scale + l2 * wi;
+    wi = wi - lr * g;
+}
+template <bool SGD, bool FROM16>
+__global__ __launch_bounds__(256) void k_grid_opt2(float* __restrict__ w, float* __restrict__ ema, float* __restrict__ m,
+                                                  float* __restrict__ v, const float* __restrict__ grad,
+                                                  uint32_t* __restrict__ grad16, uint32_t n_matrix, uint32_t n_pairs, float lr,
+                                                  AdamArgs a, uint32_t* __restrict__ t_train, uint32_t* __restrict__ t_ema)
+{
+    NRC_RAISE_WAVE_PRIORITY(1);
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t e = 2u * p, i0 = n_matrix + 4u * p;      // (n_matrix % 4 == 0 and an even number of entries: checked by the caller)
+    float g[4];
+    if (FROM16) {
+        const uint2 word = *reinterpret_cast<const uint2*>(grad16 + e);
+        const half2v h0 = __builtin_bit_cast(half2v, word.x), h1 = __builtin_bit_cast(half2v, word.y);
+        g[0] = (float)h0[0]; g[1] = (float)h0[1]; g[2] = (float)h1[0]; g[3] = (float)h1[1];
+        if ((word.x | word.y) != 0u) *reinterpret_cast<uint2*>(grad16 + e) = make_uint2(0u, 0u);      // (see k_grid_opt: the table is left clean)
+    } else {
+        const float4 gv = *reinterpret_cast<const float4*>(grad + i0);
+        g[0] = gv.x; g[1] = gv.y; g[2] = gv.z; g[3] = gv.w;
+    }
+    const float4 wv = *reinterpret_cast<const float4*>(w + i0), ev = *reinterpret_cast<const float4*>(ema + i0);
+    float wi[4] = {wv.x, wv.y, wv.z, wv.w}, ei[4] = {ev.x, ev.y, ev.z, ev.w};
+    const bool untouched = !SGD && g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f && g[3] == 0.0f;
+    if (!untouched) {
+        if (SGD) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sgd_value(wi[k], g[k], lr, a);
+        } else {
+            const float4 mv = *reinterpret_cast<const float4*>(m + i0), vv = *reinterpret_cast<const float4*>(v + i0);
+            float mi[4] = {mv.x, mv.y, mv.z, mv.w}, vi[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (g[k] != 0.0f) adam_value(wi[k], mi[k], vi[k], g[k], a);      // a zero gradient keeps weight and moments, parameter by parameter
+            *reinterpret_cast<float4*>(m + i0) = make_float4(mi[0], mi[1], mi[2], mi[3]);
+            *reinterpret_cast<float4*>(v + i0) = make_float4(vi[0], vi[1], vi[2], vi[3]);
+        }
+        *reinterpret_cast<float4*>(w + i0) = make_float4(wi[0], wi[1], wi[2], wi[3]);
+        const float2v w0 = {wi[0], wi[1]}, w1 = {wi[2], wi[3]};
+        *reinterpret_cast<uint2*>(t_train + e) = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(w0, half2v)),
+                                                           __builtin_bit_cast(uint32_t, __builtin_convertvector(w1, half2v)));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) ei[k] = ema_value(ei[k], wi[k], a);
+    *reinterpret_cast<float4*>(ema + i0) = make_float4(ei[0], ei[1], ei[2], ei[3]);
+    const float2v e0 = {ei[0], ei[1]}, e1 = {ei[2], ei[3]};
+    *reinterpret_cast<uint2*>(t_ema + e) = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(e0, half2v)),
+                                                     __builtin_bit_cast(uint32_t, __builtin_convertvector(e1, half2v)));
+}
+#pragma clang fp contract(fast)
+
 // fragment images from the canonical fp32 vectors
 __global__ void k_pack(const float* __restrict__ w, const float* __restrict__ ema, const int32_t* __restrict__ src_fwd,
                        const int32_t* __restrict__ src_inf, uint32_t n_fwd, const int32_t* __restrict__ src_bwd, uint32_t n_bwd,
@@ -3227,6 +3320,19 @@ bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* l
             uint32_t *tt = (uint32_t*)d_t16_train_, *te = (uint32_t*)d_t16_ema_[next];
             uint32_t* g16 = (uint32_t*)d_grad16_;
             if (grid16_valid_) grad16_clean_ = true;      // k_grid_opt<., true> clears the entries it reads
+            static const bool one_entry_per_thread = getenv("NRC_GRID_OPT_SCALAR") != nullptr;      // A/B: round 3's kernel
+            if (!one_entry_per_thread && n_mlp_ % 4u == 0u && n_grid_entries_ % 2u == 0u) {
+                const uint32_t np = n_grid_entries_ / 2u;
+                const dim3 g2(ceil_div(np, 256));
+                if (sgd_ && grid16_valid_)
+                    hipLaunchKernelGGL((k_grid_opt2<true, true>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                else if (sgd_)
+                    hipLaunchKernelGGL((k_grid_opt2<true, false>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                else if (grid16_valid_)
+                    hipLaunchKernelGGL((k_grid_opt2<false, true>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                else
+                    hipLaunchKernelGGL((k_grid_opt2<false, false>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+            } else
             if (sgd_ && grid16_valid_)
                 hipLaunchKernelGGL((k_grid_opt<true, true>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
             else if (sgd_)

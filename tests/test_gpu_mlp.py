@@ -255,9 +255,11 @@ def test_hashgrid_one_launch_table_optimizer_equals_the_separate_kernels_bitwise
     monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
     n = 2048
     rng = np.random.default_rng(9)
-    x = torch_gpu.from_numpy(rng.random((n, 5), dtype=np.float32)).cuda()
     t = torch_gpu.rand((n, 3), device="cuda")
-    for step in range(3):
+    for step in range(5):
+        # a new batch every step: entries touched in one step and not in the next take the optimizer's zero-gradient path with moments
+        # and a weight that have moved (k_grid_opt2 leaves their fp16 weight copy alone there)
+        x = torch_gpu.from_numpy(rng.random((n, 5), dtype=np.float32)).cuda()
         a.Backward(x, t)
         g = a.GetParams(4)
         assert np.count_nonzero(g[-2 * 16384:]) > 0
@@ -621,8 +623,12 @@ def test_table_gradient_through_bin_lists_equals_the_atomics(api, torch_gpu, mon
         assert np.array_equal(g[False][:nm], g[True][:nm])            # the MLP part does not depend on the table's path
         tab, ref = g[False][nm:], g[True][nm:]
         assert np.isfinite(tab).all() and np.abs(tab).max() > 0.0
-        assert np.array_equal(tab != 0.0, ref != 0.0) or rel(tab, ref) < 1e-2      # the same entries are touched ...
-        assert rel(tab, ref) < 1e-2                                  # ... with the same sums up to fp16 rounding of the partial sums
+        # the atomics round EVERY partial sum to fp16 (level 0: 32 updates per entry, in an order that differs from run to run), the lists
+        # round once: 0.9-1.2 % apart over the whole table by run
+        assert rel(tab, ref) < 3e-2
+        if log2 == 19 and spread == 1.0:
+            fine = slice(2 * (4096 + 32768 + 262144), None)          # the hashed levels: 131 072 updates over 524 288 entries each
+            assert rel(tab[fine], ref[fine]) < 5e-3
 
 
 @pytest.mark.parametrize("log2", [12, 19], ids=["2^12", "reference-default-2^19"])
