@@ -1193,7 +1193,13 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
 // a bin's pairs into 128 KB of fp32 accumulators in LDS and stores the entries that were touched.  The coarse levels (fewer than 8 bins)
 // and whatever does not fit a bin's list keep the atomics.  Values are the same fp16-rounded products; they are summed in fp32 and
 // rounded once (the atomics round every partial sum to fp16).
-constexpr uint32_t GB_BIN_LOG2 = 14, GB_BIN = 1u << GB_BIN_LOG2, GB_MAX_BINS = 64, GB_MIN_BINS = 8;
+#ifndef NRC_GB_BIN_LOG2
+#define NRC_GB_BIN_LOG2 12
+#endif
+#ifndef NRC_GB_GATHER_THREADS
+#define NRC_GB_GATHER_THREADS 512
+#endif
+constexpr uint32_t GB_BIN_LOG2 = NRC_GB_BIN_LOG2, GB_BIN = 1u << GB_BIN_LOG2, GB_MAX_BINS = 1u << (20 - NRC_GB_BIN_LOG2), GB_MIN_BINS = 8;
 struct GridBins {
     uint32_t first[HG_LEVELS], count[HG_LEVELS];      // per level: index of its first bin, number of bins (0: the level keeps the atomics)
     uint32_t cap;                                     // pairs a bin's list holds
@@ -1251,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ 
     }
 }
 // pass 2: one workgroup per bin; bin_entry0[b] = table entry of the bin's first slot; resets the bin's counter for the next step
-__global__ __launch_bounds__(512) void k_grid_gather(uint32_t* __restrict__ grad16, uint32_t cap, const uint32_t* __restrict__ bin_entry0,
+__global__ __launch_bounds__(NRC_GB_GATHER_THREADS) void k_grid_gather(uint32_t* __restrict__ grad16, uint32_t cap, const uint32_t* __restrict__ bin_entry0,
                                                     uint32_t* __restrict__ counters, const uint2* __restrict__ lists)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
@@ -1259,11 +1265,11 @@ __global__ __launch_bounds__(512) void k_grid_gather(uint32_t* __restrict__ grad
     const uint32_t b = blockIdx.x;
     const uint32_t total = counters[b];
     if (total == 0u) return;              // (workgroup-uniform)
-    for (uint32_t i = threadIdx.x; i < GB_BIN * 2u; i += 512u) s_acc[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < GB_BIN * 2u; i += (uint32_t)NRC_GB_GATHER_THREADS) s_acc[i] = 0.0f;
     __syncthreads();
     const uint32_t cnt = total < cap ? total : cap, e0 = bin_entry0[b];
     const uint2* L = lists + (size_t)b * cap;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 512u) {
+    for (uint32_t i = threadIdx.x; i < cnt; i += (uint32_t)NRC_GB_GATHER_THREADS) {
         const uint2 pr = L[i];
         const half2v h = __builtin_bit_cast(half2v, pr.y);
         const uint32_t local = (pr.x - e0) & (GB_BIN - 1u);
@@ -1272,7 +1278,7 @@ __global__ __launch_bounds__(512) void k_grid_gather(uint32_t* __restrict__ grad
     }
     __syncthreads();
     const bool overflow = total > cap;    // some of the bin's pairs went to the table with atomics: add, do not store
-    for (uint32_t i = threadIdx.x; i < GB_BIN; i += 512u) {
+    for (uint32_t i = threadIdx.x; i < GB_BIN; i += (uint32_t)NRC_GB_GATHER_THREADS) {
         const float2v a = {s_acc[2u * i], s_acc[2u * i + 1u]};
         if (a[0] == 0.0f && a[1] == 0.0f) continue;
         const half2v gh = __builtin_convertvector(a, half2v);
@@ -3057,7 +3063,7 @@ void Mlp::ensure_train_workspace(uint32_t n)
             for (uint32_t b = 0; b < grid_bin_count_[l]; b++) entry0.push_back(hg_off_[l] + b * GB_BIN);
             grid_bins_total_ += grid_bin_count_[l];
         }
-        grid_bin_cap_ = std::max(1024u, n / 2u);
+        grid_bin_cap_ = std::max(1024u, n / (GB_MAX_BINS / 32u));      // twice the mean of a uniformly hashed level of 2^19 entries
         if (grid_bins_total_ != 0u) {
             dev_alloc(&d_grid_lists_, (size_t)grid_bins_total_ * grid_bin_cap_ * 8, "d_grid_lists_");
             if (!d_grid_counters_) {
@@ -3232,7 +3238,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
                 }
                 hipLaunchKernelGGL(k_grid_scatter, dim3(ceil_div(n, 256), HG_LEVELS), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (uint32_t*)d_grad16_, n, lv,
                                    gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_, skip_levels);
-                hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_), dim3(512), GB_BIN * 8u, s, (uint32_t*)d_grad16_, grid_bin_cap_,
+                hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_), dim3(NRC_GB_GATHER_THREADS), GB_BIN * 8u, s, (uint32_t*)d_grad16_, grid_bin_cap_,
                                    (const uint32_t*)d_grid_bin_entry0_, (uint32_t*)d_grid_counters_, (const uint2*)d_grid_lists_);
             } else
             hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
