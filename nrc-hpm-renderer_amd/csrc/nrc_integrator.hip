@@ -2383,7 +2383,7 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
     if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     DevFrame fa = fr;
-    fa.raise_priority = (uint32_t)g_host_raise_wave_priority;
+    fa.raise_priority = (g_host_raise_wave_priority != 0 && fr.camera_priority_low == 0u) ? 1u : 0u;
     hipLaunchKernelGGL(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fa,
                        primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
                        fetch_counter, tg, full_vertex_images ? 1 : 0);
@@ -2436,7 +2436,7 @@ void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& 
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
     if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     DevFrame fa = fr;
-    fa.raise_priority = (uint32_t)g_host_raise_wave_priority;
+    fa.raise_priority = (g_host_raise_wave_priority != 0 && fr.camera_priority_low == 0u) ? 1u : 0u;
     hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,
                        cam, fa, path_length, blend_factor, (float4*)out_rgba, info, fetch_counter);
     NRC_HIP(hipGetLastError());

@@ -86,6 +86,9 @@ struct DevFrame {
     // nrc_common.hpp's run-time priority switch as a kernel argument of the camera kernels (set by their launchers): their 32 400 waves
     // would each pay two dependent scalar loads for the device-side copy (0.7 % of a launch)
     uint32_t raise_priority;
+    // set by the renderer, read by the launchers only: 1 = this renderer's camera kernels stay at the default wave priority although the
+    // library raises (they then yield issue slots to the inference / training kernels beside them; Renderer::camera_priority_low_)
+    uint32_t camera_priority_low;
     // the queries of pixels that did not scatter are not written (nobody reads them: the inference walks live_list and encodes inside its
     // kernel or from the list).  0: every slot of the query buffer is written, dead pixels with zeros (the reference's zero-filled buffer)
     uint32_t skip_dead_queries;
