@@ -1033,8 +1033,17 @@ __global__ __launch_bounds__(256) void k_encode_hash(const float* __restrict__ i
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int ND = DIR == 1 ? 2 : 8, E16 = 48;
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t sample = gid >> 4, level = gid & 15u;
+    // skip_zero & 2 (round 4): a level's table is gathered from ONE XCD -- workgroup b (on XCD b & 7) takes the levels (b & 7) and (b & 7) + 8
+    // of 128 samples (see k_encode_hash_list); otherwise 16 lanes per sample, one level each
+    uint32_t sample, level;
+    if (skip_zero & 2) {
+        sample = (blockIdx.x >> 3) * 128u + (threadIdx.x >> 1);
+        level = (blockIdx.x & 7u) + 8u * (threadIdx.x & 1u);
+    } else {
+        const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+        sample = gid >> 4; level = gid & 15u;
+    }
+    skip_zero &= 1;
     if (sample >= n) return;
     const float* p = in + (size_t)sample * 5u;
     const float x[3] = {p[0], p[1], p[2]};
@@ -1120,13 +1129,27 @@ __global__ __launch_bounds__(256) void k_encode_hash_lm(const float* __restrict_
 template <int DIR>
 __global__ __launch_bounds__(256) void k_encode_hash_list(const float* __restrict__ in, const uint32_t* __restrict__ table16,
                                                          uint32_t* __restrict__ feat_lm, uint32_t n, HashLevels lv,
-                                                         const uint32_t* __restrict__ live_list, const uint32_t* __restrict__ live_count)
+                                                         const uint32_t* __restrict__ live_list, const uint32_t* __restrict__ live_count,
+                                                         uint32_t xcd_chunks)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int ND = DIR == 1 ? 2 : 8;
-    const uint32_t slot = blockIdx.y;
+    // Which (slot, chunk of the list) a workgroup takes.  gridDim.y == 1 (round 4): a level's table is gathered from ONE XCD.  Workgroups are
+    // dealt to the eight XCDs round-robin by their linear index, so workgroup b runs on XCD b & 7; it takes the slots x, x + 8, x + 16, ... of
+    // its XCD x in turn (b >> 3 = chunk + chunks * turn): every XCD's L2 then holds the one or two 2 MB tables of its own levels for the whole
+    // launch instead of all sixteen one after the other (28 MB through each of the eight 4 MB L2s per frame, evicting the volume gen_rays
+    // reads beside it).  gridDim.y == n_slots: the level-major order of the dense variant above (every XCD gathers from every level).
+    uint32_t slot, chunk, chunks;
+    if (gridDim.y == 1u) {
+        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        chunks = xcd_chunks;
+        slot = xcd + 8u * (k / chunks);
+        chunk = k % chunks;
+    } else {
+        slot = blockIdx.y; chunk = blockIdx.x; chunks = gridDim.x;
+    }
     const uint32_t count = min(*live_count, n);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+    for (uint32_t i = chunk * 256u + threadIdx.x; i < count; i += chunks * 256u) {
         const uint32_t sample = live_list[i];
         if (sample >= n) continue;           // (a list of another launch: never written here)
         const float* p = in + (size_t)sample * 5u;
@@ -1210,7 +1233,16 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ 
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     __shared__ uint32_t s_cnt[GB_MAX_BINS], s_base[GB_MAX_BINS];
-    const uint32_t level = blockIdx.y, sample = blockIdx.x * 256u + threadIdx.x;
+    // gridDim.y == 1: a level's lists are appended to from ONE XCD (workgroup b runs on XCD b & 7 and takes level (b & 7) + 8 * turn, see
+    // k_encode_hash_list): the partial lines of a list's neighbouring runs meet in one L2
+    uint32_t level, sample;
+    if (gridDim.y == 1u) {
+        const uint32_t k = blockIdx.x >> 3, chunks = gridDim.x / HG_LEVELS;
+        level = (blockIdx.x & 7u) + 8u * (k / chunks);
+        sample = (k % chunks) * 256u + threadIdx.x;
+    } else {
+        level = blockIdx.y; sample = blockIdx.x * 256u + threadIdx.x;
+    }
     const uint32_t nb = gb.count[level];              // (workgroup-uniform)
     if (threadIdx.x < GB_MAX_BINS) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
@@ -2736,10 +2768,17 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
     for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
     const uint32_t* tab = (const uint32_t*)(use_ema ? d_t16_ema_[infer_set_] : d_t16_train_);
     if (slot == 0 && live_list != nullptr && skip_zero) {      // renderer inference with the frame's live-query list
-        const dim3 g((uint32_t)num_cus() * 2u, enc_dims_ / 2);
-        if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash_list<0>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count);
-        else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash_list<1>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count);
-        else hipLaunchKernelGGL(k_encode_hash_list<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count);
+        const uint32_t n_slots = enc_dims_ / 2;
+        dim3 g((uint32_t)num_cus() * 2u, n_slots);
+        uint32_t xc = 0;
+        static const bool level_major = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD gathers from every level
+        if (!level_major && n_slots % 8u == 0u) {      // a level's table is gathered from one XCD (see the kernel)
+            xc = (uint32_t)num_cus() * 2u;               // chunks of the list per slot: as many workgroups per slot as before
+            g = dim3(8u * xc * (n_slots / 8u), 1);
+        }
+        if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash_list<0>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count, xc);
+        else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash_list<1>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count, xc);
+        else hipLaunchKernelGGL(k_encode_hash_list<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, live_list, live_count, xc);
         return;
     }
     if (slot == 0) {         // inference: level-major gathers and feature layout (k_encode_hash_lm / k_infer_gen<..., true>)
@@ -2750,10 +2789,12 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
         else hipLaunchKernelGGL(k_encode_hash_lm<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, sk);
         return;
     }
-    const dim3 g(ceil_div(n * 16u, 256));
-    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
-    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
-    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, skip_zero ? 1 : 0);
+    static const bool level_major2 = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;
+    const dim3 g(level_major2 ? ceil_div(n * 16u, 256) : ceil_div(n, 128) * 8u);
+    const int mode = (skip_zero ? 1 : 0) | (level_major2 ? 0 : 2);
+    if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, mode);
+    else if (cfg_.dir_id == 1) hipLaunchKernelGGL(k_encode_hash<1>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, mode);
+    else hipLaunchKernelGGL(k_encode_hash<2>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, mode);
 }
 
 // this translation unit's copy of the run-time priority switch (nrc_common.hpp)
@@ -3236,7 +3277,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
                     NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB_BIN * 8u)));
                     attr_gather_set_ = true;
                 }
-                hipLaunchKernelGGL(k_grid_scatter, dim3(ceil_div(n, 256), HG_LEVELS), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (uint32_t*)d_grad16_, n, lv,
+                static const bool level_major = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD works on every level
+                hipLaunchKernelGGL(k_grid_scatter, level_major ? dim3(ceil_div(n, 256), HG_LEVELS) : dim3(ceil_div(n, 256) * HG_LEVELS, 1), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (uint32_t*)d_grad16_, n, lv,
                                    gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_, skip_levels);
                 hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_), dim3(NRC_GB_GATHER_THREADS), GB_BIN * 8u, s, (uint32_t*)d_grad16_, grid_bin_cap_,
                                    (const uint32_t*)d_grid_bin_entry0_, (uint32_t*)d_grid_counters_, (const uint2*)d_grid_lists_);
