@@ -1929,6 +1929,36 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
     for (uint32_t i = n + n_split + tid; i < n + split_max; i += 1024u) order[i] = kOrderNone;
 }
 
+// XCD-aware finish of the order (round 4; xcd_row_len = slots per tile row).  The hardware deals workgroups to the eight XCDs round-robin, so
+// the 32 M consecutive ranks of workgroups 8 M j .. 8 M (j + 1) - 1 -- tiles of about the same cost -- start together, 4 M on each XCD.  Within
+// such a window the tiles are handed out by SCREEN ROW: the 4 M topmost to the first XCD, the next to the second, ...  Every XCD then works
+// on a band of rows -- in whatever class of cost the launch is at -- and the volume's [z][y][x] lines its camera rays touch are its own: each
+// 4 MB L2 sees a part of the volume instead of all of it.  The order stays a permutation, costliest first.  wg_off = the workgroups in
+// front of the ordered ones (the hot tiles' two).  A kernel of its own because k_tile_order is ONE workgroup.
+__global__ __launch_bounds__(1024) void k_tile_order_xcd(uint32_t* __restrict__ order, uint32_t n, uint32_t xcd_row_len, uint32_t wg_off)
+{
+    NRC_RAISE_WAVE_PRIORITY(16);
+    // one workgroup per window of blockDim.x = 32 M ranks (M workgroups per XCD); a window that is not whole (the first one behind the hot
+    // tiles' workgroups, the last one) keeps its order
+    __shared__ uint32_t keys[1024];
+    const uint32_t S = blockDim.x, m4 = S >> 3;                // ranks per XCD and window
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tiles_y = n / xcd_row_len, mid = tiles_y >> 1;
+    const long long r0 = (long long)blockIdx.x * S - (long long)wg_off * 4;      // rank of the window's first slot
+    if (r0 < 0 || (unsigned long long)r0 + S > n) return;      // (workgroup-uniform)
+    const uint32_t t = order[(uint32_t)r0 + tid];
+    const uint32_t k = t / xcd_row_len, j = t - k * xcd_row_len;
+    const uint32_t ty = (k & 1u) ? mid - ((k + 1u) >> 1) : mid + (k >> 1);      // pixel_of_launch_slot's row bijection
+    const uint32_t key = (ty << 16) | j;                       // unique per tile
+    keys[tid] = key;
+    __syncthreads();
+    uint32_t pos = 0u;
+    for (uint32_t q = 0; q < S; q++) pos += keys[q] < key ? 1u : 0u;
+    // position pos of the window's tiles by screen row -> XCD pos / m4, its (pos % m4)-th slot: workgroup xcd + 8 * (slot / 4) of the window
+    const uint32_t xcd = pos / m4, q = pos - xcd * m4;
+    order[(uint32_t)r0 + ((xcd + 8u * (q >> 2)) << 2) + (q & 3u)] = t;
+}
+
 // ------------------------------------------------------------------------------------------------ empty-space tile mask
 // One thread per occupancy box (world-space AABB around a run of non-empty 8^3-voxel cells, grown by one voxel): its eight
 // corners are projected with the camera's forward transform; the screen rectangle around them, grown by a pixel, covers every
@@ -2399,10 +2429,15 @@ void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s)
 uint32_t camera_slots(uint32_t w, uint32_t h) { return camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK * ceil_div(h, 8); }
 
 void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, uint32_t split_max,
-                       uint32_t split_min_cycles, hipStream_t s)
+                       uint32_t split_min_cycles, hipStream_t s, uint32_t xcd_window, uint32_t workgroups_in_front)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order, neighbours ? camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK : 0u,
+    const uint32_t row_len = camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order, neighbours ? row_len : 0u,
                        split_max, split_min_cycles >> 9);
+    if (xcd_window != 0u && split_max == 0u && CAMERA_WAVES_PER_BLOCK == 4u && n_slots % row_len == 0u) {
+        const uint32_t S = 32u * std::min(32u, xcd_window);
+        hipLaunchKernelGGL(k_tile_order_xcd, dim3((n_slots + workgroups_in_front * 4u + S - 1u) / S), dim3(S), 0, s, order, n_slots, row_len, workgroups_in_front);
+    }
     NRC_HIP(hipGetLastError());
 }
 

@@ -131,8 +131,10 @@ void launch_flight_select(const float* table, float lambda, uint32_t* count_and_
 uint32_t camera_slots(uint32_t w, uint32_t h);
 // split_max: at most that many of the costliest tiles (cost >= split_min_cycles) are listed as two half tiles; `order` holds
 // n_slots + split_max entries
+// xcd_window = M > 0: inside every window of 32 M consecutive ranks (8 M workgroups that start together, M per XCD) the tiles are handed to the
+// XCDs by screen row (k_tile_order_xcd); workgroups_in_front: workgroups the launch puts in front of the ordered ones (the hot tiles')
 void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, uint32_t split_max,
-                       uint32_t split_min_cycles, hipStream_t s);
+                       uint32_t split_min_cycles, hipStream_t s, uint32_t xcd_window = 0, uint32_t workgroups_in_front = 0);
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);

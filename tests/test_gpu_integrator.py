@@ -1029,6 +1029,19 @@ def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc,
     rank = np.empty(n, np.int64)
     rank[order] = np.arange(n)
     assert rank[scat].mean() < 0.5 * rank[~scat].mean()
+    # XCD-aware finish (k_tile_order_xcd, round 4): behind the two workgroups of the hot tiles, every whole window of 64 ranks (a 16^3
+    # volume: M = 2, sixteen workgroups, two per XCD) hands its tiles to the XCDs by screen row -- XCD x (workgroups x and x + 8 of the
+    # window) holds positions 8 x .. 8 x + 7 of the window's tiles sorted by (row, slot in the row)
+    k_of = order // (row_blocks * 4)
+    ty_of = np.where(k_of & 1, tiles_y // 2 - (k_of + 1) // 2, tiles_y // 2 + k_of // 2)
+    key = ty_of.astype(np.int64) * 65536 + order % (row_blocks * 4)
+    whole = 0
+    for r0 in range(64 - 8, n - 64 + 1, 64):
+        win = key[r0:r0 + 64].reshape(16, 4)                       # [workgroup of the window][wave]
+        by_xcd = np.concatenate([np.concatenate([win[x], win[x + 8]]) for x in range(8)])
+        assert np.all(np.diff(by_xcd) > 0), r0
+        whole += 1
+    assert whole >= (n - 64) // 64 - 1
     # the MC renderer orders its launch the same way (one stream: the sort follows the sampled frame)
     imgs = {}
     for on in (True, False):
