@@ -3031,7 +3031,12 @@ void Mlp::infer_diagnostic(int abl, uint32_t blocks, size_t lds, hipStream_t s, 
 void Mlp::build_wgrad_tasks()
 {
     if (d_tasks_) return;
-    wgrad_old_ = getenv("NRC_WGRAD_OLD") != nullptr;
+    // Which weight-gradient kernel (and, in backward(), which generic fwd/bwd kernel): round 4's k_wgrad2 / k_train_gen2 are the faster
+    // ones alone at every width (8x128: 138 -> 64 us per step) and what the 128-wide frame needs (configs[4] 6 850 against 5 750 Msamples/s
+    // with round 3's pair); beside gen_rays the 64-wide models run better with round 3's k_wgrad / k_train_gen -- fewer, lighter workgroups
+    // (default preset + 0.7 %, HashGrid + 3.2 %, TriangleWave 64 + 2.5 %, A/B on one box).  The renderer's frame is what the library is
+    // for: round 3's kernels up to 64 neurons, round 4's for 128.  NRC_WGRAD_OLD / NRC_TRAIN_GEN_OLD = 0 | 1 override.
+    wgrad_old_ = getenv("NRC_WGRAD_OLD") ? atoi(getenv("NRC_WGRAD_OLD")) != 0 : kw_ <= 64;
     std::vector<WgradTask> tasks;
     const uint32_t D = depth_;
     for (uint32_t l = 0; l <= D; l++) {
@@ -3220,10 +3225,10 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             attr_train_set_ = true;
         }
         const uint4 *fw = (const uint4*)d_pk_fwd_, *bw = (const uint4*)d_pk_bwd_;
-        // round 4: rows split over the waves (k_train_gen2); NRC_TRAIN_GEN_OLD=1 keeps k_train_gen, NRC_TRAIN_GEN_NT=1|2 sets the tiles
+        // round 4: rows split over the waves (k_train_gen2); NRC_TRAIN_GEN_OLD=0|1 picks k_train_gen2 / k_train_gen, NRC_TRAIN_GEN_NT=1|2 sets the tiles
         // per sample group
         // (the environment is read per call: a test compares the kernels inside one process)
-        const bool gen_old = getenv("NRC_TRAIN_GEN_OLD") != nullptr;
+        const bool gen_old = getenv("NRC_TRAIN_GEN_OLD") ? atoi(getenv("NRC_TRAIN_GEN_OLD")) != 0 : kw_ <= 64;      // (see build_wgrad_tasks)
         const int gen_nt_env = getenv("NRC_TRAIN_GEN_NT") ? atoi(getenv("NRC_TRAIN_GEN_NT")) : 0;
         if (!gen_old) {
             const uint32_t sgn = 4u / (uint32_t)mtg;                 // sample groups per workgroup

@@ -130,7 +130,7 @@ private:
     int n_wgrad_tiles_ = 0;
     void* d_tasks_ = nullptr;    // WgradTask[] (row-block tasks of k_wgrad2)
     int n_wgrad_tasks_ = 0;
-    bool wgrad_old_ = false;     // NRC_WGRAD_OLD: round 3's k_wgrad (A/B)
+    bool wgrad_old_ = false;     // round 3's k_wgrad (up to 64 neurons; NRC_WGRAD_OLD=0|1)
     void build_wgrad_tasks();
     uint32_t wgrad_chunk(uint32_t n);
 };

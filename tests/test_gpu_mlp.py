@@ -462,6 +462,7 @@ def test_training_kernels_agree(api, torch_gpu, monkeypatch, pos_id, dir_id, wid
             if mode == "old":
                 monkeypatch.setenv("NRC_TRAIN_GEN_OLD", "1")
             else:
+                monkeypatch.setenv("NRC_TRAIN_GEN_OLD", "0")      # (unset: k_train_gen up to 64 neurons, k_train_gen2 for 128)
                 monkeypatch.setenv("NRC_TRAIN_GEN_NT", mode)
             c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth, hashgrid_log2_size=hg))
             c.Backward(x, t)
@@ -495,10 +496,7 @@ def test_weight_gradient_kernels_agree_at_full_batch(api, torch_gpu, monkeypatch
         x = torch_gpu.from_numpy(queries(n, seed=3, nan_frac=0.0)).cuda()
         t = torch_gpu.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
         for old in (False, True):
-            if old:
-                monkeypatch.setenv("NRC_WGRAD_OLD", "1")
-            else:
-                monkeypatch.delenv("NRC_WGRAD_OLD", raising=False)
+            monkeypatch.setenv("NRC_WGRAD_OLD", "1" if old else "0")      # (unset: k_wgrad up to 64 neurons, k_wgrad2 for 128)
             c = api.NeuralRadianceCache(api.AppConfig(nn_width=width, nn_depth=depth))
             c.Backward(x, t)
             grads[old] = c.GetParams(4).copy()
