@@ -1210,12 +1210,13 @@ __global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__
 
 // ---- round 4: the table gradient of the large levels without memory-side atomics (k_grid_scatter + k_grid_gather).
 // k_grid_backward's 2.1 M packed-fp16 atomics per step execute at the memory side -- 112 us alone, and beside the frame they cost it 41 %
-// (NRC_DIAG_GRID_SKIP_LEVELS=0xffff: 3 060 -> 4 320 Msamples/s; gen_rays 0.62 -> 0.46 ms).  A level of at least 8 x 16 384 entries is cut
-// into BINS of 16 384 entries: pass 1 (one level and 256 samples per workgroup) appends its (entry, value) pairs to the level's bin
-// lists -- a per-workgroup LDS histogram, ONE global atomic per (workgroup, bin) to reserve the run --, pass 2 (one workgroup per bin) adds
-// a bin's pairs into 128 KB of fp32 accumulators in LDS and stores the entries that were touched.  The coarse levels (fewer than 8 bins)
-// and whatever does not fit a bin's list keep the atomics.  Values are the same fp16-rounded products; they are summed in fp32 and
-// rounded once (the atomics round every partial sum to fp16).
+// (NRC_DIAG_GRID_SKIP_LEVELS=0xffff: 3 060 -> 4 320 Msamples/s; gen_rays 0.62 -> 0.46 ms).  A level of at least 8 x 4 096 entries is cut
+// into BINS of 4 096 entries: pass 1 (one level and 256 samples per workgroup) appends its (entry, value) pairs to the level's bin
+// lists -- a per-workgroup LDS histogram, ONE global atomic per (workgroup, non-empty bin) to reserve the run --, pass 2 (one workgroup per
+// bin) adds a bin's pairs into 32 KB of fp32 accumulators in LDS and stores the entries that were touched.  The coarse levels (fewer than 8
+// bins) and whatever does not fit a bin's list keep the atomics.  Values are the same fp16-rounded products; they are summed in fp32 and
+// rounded once (the atomics round every partial sum to fp16).  The bin size is a residency matter: with bins of 16 384 entries (128 KB of
+// LDS per gather workgroup) the frame gained 2.6 %, with 4 096 another 6 % -- the workgroups find room on CUs that gen_rays occupies.
 #ifndef NRC_GB_BIN_LOG2
 #define NRC_GB_BIN_LOG2 12
 #endif
@@ -3095,8 +3096,8 @@ void Mlp::ensure_train_workspace(uint32_t n)
         if (d_denc_) dev_free(d_denc_);
         d_denc_ = nullptr;
         dev_alloc(&d_denc_, (size_t)n * 32 * 2, "d_denc_");
-        // bin lists of the table gradient (k_grid_scatter): levels of at least GB_MIN_BINS bins of 16 384 entries; a list holds twice what a
-        // uniformly hashed level of 32 bins sends a bin (n * 8 / 32 pairs), the rest -- a dense level's crowded bins -- goes on with atomics
+        // bin lists of the table gradient (k_grid_scatter): levels of at least GB_MIN_BINS bins of GB_BIN entries; a list holds twice what a
+        // uniformly hashed level of 2^19 entries sends a bin (n * 8 / 128 pairs), the rest -- a dense level's crowded bins -- goes on with atomics
         if (d_grid_lists_) dev_free(d_grid_lists_);
         d_grid_lists_ = nullptr;
         grid_bins_total_ = 0;

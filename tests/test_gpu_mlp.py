@@ -597,7 +597,7 @@ def test_hashgrid_model_matches_oracle(api, orc, torch_gpu, dir_id, width, depth
 
 @pytest.mark.parametrize("log2", [19, 16], ids=["2^19", "2^16"])
 def test_table_gradient_through_bin_lists_equals_the_atomics(api, torch_gpu, monkeypatch, log2):
-    """k_grid_scatter + k_grid_gather (round 4: the pairs of the levels with at least 8 bins of 16 384 entries go to per-bin lists and are
+    """k_grid_scatter + k_grid_gather (round 4: the pairs of the levels with at least 8 bins of 4 096 entries go to per-bin lists and are
     summed in fp32 in LDS; the coarse levels and what overflows a list keep the packed-fp16 atomics) against k_grid_backward
     (NRC_GRID_BACKWARD_ATOMICS=1): the same fp16-rounded products, summed in another order and precision -- within fp16 rounding of each other,
     on a full batch (every list far from full) and on a batch whose samples sit in one corner of the volume (lists overflow into atomics)"""
