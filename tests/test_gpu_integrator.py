@@ -467,6 +467,42 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
         assert np.array_equal(base[4].view(np.uint32), other[4].view(np.uint32))
 
 
+def test_scheduling_choices_of_the_wide_models_change_no_pixel(api, sc, cloud16, torch_gpu, monkeypatch):
+    """what a 128-wide dense model's renderer does differently (end of round 4) is scheduling only: camera kernels at the default wave
+    priority under the library's other kernels (NRC_CAMERA_PRIORITY_LOW), three frames between a cost sample and the launch order made of
+    it (NRC_COST_ORDER_LAG), the XCD-aware finish of that order (NRC_NO_XCD_ROWS / NRC_XCD_WINDOW), round 4's training kernels
+    (NRC_TRAIN_GEN_OLD / NRC_WGRAD_OLD = 1: round 3's) -- after 10 trained, blended frames the framebuffer, the loss and the parameters are
+    the same bit for bit whichever way they are set (the weight-gradient kernels differ in their chunk sums: not toggled here)"""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    frs = sc.frame_randoms(10, seed=33)
+    switches = ("NRC_CAMERA_PRIORITY_LOW", "NRC_COST_ORDER_LAG", "NRC_NO_XCD_ROWS", "NRC_XCD_WINDOW", "NRC_TRAIN_GEN_OLD")
+    results = []
+    for env in ({}, {"NRC_CAMERA_PRIORITY_LOW": "0"}, {"NRC_COST_ORDER_LAG": "2"}, {"NRC_NO_XCD_ROWS": "1"}, {"NRC_XCD_WINDOW": "16"},
+                {"NRC_TRAIN_GEN_OLD": "1"}):
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=3, dir_id=0, nn_width=128, nn_depth=3, train_batch_count=1,
+                                        log2_train_batch_size=10)
+        ren.SetBlend(True)
+        for f in range(10):               # the cost order is sampled at frame 0, 4, 8 and in use from frame 2 / 3 on
+            ren.SetFrameRandom(frs[f])
+            ren.Render(None, True)
+        results.append((ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy()))
+        ren.Destroy()
+        nrc.Destroy()
+    for k in switches:
+        monkeypatch.delenv(k, raising=False)
+    base = results[0]
+    assert np.isfinite(base[0]).all() and base[0].max() > 0.0
+    for other in results[1:]:
+        assert np.array_equal(base[0].view(np.uint32), other[0].view(np.uint32))
+        assert base[1] == other[1]
+        assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
+
+
 @pytest.mark.parametrize("model", [(2, 2, 64, 3), (3, 0, 128, 2), (3, 0, 64, 6)], ids=["generic-64", "generic-128", "fused"])
 def test_deferred_compositing_inside_render_frames_changes_no_pixel(api, sc, cloud16, torch_gpu, model, monkeypatch):
     """nrc_renderer_render_frames composites every frame but its last on the train-ray stream, one frame late (round 4: stream C --
