@@ -165,6 +165,20 @@ int nrc_cache_set_collective_hooks(nrc_cache_t* c, int rank, int world, nrc_allr
 /* checkpointing: which = 0 master weights, 1 EMA weights, 2 Adam m, 3 Adam v, 4 gradient (host fp32 arrays) */
 int nrc_cache_get_params(nrc_cache_t* c, int which, float* host_out);
 int nrc_cache_set_params(nrc_cache_t* c, int which, const float* host_in);
+/* the same vectors in tiny-cuda-nn v1.6's OWN parameter layout -- what a dump of its Trainer's params_full_precision holds for the model
+ * tcnn::create_from_config(5, 3, cfg) builds at src/NeuralRadianceCache.cu:39, so that weights saved from the reference can be loaded
+ * (and the other way round): the matrices in the same order and row-major orientation, the output matrix with its rows padded to 16
+ * (16 x nnWidth; rows 3..15 feed the padded outputs nobody reads: kept on the host as initialised / last set, never trained), then the
+ * encoding's table.  count = nrc_cache_param_count + 13 * nnWidth (26 624 for the 6 x 64 model with the 80-wide encoding). */
+uint32_t nrc_cache_param_count_tcnn(nrc_cache_t* c);
+int nrc_cache_get_params_tcnn(nrc_cache_t* c, int which, float* host_out);
+int nrc_cache_set_params_tcnn(nrc_cache_t* c, int which, const float* host_in);
+/* checkpoint FILE (the reference has none; SURVEY.md section 5 "checkpoint / resume"): little-endian, 64-byte header {"NRCCKPT1", posID,
+ * dirID, nnWidth, nnDepth, hashgrid log2 size, tcnn parameter count, optimizer step, 0...} + the four vectors which = 0..3 in the
+ * tiny-cuda-nn layout above.  load checks the header against the cache's model (NRC_ERR_INVALID on a mismatch, a short or unreadable
+ * file) and leaves the cache untouched on failure. */
+int nrc_cache_save_checkpoint(nrc_cache_t* c, const char* path);
+int nrc_cache_load_checkpoint(nrc_cache_t* c, const char* path);
 int nrc_cache_get_step(nrc_cache_t* c, uint32_t* step);
 int nrc_cache_set_step(nrc_cache_t* c, uint32_t step);
 

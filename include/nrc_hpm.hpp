@@ -336,6 +336,24 @@ public:
         nrc_check(nrc_cache_set_collective_hooks(h_, rank, world, allreduce, allgather, user));
     }
 
+    // Parameters in tiny-cuda-nn's own layout (what the reference's trainer->params_full_precision() holds for the model of
+    // src/NeuralRadianceCache.cu:39; output matrix 16 x nnWidth): which = 0 master weights, 1 EMA weights, 2 Adam m, 3 Adam v
+    uint32_t ParamCountTcnn() const { return nrc_cache_param_count_tcnn(h_); }
+    std::vector<float> GetParamsTcnn(int which = 0) const
+    {
+        std::vector<float> v(ParamCountTcnn());
+        nrc_check(nrc_cache_get_params_tcnn(h_, which, v.data()));
+        return v;
+    }
+    void SetParamsTcnn(int which, const std::vector<float>& v)
+    {
+        if (v.size() != ParamCountTcnn()) throw std::runtime_error("SkyRenderer ERROR: SetParamsTcnn: wrong parameter count");
+        nrc_check(nrc_cache_set_params_tcnn(h_, which, v.data()));
+    }
+    // checkpoint file (the reference has none): model shape, step, weights / EMA weights / Adam moments
+    void SaveCheckpoint(const std::string& filePath) const { nrc_check(nrc_cache_save_checkpoint(h_, filePath.c_str())); }
+    void LoadCheckpoint(const std::string& filePath) { nrc_check(nrc_cache_load_checkpoint(h_, filePath.c_str())); }
+
 private:
     nrc_cache_t* h_ = nullptr;
 };
@@ -382,6 +400,9 @@ public:
     const nrc_tile& Tile() const { return tile_; }
     void EvaluateTimestampQueries() { (void)nrc_renderer_frame_time_ms(h_, stage_ms_); }
     const float* GetImage() const { return nrc_renderer_framebuffer(h_); }     // RGBA32F [height][width]
+    // VkImageView GetImageView() of the reference (include/engine/graphics/renderer/NrcHpmRenderer.hpp:37, src/main.cu:375: what the
+    // UI samples): there is one view of the output image here, the device pointer itself
+    const float* GetImageView() const { return GetImage(); }
     const float* GetImage(void* consumerStream) const { return nrc_renderer_framebuffer_on(h_, consumerStream); }
     // the reads of the image enqueued on consumerStream end here: the next frame's compositing waits for them
     void ReleaseImage(void* consumerStream) { nrc_check(nrc_renderer_release_frame(h_, consumerStream)); }
@@ -434,6 +455,11 @@ public:
     }
     void ExportOutputImageToFile(void* /*queue*/, const std::string& filePath) const { nrc_check(nrc_mc_renderer_export_exr(h_, filePath.c_str())); }
     const float* GetImage() const { return nrc_mc_renderer_framebuffer(h_); }
+    const float* GetImageView() const { return GetImage(); }      // include/engine/graphics/renderer/McHpmRenderer.hpp:25
+    // include/engine/graphics/renderer/McHpmRenderer.hpp:22-23, called once per frame at src/main.cu:284: reads the frame's
+    // timestamps; GetFrameTimeMS() is what it found (ms of the last completed frame, 0 before the first)
+    void EvaluateTimestampQueries() { frame_ms_ = nrc_mc_renderer_frame_time_ms(h_); }
+    float GetFrameTimeMS() const { return frame_ms_; }
     void SetCamera(void* /*queue*/, const nrc_camera* camera) { nrc_check(nrc_mc_renderer_set_camera(h_, camera)); }
     void SetCamera(void* queue, const Camera* camera) { SetCamera(queue, camera->Matrices()); }
     void SetBlend(bool blend) { nrc_check(nrc_mc_renderer_set_blend(h_, blend ? 1 : 0)); }
@@ -444,6 +470,7 @@ public:
 
 private:
     nrc_mc_renderer_t* h_ = nullptr;
+    float frame_ms_ = 0.0f;
 };
 
 // en::Reference (src/Reference.cpp): the converged ground-truth image of a scene, seen from a fixed reference camera, and the

@@ -73,7 +73,8 @@ ABI_SYMBOLS = [
     "nrc_comm_unique_id", "nrc_cache_comm_init", "nrc_cache_comm_sparse", "nrc_cache_grid_list_capacity",
     "nrc_cache_grid_grad_pack", "nrc_cache_grid_grad_apply",
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
-    "nrc_cache_get_step", "nrc_cache_set_step",
+    "nrc_cache_get_step", "nrc_cache_set_step", "nrc_cache_param_count_tcnn", "nrc_cache_get_params_tcnn", "nrc_cache_set_params_tcnn",
+    "nrc_cache_save_checkpoint", "nrc_cache_load_checkpoint",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_render_frames", "nrc_renderer_set_stage_events", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
     "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_framebuffer_on",
@@ -126,6 +127,8 @@ def load_library():
     L.nrc_cache_grad_ptr.restype = C.c_void_p
     L.nrc_cache_loss_ptr.restype = C.c_void_p
     L.nrc_cache_param_count.restype = C.c_uint32
+    L.nrc_cache_param_count_tcnn.restype = C.c_uint32
+    L.nrc_cache_param_count_tcnn.argtypes = [C.c_void_p]
     L.nrc_renderer_framebuffer.restype = C.c_void_p
     L.nrc_renderer_framebuffer_on.restype = C.c_void_p
     L.nrc_renderer_buffer.restype = C.c_void_p
@@ -455,6 +458,27 @@ class NeuralRadianceCache:
         v = np.ascontiguousarray(values, np.float32)
         assert v.size == self.ParamCount()
         _check(self.L.nrc_cache_set_params(self.h, C.c_int(which), v.ctypes.data_as(C.c_void_p)))
+
+    def ParamCountTcnn(self):
+        return int(self.L.nrc_cache_param_count_tcnn(self.h))
+
+    def GetParamsTcnn(self, which=0):
+        """buffer `which` in tiny-cuda-nn's own layout (output matrix padded to 16 rows): what a weight dump of the reference holds"""
+        out = np.zeros(self.ParamCountTcnn(), np.float32)
+        _check(self.L.nrc_cache_get_params_tcnn(self.h, C.c_int(which), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def SetParamsTcnn(self, which, values):
+        v = np.ascontiguousarray(values, np.float32)
+        assert v.size == self.ParamCountTcnn()
+        _check(self.L.nrc_cache_set_params_tcnn(self.h, C.c_int(which), v.ctypes.data_as(C.c_void_p)))
+
+    def SaveCheckpoint(self, path):
+        """nrc_cache_save_checkpoint: model shape + step + weights / EMA weights / Adam moments (tiny-cuda-nn layout) in one file"""
+        _check(self.L.nrc_cache_save_checkpoint(self.h, os.fsencode(path)))
+
+    def LoadCheckpoint(self, path):
+        _check(self.L.nrc_cache_load_checkpoint(self.h, os.fsencode(path)))
 
     def GetStep(self):
         s = C.c_uint32(0)

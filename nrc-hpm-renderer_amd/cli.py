@@ -112,11 +112,25 @@ def main(argv=None):
             mc.Destroy()
         eval_renderer = api.NrcHpmRenderer(lw, H, False, camera, cfg, scene, nrc, tile=tile)        # Reference::CompareNrc renders with train=false
 
+    # A NaN / Inf loss ends the run (src/main.cu:380-384).  With several ranks the decision is COLLECTIVE: the poll below never blocks, so
+    # ranks can see the (all-reduced, identical) bad value at different frames -- a rank that left the loop on its own would enter the
+    # collective export while its peers are still inside Render()'s gradient exchange, and the job would hang.  Every rank therefore
+    # only NOTES a bad loss, the flag is max-reduced every kStopEvery frames (and at the last one), and all ranks leave at that frame.
+    kStopEvery = 8
+    bad, failed = False, False
     for frame in range(args.frames):
         nrc_renderer.Render(None, True)
         loss = nrc.GetLoss(wait=False)          # src/main.cu:376: polled every frame, never blocks the frame pipeline
         if math.isnan(loss) or math.isinf(loss):                    # src/main.cu:380-384
             print("SkyRenderer ERROR: NRC Loss is %s" % loss, file=sys.stderr)
+            bad = True
+        if world == 1:
+            failed = bad
+        elif frame % kStopEvery == kStopEvery - 1 or frame == args.frames - 1:
+            flag = torch.tensor([1.0 if bad else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = bool(flag.item() > 0.0)
+        if failed:
             break
         if ref is not None:
             eval_renderer.Render(None, False)
@@ -132,16 +146,17 @@ def main(argv=None):
             print("frame %d: loss %.5f, %.3f ms" % (frame, loss, nrc_renderer.GetFrameTimeMS()))
     if log is not None:
         log.close()
-    if args.export:
+    if args.export and not failed:
         nrc_renderer.ExportOutputImageToFile(None, args.export)      # sharded: collective, rank 0 writes the whole frame
     nrc_renderer.Destroy()
     if ref is not None:
         eval_renderer.Destroy()
     nrc.Destroy()
     if world > 1:
-        dist.barrier()
+        if not failed:
+            dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":

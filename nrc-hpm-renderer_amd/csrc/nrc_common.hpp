@@ -40,10 +40,10 @@ void dev_free(void* p);
 template <class T>
 inline void dev_alloc(T** p, size_t bytes, const char* what = "") { dev_alloc(reinterpret_cast<void**>(p), bytes, what); }
 
-// O'Neill's pcg32 (XSH-RR): the generator tiny-cuda-nn uses for weight init (seed 1337)
+// O'Neill's pcg32 (XSH-RR) as tiny-cuda-nn vendors it (pcg32.h): its Trainer seeds pcg32{1337}, i.e. stream initseq = 1
 struct Pcg32 {
     uint64_t state = 0, inc = 1;
-    void seed(uint64_t init_state, uint64_t init_seq)
+    void seed(uint64_t init_state, uint64_t init_seq = 1u)
     {
         state = 0; inc = (init_seq << 1) | 1u; next(); state += init_state; next();
     }
@@ -55,7 +55,14 @@ struct Pcg32 {
         uint32_t rot = (uint32_t)(old >> 59u);
         return (xs >> rot) | (xs << ((32u - rot) & 31u));
     }
-    float nextf() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+    // pcg32::next_float: a float in [1, 2) from the top 23 bits (the MTGP trick), minus 1
+    float nextf()
+    {
+        const uint32_t u = (next() >> 9) | 0x3f800000u;
+        float f;
+        __builtin_memcpy(&f, &u, 4);
+        return f - 1.0f;
+    }
 };
 
 }  // namespace nrc

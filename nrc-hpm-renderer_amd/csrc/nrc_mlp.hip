@@ -2598,15 +2598,36 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     }
     n_params_ = n_mlp_ + n_grid;
 
-    // Xavier-uniform init from pcg32(seed), then the grid uniform in [-1e-4, 1e-4) -- same stream as the oracle's statement
+    // tiny-cuda-nn v1.6's initialisation (src/NeuralRadianceCache.cu:39 -> tcnn::create_from_config -> Trainer::initialize_params;
+    // recalled from upstream, the submodule is absent -- DESIGN.md section 2): pcg32{seed} on stream 1; the network's matrices first
+    // -- each Xavier-uniform under the bound sqrt(6 / (rows + columns)) of its STORED shape, element = next_float() * 2 * scale - scale
+    // in that order of operations, the output matrix stored with 16 rows (rows 3..15 feed the padded outputs nobody reads: drawn,
+    // kept for the tcnn-layout dump, never part of this model) --, then the table: generate_random_uniform's GPU order (thread i of
+    // ceil(n / 4) rounded up to 128 writes draw 4 i + j to element i + n_threads * j), value = fma(u, 2e-4, -1e-4).
     std::vector<float> w(n_params_);
     Pcg32 rng;
-    rng.seed(cfg.seed, 0);
-    for (const MlpLayer& L : layers_) {
-        const float scale = sqrtf(6.0f / (float)(L.in + L.out));
-        for (uint32_t i = 0; i < L.in * L.out; i++) w[L.off + i] = (rng.nextf() * 2.0f - 1.0f) * scale;
+    rng.seed(cfg.seed, 1);
+    for (int k = 0; k < 4; k++) tcnn_dead_rows_[k].assign((size_t)13 * width_, 0.0f);
+    for (uint32_t l = 0; l <= depth_; l++) {
+        const MlpLayer& L = layers_[l];
+        const uint32_t rows = l == depth_ ? 16u : L.out;
+        const float scale = 1.0f * sqrtf(6.0f / (float)(L.in + rows));
+        for (uint32_t i = 0; i < L.in * rows; i++) {
+            const float x = rng.nextf() * 2.0f * scale - scale;
+            if (i < L.in * L.out) w[L.off + i] = x;
+            else tcnn_dead_rows_[0][i - L.in * L.out] = x;
+        }
     }
-    for (uint32_t i = 0; i < n_grid; i++) w[n_mlp_ + i] = rng.nextf() * 2e-4f - 1e-4f;
+    tcnn_dead_rows_[1] = tcnn_dead_rows_[0];      // the EMA copy starts as the weights
+    if (n_grid > 0) {
+        const size_t n_threads = (((size_t)n_grid + 3) / 4 + 127) / 128 * 128;
+        const float lower = -1e-4f, upper = 1e-4f;
+        for (size_t k = 0; k < 4 * n_threads; k++) {
+            const float u = rng.nextf();
+            const size_t idx = k / 4 + n_threads * (k % 4);
+            if (idx < n_grid) w[n_mlp_ + idx] = fmaf(u, upper - lower, lower);
+        }
+    }
 
     const size_t pb = (size_t)n_params_ * sizeof(float);
     dev_alloc(&d_w_, pb, "d_w_");
@@ -2735,6 +2756,25 @@ float* Mlp::buffer(int which)
     case 4: return d_grad_;
     default: fail("bad parameter buffer id");
     }
+}
+
+void Mlp::to_tcnn_layout(int which, const float* own, float* tcnn) const
+{
+    if (which < 0 || which > 4) fail("bad parameter buffer id");
+    const size_t n_out = (size_t)3 * width_, head = n_mlp_ - n_out, dead = (size_t)13 * width_;
+    std::memcpy(tcnn, own, (head + n_out) * sizeof(float));
+    if (which < 4) std::memcpy(tcnn + n_mlp_, tcnn_dead_rows_[which].data(), dead * sizeof(float));
+    else std::memset(tcnn + n_mlp_, 0, dead * sizeof(float));
+    std::memcpy(tcnn + n_mlp_ + dead, own + n_mlp_, (size_t)(n_params_ - n_mlp_) * sizeof(float));
+}
+
+void Mlp::from_tcnn_layout(int which, const float* tcnn, float* own)
+{
+    if (which < 0 || which > 4) fail("bad parameter buffer id");
+    const size_t dead = (size_t)13 * width_;
+    std::memcpy(own, tcnn, (size_t)n_mlp_ * sizeof(float));
+    if (which < 4) std::memcpy(tcnn_dead_rows_[which].data(), tcnn + n_mlp_, dead * sizeof(float));
+    std::memcpy(own + n_mlp_, tcnn + n_mlp_ + dead, (size_t)(n_params_ - n_mlp_) * sizeof(float));
 }
 
 // The inference (EMA) image and table are double-buffered: this writes the set inference is NOT reading and then makes it

@@ -61,6 +61,13 @@ public:
     float* grad_ptr() { return d_grad_; }
     float* loss_ptr() { return d_loss_; }
     float* buffer(int which);    // 0 w, 1 ema, 2 m, 3 v, 4 grad
+    // tiny-cuda-nn's own parameter layout (params_full_precision of its Trainer): the same matrices in the same order with the output
+    // matrix stored 16 x width (rows 3..15 feed the padded outputs nobody reads), then the table.  tcnn_param_count() = n_params() +
+    // 13 * width.  to / from convert a host vector of buffer `which` (0..3; the dead rows of 4, the gradient, are zero); the dead
+    // rows are kept on the host as they were initialised / last set, so that a dump read back is the dump
+    uint32_t tcnn_param_count() const { return n_params_ + 13u * width_; }
+    void to_tcnn_layout(int which, const float* own, float* tcnn) const;
+    void from_tcnn_layout(int which, const float* tcnn, float* own);
     // sparse exchange of the HashGrid table gradient (nrc_mlp.hip, k_grid_pack): the gradient vector is
     // [n_mlp_params() matrix gradients][2 per table entry][2-word loss cell]
     bool has_grid() const { return hash_; }
@@ -109,6 +116,7 @@ private:
     bool attr_gather_set_ = false;
 
     float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
+    std::vector<float> tcnn_dead_rows_[4];      // rows 3..15 of tiny-cuda-nn's 16 x width output matrix, per buffer 0..3
     // fp16 MFMA A-operand fragment images ([frag][lane][8 halfs]): inference (EMA), training forward, training dgrad (W^T)
     void *d_pk_infer_[2] = {nullptr, nullptr}, *d_pk_fwd_ = nullptr, *d_pk_bwd_ = nullptr;
     int32_t *d_src_fwd_ = nullptr, *d_src_bwd_ = nullptr;   // packed slot -> canonical index (-1 = zero)

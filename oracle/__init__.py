@@ -190,6 +190,12 @@ class Oracle:
                              C.c_uint32(W), C.c_uint32(H), _ptr(r))
         return dict(mse=float(r[0]), ref_mean=float(r[1]), own_mean=float(r[2]), own_var=float(r[3]), valid=float(r[4]))
 
+    def pcg32(self, seed, seq, n):
+        u = np.zeros(n, np.uint32)
+        f = np.zeros(n, np.float32)
+        self.lib.orc_pcg32(C.c_uint64(seed), C.c_uint64(seq), C.c_uint32(n), u.ctypes.data_as(C.c_void_p), _ptr(f))
+        return u, f
+
     # ---- NN ----
     def nn_create(self, pos_id=3, dir_id=0, width=64, depth=6, loss_id=0, lr=0.01, ema_decay=0.99, seed=1337,
                   hashgrid_log2_size=0, optimizer="Adam"):
@@ -216,6 +222,20 @@ class OracleNN:
 
     def set_step(self, step):
         self.orc.lib.orc_nn_set_step(self.h, C.c_uint32(step))
+
+    def tcnn_params(self, which=0, width=None):
+        """buffer `which` in tiny-cuda-nn's own layout: the output matrix padded to 16 rows (rows 3..15: the values the
+        initialisation drew for them for which 0 / 1, zeros otherwise), then the table"""
+        v = self.buffer(which)
+        n_out = 3 * width
+        head, tail = v[:self.n_mlp - n_out], v[self.n_mlp:]
+        out3 = v[self.n_mlp - n_out:self.n_mlp]
+        f = self.orc.lib.orc_nn_tcnn_dead_rows
+        f.restype = C.POINTER(C.c_float)
+        dead = np.ctypeslib.as_array(f(self.h), shape=(13 * width,)).copy()
+        if which not in (0, 1):
+            dead[:] = 0
+        return np.concatenate([head, out3, dead, tail]).astype(np.float32)
 
     def encode(self, x):
         x = np.ascontiguousarray(x, np.float32)

@@ -595,9 +595,9 @@ void orc_compare(const float* ref_rgba, const float* own_rgba, uint32_t W, uint3
 /* ====================================================================== neural radiance cache arithmetic */
 namespace {
 
-struct Pcg32 {     /* O'Neill's pcg32 (XSH-RR), the generator tiny-cuda-nn seeds with 1337 */
+struct Pcg32 {     /* O'Neill's pcg32 (XSH-RR) as tiny-cuda-nn vendors it (pcg32.h): the Trainer seeds pcg32{1337}, i.e. initseq = 1 */
     uint64_t state, inc;
-    void seed(uint64_t init_state, uint64_t init_seq) { state = 0; inc = (init_seq << 1) | 1u; next(); state += init_state; next(); }
+    void seed(uint64_t init_state, uint64_t init_seq = 1u) { state = 0; inc = (init_seq << 1) | 1u; next(); state += init_state; next(); }
     uint32_t next() {
         uint64_t old = state;
         state = old * 6364136223846793005ULL + inc;
@@ -605,7 +605,8 @@ struct Pcg32 {     /* O'Neill's pcg32 (XSH-RR), the generator tiny-cuda-nn seeds
         uint32_t rot = (uint32_t)(old >> 59u);
         return (xs >> rot) | (xs << ((32u - rot) & 31u));
     }
-    float nextf() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+    /* pcg32::next_float: the MTGP trick -- a float in [1, 2) from the top 23 bits, minus 1 */
+    float nextf() { uint32_t u = (next() >> 9) | 0x3f800000u; float f; memcpy(&f, &u, 4); return f - 1.0f; }
 };
 
 struct Layer { uint32_t out, in; size_t off; };
@@ -620,6 +621,7 @@ struct NN {
     std::vector<float> w, ema, m, v, grad; /* MLP parameters, then (posID 0) the hash-grid table */
     size_t n_mlp = 0;                      /* number of matrix (MLP) parameters */
     uint32_t hg_off[HG_LEVELS + 1] = {0};  /* per-level entry offsets */
+    std::vector<float> dead_rows;          /* rows 3..15 of tiny-cuda-nn's padded 16 x width output matrix (initial values; never read by the model) */
     uint32_t step;
 };
 
@@ -804,12 +806,38 @@ void* orc_nn_create(const orc_nn_config* cfg)
         n_grid = (size_t)o * HG_FEATS;
     }
     nn->w.assign(off + n_grid, 0.0f); nn->ema = nn->w; nn->m = nn->w; nn->v = nn->w; nn->grad = nn->w;
-    Pcg32 rng; rng.seed(cfg->seed, 0);
-    for (const Layer& L : nn->layers) {           /* Xavier uniform */
-        float scale = sqrtf(6.0f / (float)(L.in + L.out));
-        for (size_t i = 0; i < (size_t)L.in * L.out; i++) nn->w[L.off + i] = (rng.nextf() * 2.0f - 1.0f) * scale;
+    /* tiny-cuda-nn v1.6 initialisation, recalled from upstream (PARITY UNPINNED: the submodule is empty):
+     *   Trainer::initialize_params: pcg32 rng{seed = 1337} (stream 1) -> NetworkWithInputEncoding::initialize_params: the network
+     *   first, the encoding's parameters after it.
+     *   FullyFusedMLP::initialize_params: the matrices in order -- first (width x enc), hidden (width x width), output with its rows
+     *   PADDED to 16 (16 x width) -- each GPUMatrix::initialize_xavier_uniform: scale = sqrt(6 / (fan_in + fan_out)) of the STORED
+     *   shape (rows + columns), element i (row-major) = next_float() * 2 * scale - scale, evaluated left to right in fp32.
+     *   The output matrix therefore draws 16 * width numbers under the bound sqrt(6 / (16 + width)); rows 3..15 produce the padded
+     *   outputs nobody reads (this model keeps rows 0..2; orc_nn_tcnn_dead_rows hands out the rest for the tcnn-layout dump). */
+    Pcg32 rng; rng.seed(cfg->seed, 1);
+    nn->dead_rows.assign((size_t)13 * cfg->width, 0.0f);
+    for (uint32_t l = 0; l <= cfg->depth; l++) {
+        const Layer& L = nn->layers[l];
+        const uint32_t rows = (l == cfg->depth) ? 16u : L.out;
+        const float scale = 1.0f * sqrtf(6.0f / (float)(L.in + rows));
+        for (size_t i = 0; i < (size_t)L.in * rows; i++) {
+            const float x = rng.nextf() * 2.0f * scale - scale;
+            if (i < (size_t)L.in * L.out) nn->w[L.off + i] = x;
+            else nn->dead_rows[i - (size_t)L.in * L.out] = x;
+        }
     }
-    for (size_t i = 0; i < n_grid; i++) nn->w[off + i] = rng.nextf() * 2e-4f - 1e-4f;     /* grid: uniform [-1e-4, 1e-4) */
+    /* GridEncoding::initialize_params: generate_random_uniform<float>(rng, n_params, -1e-4, 1e-4) ON THE GPU: ceil(n / 4) threads in
+     * blocks of 128, thread i skips ahead 4 i draws and writes draw 4 i + j to element i + n_threads * j (n_threads = the whole grid,
+     * j = 0..3, elements beyond n dropped), value = next_float() * (upper - lower) + lower contracted to one FMA by nvcc. */
+    if (n_grid > 0) {
+        const size_t n_threads = ((n_grid + 3) / 4 + 127) / 128 * 128;
+        const float lower = -1e-4f, upper = 1e-4f;
+        for (size_t k = 0; k < 4 * n_threads; k++) {
+            const float u = rng.nextf();
+            const size_t idx = k / 4 + n_threads * (k % 4);
+            if (idx < n_grid) nn->w[off + idx] = fmaf(u, upper - lower, lower);
+        }
+    }
     nn->ema = nn->w;
     nn->step = 0;
     return nn;
@@ -820,6 +848,15 @@ uint32_t orc_nn_param_count(void* p) { return (uint32_t)((NN*)p)->w.size(); }
 uint32_t orc_nn_encoded_dims(void* p) { return ((NN*)p)->enc_dims; }
 uint32_t orc_nn_mlp_param_count(void* p) { return (uint32_t)((NN*)p)->n_mlp; }
 void orc_nn_set_step(void* p, uint32_t step) { ((NN*)p)->step = step; }
+const float* orc_nn_tcnn_dead_rows(void* p) { return ((NN*)p)->dead_rows.data(); }
+/* the generator by itself (known-answer test: pcg-c-basic's published demo vector for seed 42, stream 54) */
+void orc_pcg32(uint64_t seed, uint64_t seq, uint32_t n, uint32_t* out_u32, float* out_float)
+{
+    Pcg32 a; a.seed(seed, seq);
+    for (uint32_t i = 0; i < n; i++) out_u32[i] = a.next();
+    Pcg32 b; b.seed(seed, seq);
+    for (uint32_t i = 0; i < n; i++) out_float[i] = b.nextf();
+}
 
 float* orc_nn_buffer(void* p, int which)
 {

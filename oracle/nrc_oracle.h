@@ -109,6 +109,10 @@ uint32_t orc_nn_encoded_dims(void* nn);
 uint32_t orc_nn_mlp_param_count(void* nn);
 float* orc_nn_buffer(void* nn, int which);
 void orc_nn_set_step(void* nn, uint32_t step);
+/* 13 * width initial values of rows 3..15 of tiny-cuda-nn's padded 16 x width output matrix (drawn by the init, read by nothing) */
+const float* orc_nn_tcnn_dead_rows(void* nn);
+/* pcg32 (seed, stream): n raw outputs, and the n floats next_float() makes of the same stream */
+void orc_pcg32(uint64_t seed, uint64_t seq, uint32_t n, uint32_t* out_u32, float* out_float);
 /* features after fp16 rounding, [n][encoded_dims] */
 void orc_nn_encode(void* nn, const float* in, uint32_t n, float* out);
 /* mode 0: fp32 everywhere; mode 1: fp16 weights/activations, wide accumulate (the product's mode) */

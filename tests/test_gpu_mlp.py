@@ -46,6 +46,42 @@ def test_initial_weights_match_oracle(cache, orc):
     assert np.array_equal(cache.GetParams(1), onn.buffer(1))
 
 
+@pytest.mark.parametrize("model", [dict(), dict(nn_width=128, nn_depth=8), dict(pos_id=0, hashgrid_log2_size=12, nn_depth=3)],
+                         ids=["6x64", "8x128", "hashgrid"])
+def test_tcnn_parameter_layout_roundtrip(api, orc, torch_gpu, model):
+    """nrc_cache_{get,set}_params_tcnn: the vectors in tiny-cuda-nn's own layout (output matrix 16 x width) -- equal to the oracle's
+    statement of tiny-cuda-nn's initialisation bit for bit, 26 624 numbers for the 6 x 64 model; a dump set into a cache of another
+    seed gives the same network (same outputs, same dump back, dead rows included)"""
+    a = api.NeuralRadianceCache(api.AppConfig(**model))
+    width, depth = model.get("nn_width", 64), model.get("nn_depth", 6)
+    onn = orc.nn_create(pos_id=model.get("pos_id", 3), width=width, depth=depth, hashgrid_log2_size=model.get("hashgrid_log2_size", 0))
+    assert a.ParamCountTcnn() == a.ParamCount() + 13 * width
+    if not model:
+        assert a.ParamCountTcnn() == 26624
+    t0 = a.GetParamsTcnn(0)
+    assert np.array_equal(t0, onn.tcnn_params(0, width)) and np.array_equal(a.GetParamsTcnn(1), onn.tcnn_params(1, width))
+    assert not a.GetParamsTcnn(2).any()
+    # rows 3..15 of the output matrix are tiny-cuda-nn's padding rows: present in the dump, absent from the model
+    n_mlp = onn.n_mlp
+    assert np.array_equal(t0[:n_mlp], a.GetParams(0)[:n_mlp]) and t0[n_mlp:n_mlp + 13 * width].any()
+    assert np.array_equal(t0[n_mlp + 13 * width:], a.GetParams(0)[n_mlp:])
+    rng = np.random.default_rng(3)
+    dump = (t0 * 1.25 + rng.standard_normal(t0.size).astype(np.float32) * 0.003).astype(np.float32)
+    b = api.NeuralRadianceCache(api.AppConfig(seed=7, **model))
+    assert not np.array_equal(b.GetParamsTcnn(0), t0)
+    for which in (0, 1):
+        b.SetParamsTcnn(which, dump)
+        a.SetParamsTcnn(which, dump)
+        assert np.array_equal(b.GetParamsTcnn(which), dump)
+    x = torch_gpu.from_numpy(queries(512, seed=9)).cuda()
+    oa, ob = torch_gpu.empty((512, 3), device="cuda"), torch_gpu.empty((512, 3), device="cuda")
+    a.Infer(x, oa, True)
+    b.Infer(x, ob, True)
+    assert torch_gpu.equal(oa, ob)
+    a.Destroy()
+    b.Destroy()
+
+
 @pytest.mark.parametrize("use_ema", [True, False])
 def test_inference_matches_oracle(cache, orc, torch_gpu, use_ema):
     onn = orc.nn_create()
@@ -349,6 +385,44 @@ def test_checkpoint_roundtrip(api, torch_gpu):
     assert torch_gpu.equal(oa, ob)
     a.Destroy()
     b.Destroy()
+
+
+def test_checkpoint_file_roundtrip_and_rejections(api, torch_gpu, tmp_path):
+    """nrc_cache_save_checkpoint / _load_checkpoint: a cache of another seed resumes bit for bit; a file of another model, a truncated
+    file and a file with trailing bytes are refused and leave the cache as it was"""
+    a = api.NeuralRadianceCache(api.AppConfig())
+    x = torch_gpu.from_numpy(queries(1024, seed=61, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((1024, 3), device="cuda")
+    for _ in range(3):
+        a.Backward(x, t)
+        a.OptimizerStep()
+    path = str(tmp_path / "nrc.ckpt")
+    a.SaveCheckpoint(path)
+    assert (tmp_path / "nrc.ckpt").stat().st_size == 64 + 4 * 4 * 26624
+    b = api.NeuralRadianceCache(api.AppConfig(seed=99))
+    b.LoadCheckpoint(path)
+    assert b.GetStep() == a.GetStep() == 3
+    for c in (a, b):
+        c.Backward(x, t)
+        c.OptimizerStep()
+    for which in range(4):
+        assert np.array_equal(a.GetParamsTcnn(which), b.GetParamsTcnn(which))
+    before = b.GetParams(0)
+    other = api.NeuralRadianceCache(api.AppConfig(nn_width=32))
+    with pytest.raises(RuntimeError, match="not of this model"):
+        other.LoadCheckpoint(path)
+    raw = (tmp_path / "nrc.ckpt").read_bytes()
+    (tmp_path / "short.ckpt").write_bytes(raw[:-100])
+    (tmp_path / "long.ckpt").write_bytes(raw + b"x")
+    with pytest.raises(RuntimeError, match="truncated"):
+        b.LoadCheckpoint(str(tmp_path / "short.ckpt"))
+    with pytest.raises(RuntimeError, match="trailing"):
+        b.LoadCheckpoint(str(tmp_path / "long.ckpt"))
+    with pytest.raises(RuntimeError, match="cannot read"):
+        b.LoadCheckpoint(str(tmp_path / "absent.ckpt"))
+    assert np.array_equal(b.GetParams(0), before)
+    for c in (a, b, other):
+        c.Destroy()
 
 
 @pytest.mark.parametrize("model", [dict(), dict(pos_id=0, hashgrid_log2_size=10, nn_depth=3)], ids=["fused", "hashgrid"])

@@ -14,6 +14,43 @@ def queries(n, seed=0, nan_frac=0.1):
     return x
 
 
+def test_pcg32_known_answers(orc):
+    """the generator against the vector its authors publish (pcg-c-basic, pcg32-demo: seed 42, stream 54) and tiny-cuda-nn's
+    next_float() = bits((u >> 9) | 0x3f800000) - 1"""
+    u, f = orc.pcg32(42, 54, 6)
+    assert [int(x) for x in u] == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    want = ((u >> 9) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1.0)
+    assert np.array_equal(f, want) and (f >= 0).all() and (f < 1).all()
+
+
+def tcnn_init(width=64, depth=6, enc=80, seed=1337, n_grid=0, orc=None):
+    """tiny-cuda-nn v1.6's initialisation written out once more, from the generator's raw output (recalled
+    from upstream): pcg32{seed}, stream 1; matrices in order, output matrix 16 x width; x = u * 2 * scale - scale in fp32; then
+    the table in generate_random_uniform's GPU order"""
+    shapes = [(width, enc)] + [(width, width)] * (depth - 1) + [(16, width)]
+    n = sum(r * c for r, c in shapes)
+    n_threads = ((n_grid + 3) // 4 + 127) // 128 * 128 if n_grid else 0
+    _, f = orc.pcg32(seed, 1, n + 4 * n_threads)
+    out, k = [], 0
+    for r, c in shapes:
+        scale = np.float32(1.0) * np.sqrt(np.float32(6.0) / np.float32(r + c), dtype=np.float32)
+        u = f[k:k + r * c]
+        k += r * c
+        out.append(u * np.float32(2.0) * scale - scale)
+    grid = None
+    if n_grid:
+        u = f[k:k + 4 * n_threads].astype(np.float64)
+        # fma(u, 2e-4f, -1e-4f): the product of two floats is exact in double, one rounding to float
+        hi = np.float64(np.float32(1e-4) - np.float32(-1e-4))
+        v = (u * hi + np.float64(np.float32(-1e-4))).astype(np.float32)
+        kk = np.arange(4 * n_threads)
+        idx = kk // 4 + n_threads * (kk % 4)
+        grid = np.zeros(n_grid, np.float32)
+        keep = idx < n_grid
+        grid[idx[keep]] = v[keep]
+    return out, grid
+
+
 def test_param_count_and_init(orc):
     nn = orc.nn_create()
     assert nn.enc_dims == 80
@@ -23,6 +60,34 @@ def test_param_count_and_init(orc):
     assert np.abs(w[:64 * 80]).max() <= s0 + 1e-6 and np.abs(w[:64 * 80]).max() > 0.9 * s0
     assert np.array_equal(w, nn.buffer(1))             # EMA starts at the weights
     assert np.array_equal(orc.nn_create().buffer(0), w)    # seed 1337 is deterministic
+
+
+@pytest.mark.parametrize("width,depth", [(64, 6), (128, 8), (16, 2)])
+def test_init_follows_tiny_cuda_nn(orc, width, depth):
+    """every matrix draws rows x columns numbers of ITS STORED SHAPE from pcg32{1337} (stream 1) under the Xavier bound of that
+    shape; the output matrix is stored 16 x width: 16 * width draws, bound sqrt(6 / (16 + width)), rows 3..15 dead"""
+    nn = orc.nn_create(width=width, depth=depth)
+    mats, _ = tcnn_init(width, depth, 80, orc=orc)
+    flat = np.concatenate(mats)
+    assert flat.size == nn.n_params + 13 * width == (26624 if (width, depth) == (64, 6) else flat.size)
+    t = nn.tcnn_params(0, width)
+    assert np.array_equal(t, flat)                      # bit for bit, dead rows included
+    own = nn.buffer(0)
+    assert np.array_equal(own[:nn.n_mlp - 3 * width], flat[:nn.n_mlp - 3 * width])
+    assert np.array_equal(own[nn.n_mlp - 3 * width:], mats[-1][:3 * width])
+    bound = np.sqrt(6.0 / (16 + width))
+    assert np.abs(mats[-1]).max() <= bound and np.abs(mats[-1]).max() > 0.95 * bound
+
+
+def test_hashgrid_init_follows_tiny_cuda_nn(orc):
+    nn = orc.nn_create(pos_id=0, hashgrid_log2_size=12)
+    n_grid = nn.n_params - nn.n_mlp
+    enc = nn.enc_dims
+    mats, grid = tcnn_init(64, 6, enc, n_grid=n_grid, orc=orc)
+    own = nn.buffer(0)
+    assert np.array_equal(own[nn.n_mlp:], grid)
+    assert np.abs(grid).max() <= 1e-4 and np.abs(grid).max() > 0.99e-4 and abs(grid.mean()) < 5e-6
+    assert np.array_equal(own[:64 * enc], mats[0])
 
 
 def test_frequency_encoding(orc):
