@@ -165,6 +165,20 @@ class Oracle:
                                   C.c_int(threads), C.byref(nf))
         return dict(primary=primary, info=info, origin=origin, dir=direc, infer_input=infer_in, n_fetch=nf.value)
 
+    def nrc_walk_lengths(self, scene, cam, W, H, primary_ray_length, primary_ray_prob, frame_random, walks_per_pixel=8, threads=1):
+        """[H][W][walks_per_pixel] uint16: free flights drawn by each tracking walk of a pixel of the NRC frame, in program order"""
+        s, c = self.make_scene(scene), self.make_camera(cam)
+        primary = np.zeros((H, W, 4), np.float32)
+        info = np.zeros((H, W), np.float32)
+        origin = np.zeros((H, W, 4), np.float32)
+        direc = np.zeros((H, W, 4), np.float32)
+        out = np.zeros((H, W, walks_per_pixel), np.uint16)
+        fr = np.asarray(frame_random, np.float32)
+        self.lib.orc_nrc_walk_lengths(C.byref(s), C.byref(c), C.c_uint32(W), C.c_uint32(H), C.c_uint32(0), C.c_uint32(H),
+                                      C.c_uint32(primary_ray_length), C.c_float(primary_ray_prob), _ptr(fr), _ptr(primary), _ptr(info),
+                                      _ptr(origin), _ptr(direc), C.c_int(threads), out.ctypes.data_as(C.c_void_p), C.c_uint32(walks_per_pixel))
+        return out, info
+
     def nrc_prep_train(self, scene, W, H, TW, TH, x_dist, y_dist, train_spp, train_ray_length, ring_size,
                        frame_random, info, origin, direc, head_tail, ring, threads=1):
         s = self.make_scene(scene)

@@ -54,6 +54,9 @@ struct Ctx {
     float fnx, fny, fnz;
     float rng;               /* randomState, random.glsl:59 */
     uint64_t fetches;
+    uint16_t* trace = nullptr;   /* tests/walk_model.py: every tracking walk appends the number of free flights it drew */
+    uint32_t trace_n = 0, trace_max = 0;
+    void walk_done(uint32_t flights) { if (trace && trace_n < trace_max) trace[trace_n++] = (uint16_t)flights; }
     float rand(float max_val) { rng = random1(rng); return rng * max_val; }   /* random.glsl:66-70 */
 };
 
@@ -176,12 +179,15 @@ static inline float ratio_track(Ctx& c, V3 start, V3 end)       /* path_trace.gl
     V3 dir = normalize(d);
     float t_max = length(d);
     float tr = 1.0f, t = 0.0f;
-    for (uint32_t i = 0; i < 128; i++) {
+    uint32_t i = 0, flights = 0;
+    for (; i < 128; i++) {
         t = orc_fmaf_(-orc_logf(1.0f - c.rand(1.0f)), c.inv_max_density, t);
+        flights++;
         if (t >= t_max) break;
         V3 p = madd(dir, t, start);
         tr *= orc_fmaf_(-get_density(c, p), c.inv_max_density, 1.0f);
     }
+    c.walk_done(flights);
     return tr;
 }
 
@@ -270,12 +276,15 @@ static inline V3 delta_track(Ctx& c, V3 ro, V3 rd, bool* volume_exit)    /* path
     find_entry_exit(c, ro, rd, &en, &ex);
     float t_max = length(sub(ex, ro));
     float t = 0.0f;
+    uint32_t flights = 0;
     for (uint32_t i = 0; i < 128; i++) {
         t = orc_fmaf_(-orc_logf(1.0f - c.rand(1.0f)), c.inv_max_density, t);
+        flights++;
         if (t >= t_max) { *volume_exit = true; break; }
         V3 p = madd(rd, t, ro);
-        if (get_density(c, p) * c.inv_max_density > c.rand(1.0f)) return p;
+        if (get_density(c, p) * c.inv_max_density > c.rand(1.0f)) { c.walk_done(flights); return p; }
     }
+    c.walk_done(flights);
     return madd(rd, c.rand(t_max), ro);
 }
 
@@ -407,11 +416,11 @@ void orc_mc_render(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint3
 }
 
 /* ---------------------------------------------------------------- nrc/gen_rays.comp:7-101 + nrc/prep_infer_rays.comp:26-46 */
-void orc_nrc_gen_rays(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H,
+static void nrc_gen_rays_impl(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H,
                       uint32_t y0, uint32_t y1, uint32_t primary_ray_length, float primary_ray_prob,
                       const float frame_random[4], float* primary_rgba, float* info,
                       float* nrc_origin, float* nrc_dir, float* infer_input,
-                      int n_threads, uint64_t* n_fetch)
+                      int n_threads, uint64_t* n_fetch, uint16_t* walk_lengths, uint32_t walks_per_pixel)
 {
     std::vector<uint64_t> fetch((size_t)std::max(n_threads, 1), 0);
     parallel_rows(y0, y1, n_threads, [&](uint32_t y, int tid) {
@@ -420,6 +429,7 @@ void orc_nrc_gen_rays(const orc_scene* sc, const orc_camera* cam, uint32_t W, ui
             float u, v; V3 ro, rd;
             camera_ray(cam, W, H, x, y, &u, &v, &ro, &rd);
             init_random(c, u, v, frame_random);
+            if (walk_lengths) { c.trace = walk_lengths + ((size_t)y * W + x) * walks_per_pixel; c.trace_n = 0; c.trace_max = walks_per_pixel; }
             V3 entry, ex;
             find_entry_exit(c, ro, rd, &entry, &ex);
             size_t pix = (size_t)y * W + x;
@@ -464,6 +474,26 @@ void orc_nrc_gen_rays(const orc_scene* sc, const orc_camera* cam, uint32_t W, ui
         fetch[tid] += c.fetches;
     });
     if (n_fetch) { uint64_t s = 0; for (auto f : fetch) s += f; *n_fetch = s; }
+}
+
+void orc_nrc_gen_rays(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H,
+                      uint32_t y0, uint32_t y1, uint32_t primary_ray_length, float primary_ray_prob,
+                      const float frame_random[4], float* primary_rgba, float* info,
+                      float* nrc_origin, float* nrc_dir, float* infer_input,
+                      int n_threads, uint64_t* n_fetch)
+{
+    nrc_gen_rays_impl(sc, cam, W, H, y0, y1, primary_ray_length, primary_ray_prob, frame_random, primary_rgba, info, nrc_origin, nrc_dir,
+                      infer_input, n_threads, n_fetch, nullptr, 0);
+}
+
+/* the same frame; walk_lengths[(y * W + x) * walks_per_pixel + k] = free flights drawn by the pixel's k-th tracking walk, in program
+ * order (delta, dir light, [point light,] environment, delta, ...), 0 beyond its last walk (caller zero-fills).  tests/walk_model.py */
+void orc_nrc_walk_lengths(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                          uint32_t primary_ray_length, float primary_ray_prob, const float frame_random[4], float* primary_rgba,
+                          float* info, float* nrc_origin, float* nrc_dir, int n_threads, uint16_t* walk_lengths, uint32_t walks_per_pixel)
+{
+    nrc_gen_rays_impl(sc, cam, W, H, y0, y1, primary_ray_length, primary_ray_prob, frame_random, primary_rgba, info, nrc_origin, nrc_dir,
+                      nullptr, n_threads, nullptr, walk_lengths, walks_per_pixel);
 }
 
 /* ---------------------------------------------------------------- nrc/clear.comp:5-9 + nrc/prep_train_rays.comp:7-138

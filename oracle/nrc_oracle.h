@@ -72,6 +72,11 @@ void orc_nrc_gen_rays(const orc_scene* sc, const orc_camera* cam, uint32_t W, ui
                       const float frame_random[4], float* primary_rgba, float* info,
                       float* nrc_origin, float* nrc_dir, float* infer_input,
                       int n_threads, uint64_t* n_fetch);
+/* the same frame, plus per pixel the number of free flights each of its tracking walks drew, in program order (analysis:
+ * tests/walk_model.py); walk_lengths is [H][W][walks_per_pixel], zero-filled by the caller */
+void orc_nrc_walk_lengths(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+                          uint32_t primary_ray_length, float primary_ray_prob, const float frame_random[4], float* primary_rgba,
+                          float* info, float* nrc_origin, float* nrc_dir, int n_threads, uint16_t* walk_lengths, uint32_t walks_per_pixel);
 
 /* nrc/clear.comp + nrc/prep_train_rays.comp, deterministic two-phase ring semantics. */
 void orc_nrc_prep_train(const orc_scene* sc, uint32_t W, uint32_t H, uint32_t TW, uint32_t TH,
