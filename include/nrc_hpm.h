@@ -25,6 +25,8 @@ extern "C" {
 #define NRC_ERR_INVALID (-1)    /* bad argument / unsupported configuration */
 #define NRC_ERR_HIP (-2)        /* a HIP runtime call failed (message holds hipGetErrorString) */
 #define NRC_ERR_STATE (-3)      /* call order violated (e.g. InferAndTrain before Init) */
+#define NRC_ERR_COMM (-4)       /* multi-GPU: a collective failed or a peer did not answer in time; the communicator is aborted (see
+                                 * nrc_cache_comm_status) -- every later call that needs it fails at once, destroy the cache */
 
 const char* nrc_last_error(void);
 const char* nrc_version(void);
@@ -130,6 +132,15 @@ int nrc_comm_unique_id(void* out128);
 int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world);
 /* rank / size as the library's own RCCL communicator reports them (ncclCommUserRank / ncclCommCount); world = 0: none */
 int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world);
+/* Failure detection on the exchange ("RCCL error -> status code").  An enqueued collective reports nothing by itself:
+ * every call into the library that uses the communicator first polls ncclCommGetAsyncError (non-blocking), and every wait of the library
+ * for work that sits behind a collective -- the frame gather, the sharded metrics, nrc_cache_get_loss_blocking, the collective export --
+ * has a deadline (default 30 000 ms once the frame has more than one rank; 0 = wait for ever).  On an asynchronous error, a collective
+ * hook that returns non-zero, or a missed deadline the communicator is aborted (ncclCommAbort: its kernels are killed, nothing is left
+ * hanging on the streams), the call returns NRC_ERR_COMM with the reason, and so does every later call that would need the exchange;
+ * the ranks that still work see the same through their own deadline.  nrc_cache_comm_status: NRC_OK, or NRC_ERR_COMM (polls, never blocks). */
+int nrc_cache_comm_status(nrc_cache_t* c);
+int nrc_cache_set_comm_timeout_ms(nrc_cache_t* c, uint32_t ms);
 /* measurement: *avg_us = average duration of the training step's ncclAllReduce (gradient vector + loss cell, zeroed first), issued
  * `reps` times back to back on the cache's stream; collective -- every rank calls it with the same reps.  0 without a communicator. */
 int nrc_cache_comm_time_exchange(nrc_cache_t* c, uint32_t reps, float* avg_us);

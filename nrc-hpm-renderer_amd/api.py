@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "nrc_cache_grid_grad_pack", "nrc_cache_grid_grad_apply",
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
     "nrc_cache_get_step", "nrc_cache_set_step", "nrc_cache_param_count_tcnn", "nrc_cache_get_params_tcnn", "nrc_cache_set_params_tcnn",
-    "nrc_cache_save_checkpoint", "nrc_cache_load_checkpoint",
+    "nrc_cache_save_checkpoint", "nrc_cache_load_checkpoint", "nrc_cache_comm_status", "nrc_cache_set_comm_timeout_ms",
     "nrc_renderer_create", "nrc_renderer_render", "nrc_renderer_render_frames", "nrc_renderer_set_stage_events", "nrc_renderer_set_camera", "nrc_renderer_set_blend",
     "nrc_renderer_set_scene_params", "nrc_mc_renderer_set_scene_params",
     "nrc_renderer_set_show_nrc", "nrc_renderer_set_frame_random", "nrc_renderer_framebuffer", "nrc_renderer_framebuffer_on",
@@ -149,9 +149,14 @@ def load_library():
     return L
 
 
+class CommError(RuntimeError):
+    """NRC_ERR_COMM: a collective failed or a peer did not answer within the communicator's deadline; the communicator is aborted"""
+
+
 def _check(status):
     if status != 0:
-        raise RuntimeError(load_library().nrc_last_error().decode() or "SkyRenderer ERROR: status %d" % status)
+        msg = load_library().nrc_last_error().decode() or "SkyRenderer ERROR: status %d" % status
+        raise (CommError if status == -4 else RuntimeError)(msg)
 
 
 def _vp(x):
@@ -399,6 +404,19 @@ class NeuralRadianceCache:
 
         self._hook_keep = GRAD_HOOK(tramp)
         _check(self.L.nrc_cache_set_grad_hook(self.h, self._hook_keep, None))
+
+    def CommStatus(self):
+        """nrc_cache_comm_status: raises CommError once the exchange has failed (polls RCCL's asynchronous error state; never blocks)"""
+        _check(self.L.nrc_cache_comm_status(self.h))
+
+    def SetCommTimeoutMs(self, ms):
+        """deadline of the library's waits behind a collective (default 30 000 ms once the frame has more than one rank; 0: none)"""
+        _check(self.L.nrc_cache_set_comm_timeout_ms(self.h, C.c_uint32(int(ms))))
+
+    def SetRawCollectiveHooks(self, rank, world, allreduce, allgather):
+        """nrc_cache_set_collective_hooks with the caller's own ALLREDUCE_F64_HOOK / ALLGATHER_HOOK callables (tests: failing transports)"""
+        self._coll_keep = (ALLREDUCE_F64_HOOK(allreduce), ALLGATHER_HOOK(allgather))
+        _check(self.L.nrc_cache_set_collective_hooks(self.h, C.c_int(rank), C.c_int(world), self._coll_keep[0], self._coll_keep[1], None))
 
     def SetCollectiveHooks(self, rank, world, group=None):
         """the frame gather / metric reduction of a cache WITHOUT a native RCCL communicator go through torch.distributed (any backend:

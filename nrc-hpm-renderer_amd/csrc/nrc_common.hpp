@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -27,7 +28,24 @@ struct HipError : std::runtime_error {
                                   __FILE__ + ":" + std::to_string(__LINE__) + ")");                     \
     } while (0)
 
+// a collective failed, or a peer did not answer within the communicator's deadline: the communicator has been aborted (NRC_ERR_COMM)
+struct CommError : std::runtime_error {
+    explicit CommError(const std::string& m) : std::runtime_error("SkyRenderer ERROR: " + m) {}
+};
+
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// XCDs (accelerator complex dies, each with its own L2) of the current device.  Several launch mappings hand the work of one table level /
+// one screen band to the workgroups of ONE XCD (workgroup b runs on XCD b mod count: round-robin dispatch) -- a placement for speed only,
+// never for correctness; they are written for the MI355X's eight and are switched off on any other count (another partition mode, another chip).
+inline int device_xcds()
+{
+    if (const char* e = getenv("NRC_ASSUME_XCDS")) return atoi(e);      // tests: the paths of a device that does not have eight
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) return 0;
+    return n;
+}
 
 // Every device allocation of the library goes through these two (nrc_api.hip).  Diagnostic environment switches, read once:
 //   NRC_POISON_ALLOC=1  every allocation is filled with 0xFF bytes at creation (fp32 NaN, fp16 NaN, index 0xFFFFFFFF): whatever a

@@ -177,7 +177,6 @@ struct CtxT {
     // raw buffer view of the volume: offsets >= the voxel count read 0, which is the sampler's black border
     __amdgpu_buffer_rsrc_t vol = __builtin_amdgcn_make_buffer_rsrc((void*)sc.density, 0, (int)(sc.nx * sc.ny * sc.nz), 0x00020000);
     const uint32_t* occ = nullptr;      // LDS copy of DevScene::occ_bits (load_occupancy), or nullptr
-    float* grp = nullptr;               // this wave's LDS scratch for the thin trips of the tracking loops (ratio_groups / delta_groups), or nullptr
 #ifdef NRC_LOOP_PROFILE
     uint32_t useful[8] = {0, 0, 0, 0, 0, 0, 0, 0}, issued[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fee_kind = 1;
@@ -692,321 +691,11 @@ __device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool al
 __device__ __forceinline__ bool lane_bool(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ unsigned long long lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
-// ---- thin trips, round 5: L lanes per surviving walk ---------------------------------------------------------------------------
-// The pair tail above halves what a thin trip costs per collision; what it cannot change is that a tracking loop whose last walks are
-// long runs one memory round trip and one full loop body per four collisions for as long as ONE walk lasts (tests/walk_model.py, from
-// the oracle's per-walk free-flight counts of the bench frame: the second vertex's delta loop runs 11.5 wave-level trips for walks of
-// 2.1 trips on average -- 16 % lane utilisation --, the environment walks 21 for 10.5).  Only a walk's hash chain is serial (nine
-// integer operations per draw) -- and its running sums, one fma / one multiply per collision; the logarithms, positions, voxel indices,
-// look-ups and transmittance factors of different collisions are independent.  So when a loop is down to k <= 32 walks each is handed
-// to a GROUP of L = 2^floor(log2(64 / k)) lanes: the record of walk r goes through LDS to lanes r L .. r L + L - 1, and one iteration
-// advances every walk by a CHUNK of 2 Lc collisions (Lc <= L, no wider than the longest surviving walk is expected to need): every lane
-// draws the chunk's chain (lane j keeps draws j + 1 and Lc + j + 1), takes its two logarithms (packed), the free-flight positions are
-// summed in the walk's own order (one ds_bpermute + one fma per collision, by all lanes), each lane locates and looks up its two
-// collisions, and the transmittance factors are multiplied up in the walk's order again.  Per two collisions that is 38 + 130 / Lc
-// instructions against 181 in the main loop -- and a long last walk costs one memory round trip per 2 Lc collisions instead of four.
-// Walks that end leave their result in LDS for their owner lane; when half the groups are empty the survivors are re-dealt to groups
-// of 2 L.  Every walk draws and computes exactly what the one-lane loop does (the sequential sums are replayed in order): bit for bit
-// the same results.  NRC_GROUP_TAIL=0 builds the pair tail instead.
-#ifndef NRC_GROUP_TAIL
-#define NRC_GROUP_TAIL 1
-#endif
-constexpr uint32_t kGrpRecWords = 12, kGrpMaxWalks = 32;
-constexpr uint32_t kGrpWords = kGrpMaxWalks * kGrpRecWords + 64u * 4u;      // walk records + one result slot per owner lane: 2 560 B per wave
-
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// value of lane (gb4 / 4 + idx) -- gb4: byte address of the reader's group base lane, idx wave-uniform
-__device__ __forceinline__ float grp_bcast(float x, uint32_t gb4, uint32_t idx)
-{
-    return nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(gb4 + idx * 4u), (int)nrc_f2u(x)));
-}
-// value of the lane below (lane 0: unspecified) -- DPP wave_shr:1, a register move: the sequential recurrences of a walk (hash chain,
-// free-flight positions, transmittance product) run as SCANS along the lanes of its group: lane j of the group computes element j + 1
-// from lane j - 1's element j, every lane repeats its step until its input has settled, and after Lc steps the first Lc lanes hold
-// elements 1 .. Lc -- each computed by exactly the operations of the sequential walk.
-__device__ __forceinline__ float lane_below(float x)
-{
-    // NEVER call this inside one arm of a conditional expression: `first ? base : lane_below(x)` evaluates the move on the lanes that
-    // are not first only -- a divergent branch in which the lane below a group's second lane is masked off and reads as 0
-    // (tools/scan_probe.hip).  Take the value first, select afterwards.
-    return nrc_u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)nrc_f2u(x), 0x138, 0xf, 0xf, true));
-}
-// number of leading ones of the group's Lc-bit field of two lane masks read as one 2 Lc-bit sequence (first b1's bits, then b2's);
-// bits at and above Lc are zero in both
-__device__ __forceinline__ uint32_t grp_leading(unsigned long long b1, unsigned long long b2, uint32_t gbase, uint32_t Lc)
-{
-    const uint32_t fm = 0xffffffffu >> (32u - Lc);      // (the lanes above Lc of a group of L = Lc lanes belong to the next group)
-    const uint32_t g1 = (uint32_t)(b1 >> gbase) & fm, g2 = (uint32_t)(b2 >> gbase) & fm;
-    const uint32_t k1 = g1 == fm ? Lc : (uint32_t)__builtin_ctz(~g1);
-    const uint32_t k2 = g2 == fm ? Lc : (uint32_t)__builtin_ctz(~g2);
-    return k1 < Lc ? k1 : Lc + k2;
-}
-// chunk half-width for the walks still alive: a power of two in 2 .. L, at least the largest expected number of collisions left
-// (rem, in free-flight lengths) among them -- a chunk wider than the walks need only costs chain draws
-#ifndef NRC_GROUP_CAP
-#define NRC_GROUP_CAP 2.0f      // a chunk of 2 Lc collisions is at most this many times the longest expected remainder
-#endif
-#ifndef NRC_GROUP_ENTER
-#define NRC_GROUP_ENTER 32      // walks alive at which a tracking loop hands over to the groups
-#endif
-__device__ __forceinline__ uint32_t grp_chunk(bool on, float rem, uint32_t L)
-{
-    const float r = rem * (0.5f * (NRC_GROUP_CAP));      // Lc <= r
-    uint32_t Lc = 2u;
-    if (L > 2u && __ballot(on & (r >= 4.0f)) != 0ull) Lc = 4u;
-    if (L > 4u && __ballot(on & (r >= 8.0f)) != 0ull) Lc = 8u;
-    if (L > 8u && __ballot(on & (r >= 16.0f)) != 0ull) Lc = 16u;
-    if (L > 16u && __ballot(on & (r >= 32.0f)) != 0ull) Lc = 32u;
-    return Lc;
-}
-// the (re-)deal: the lanes of `src_m` (owners, or leaders of surviving groups) have written their records at rec[rank]; returns the
-// group shift for k walks
-__device__ __forceinline__ uint32_t grp_shift(uint32_t k)
-{
-    // L = 2^sh with k * L <= 64, at most 32 lanes per walk
-    const uint32_t sh = 31u - (uint32_t)__builtin_clz(64u / k);
-    return sh > 5u ? 5u : sh;
-}
-
-// the surviving walks of a ratio_track loop (see above).  On entry: the lanes of `am` (at most 32) have a walk whose base state is
-// (bs, bt) = (chain value before its next draw, free-flight position before it), n collisions done, transmittance tr.  On exit: tr / rng
-// of those lanes are the finished walks' results.
-template <class C>
-__device__ __forceinline__ void ratio_groups(C& c, unsigned long long am, V3 start, V3 dir, float t_max, float inv, float bs, float bt, uint32_t n,
-                                             float& tr, float& rng)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    float* rec = c.grp;
-    float* res = c.grp + kGrpMaxWalks * kGrpRecWords;
-    const bool alive = lane_bool(am);
-    uint32_t k = (uint32_t)__popcll(am);
-    {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        if (alive) {
-            float4* r4 = reinterpret_cast<float4*>(rec + rank * kGrpRecWords);
-            r4[0] = make_float4(bs, bt, tr, t_max);
-            r4[1] = make_float4(nrc_u2f(n), start.x, start.y, start.z);
-            r4[2] = make_float4(dir.x, dir.y, dir.z, nrc_u2f(lane));
-        }
-    }
-    const float sigma = c.sc.density_factor;
-    for (;;) {      // one pass per deal
-        wave_lds_fence();
-        const uint32_t sh = grp_shift(k), L = 1u << sh;
-        const uint32_t g = lane >> sh, j = lane & (L - 1u), gbase = lane & ~(L - 1u), gb4 = gbase * 4u;
-        bool on = g < k;
-        const float4* r4 = reinterpret_cast<const float4*>(rec + (on ? g : 0u) * kGrpRecWords);
-        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
-        float R0 = ra.x, t0 = ra.y, T = ra.z;
-        const float tm = ra.w;
-        uint32_t nn = nrc_f2u(rb.x);
-        const V3 st = v3(rb.y, rb.z, rb.w), dr = v3(rc.x, rc.y, rc.z);
-        const uint32_t owner = nrc_f2u(rc.w);
-        wave_lds_fence();      // (the records may be rewritten by the next deal)
-        uint32_t ka;
-        for (;;) {
-            const uint32_t Lc = grp_chunk(on, (tm - t0) * sigma, L);
-            NRC_PROF_LIVE(1, __ballot(on & (j == 0u)));
-            // the chunk's chain as two scans: lane j ends up with draws j + 1 and Lc + j + 1
-            const bool first = j == 0u;
-            float s1 = R0, s2;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(s1); s1 = random1(first ? R0 : lb); }
-            const float Rm = grp_bcast(s1, gb4, Lc - 1u);
-            s2 = Rm;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(s2); s2 = random1(first ? Rm : lb); }
-            const float R = grp_bcast(s2, gb4, Lc - 1u);
-            const f2 l = logf2(f2{1.0f - s1, 1.0f - s2});
-            // free-flight positions in the walk's order (scans again)
-            float t1 = t0, t2;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(t1); t1 = nrc_fmaf_(-l.x, inv, first ? t0 : lb); }
-            const float tmid = grp_bcast(t1, gb4, Lc - 1u);
-            t2 = tmid;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(t2); t2 = nrc_fmaf_(-l.y, inv, first ? tmid : lb); }
-            const float t = grp_bcast(t2, gb4, Lc - 1u);
-            // collision d (1-based in the chunk) belongs to the walk while every draw up to it was made (128 in all) and lies inside the segment
-            const bool inc = on & (j < Lc);
-            const bool v1 = inc & (nn + j + 1u <= 128u) & !(t1 >= tm);
-            const bool v2 = inc & (nn + Lc + j + 1u <= 128u) & !(t2 >= tm);
-            const uint32_t K = grp_leading(__ballot(v1), __ballot(v2), gbase, Lc);      // collisions 1 .. K of the chunk are the walk's
-            const bool m1 = inc & (j < K), m2 = inc & (Lc + j < K);
-            const Addr2 ad = fetch2_addr(c, dr, st, t1, t2, m1, m2);
-            const Fetch2 fa = fetch2_load(c, ad);
-            const f2 dens = fetch2_density(c.sc, fa);
-            // transmittance in the walk's order: the factors of the walk's collisions, exactly 1 beyond them (x * 1 = x)
-            const float f1 = m1 ? nrc_fmaf_(-dens.x, inv, 1.0f) : 1.0f, f2_ = m2 ? nrc_fmaf_(-dens.y, inv, 1.0f) : 1.0f;
-            c.count((on & first) ? K : 0u);
-            float P = T;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(P); P = (first ? T : lb) * f1; }
-            T = grp_bcast(P, gb4, Lc - 1u);
-            if (__ballot(on & (K > Lc)) != 0ull) {
-                P = T;
-                for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(P); P = (first ? T : lb) * f2_; }
-                T = grp_bcast(P, gb4, Lc - 1u);
-            }
-            // the last draw made (1-based): the whole chunk when no collision ended the walk; else draw K + 1 (beyond the segment)
-            // unless the 128-collision cap ended it with draw K
-            const bool whole = K == 2u * Lc;
-            const uint32_t d_last = whole ? 2u * Lc : (nn + K + 1u <= 128u ? K + 1u : K);
-            const uint32_t li = d_last - 1u;      // (d_last >= 1: a walk that is on has made fewer than 128 draws)
-            const bool second = li >= Lc;
-            const uint32_t src4 = gb4 + (second ? li - Lc : li) * 4u;
-            const float ra1 = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)nrc_f2u(s1)));
-            const float ra2 = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)nrc_f2u(s2)));
-            const bool cont = on & whole & (nn + 2u * Lc < 128u);
-            if (on & !cont & (j == 0u)) {
-                float2* o2 = reinterpret_cast<float2*>(res + owner * 4u);
-                *o2 = make_float2(T, second ? ra2 : ra1);
-            }
-            on = cont;
-            nn += 2u * Lc;
-            R0 = R;
-            t0 = t;
-            const unsigned long long lm = __ballot(on & (j == 0u));
-            ka = (uint32_t)__popcll(lm);
-            if (ka == 0u || (L < 32u && ka * 2u * L <= 64u)) {
-                if (ka != 0u && on && j == 0u) {      // re-deal: the leaders of the surviving groups write their records
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    float4* w4 = reinterpret_cast<float4*>(rec + rank * kGrpRecWords);
-                    w4[0] = make_float4(R0, t0, T, tm);
-                    w4[1] = make_float4(nrc_u2f(nn), st.x, st.y, st.z);
-                    w4[2] = make_float4(dr.x, dr.y, dr.z, nrc_u2f(owner));
-                }
-                break;
-            }
-        }
-        if (ka == 0u) break;
-        k = ka;
-    }
-    wave_lds_fence();
-    if (alive) {
-        const float2 r = *reinterpret_cast<const float2*>(res + lane * 4u);
-        tr = r.x;
-        rng = r.y;
-    }
-}
-
-// the surviving walks of a delta_track loop, L lanes per walk (see ratio_groups): a chunk is 2 Lc tentative collisions = 4 Lc draws (flight,
-// acceptance, flight, ...); every collision of the chunk that lies inside the segment is looked up -- the walk's own look-ups are those
-// up to its first accepted collision, the others are speculative and discarded.  On exit rng / hit / t_hit / vexit of the lanes of `am`
-// are what the one-lane loop leaves.
-template <class C>
-__device__ __forceinline__ void delta_groups(C& c, unsigned long long am, V3 ro, V3 rd, float t_max, float inv, float bs, float bt, uint32_t n,
-                                             float& rng, bool& hit, float& t_hit, bool& vexit)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    float* rec = c.grp;
-    float* res = c.grp + kGrpMaxWalks * kGrpRecWords;
-    const bool alive = lane_bool(am);
-    uint32_t k = (uint32_t)__popcll(am);
-    {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        if (alive) {
-            float4* r4 = reinterpret_cast<float4*>(rec + rank * kGrpRecWords);
-            r4[0] = make_float4(bs, bt, nrc_u2f(lane), t_max);
-            r4[1] = make_float4(nrc_u2f(n), ro.x, ro.y, ro.z);
-            r4[2] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-        }
-    }
-    const float sigma = c.sc.density_factor;
-    for (;;) {
-        wave_lds_fence();
-        const uint32_t sh = grp_shift(k), L = 1u << sh;
-        const uint32_t g = lane >> sh, j = lane & (L - 1u), gbase = lane & ~(L - 1u), gb4 = gbase * 4u;
-        bool on = g < k;
-        const float4* r4 = reinterpret_cast<const float4*>(rec + (on ? g : 0u) * kGrpRecWords);
-        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
-        float R0 = ra.x, t0 = ra.y;
-        const uint32_t owner = nrc_f2u(ra.z);
-        const float tm = ra.w;
-        uint32_t nn = nrc_f2u(rb.x);
-        const V3 o = v3(rb.y, rb.z, rb.w), dv = v3(rc.x, rc.y, rc.z);
-        wave_lds_fence();
-        uint32_t ka;
-        for (;;) {
-            const uint32_t Lc = grp_chunk(on, (tm - t0) * sigma, L);
-            NRC_PROF_LIVE(2, __ballot(on & (j == 0u)));
-            // 4 Lc draws -- flight and acceptance of collisions 1 .. 2 Lc -- as two scans: lane j ends up with those of collisions j + 1 and Lc + j + 1
-            const bool first = j == 0u;
-            float s1 = R0, a1 = R0, s2, a2;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(a1); s1 = random1(first ? R0 : lb); a1 = random1(s1); }
-            const float Rm = grp_bcast(a1, gb4, Lc - 1u);
-            s2 = a2 = Rm;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(a2); s2 = random1(first ? Rm : lb); a2 = random1(s2); }
-            const float R = grp_bcast(a2, gb4, Lc - 1u);
-            const f2 l = logf2(f2{1.0f - s1, 1.0f - s2});
-            float t1 = t0, t2;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(t1); t1 = nrc_fmaf_(-l.x, inv, first ? t0 : lb); }
-            const float tmid = grp_bcast(t1, gb4, Lc - 1u);
-            t2 = tmid;
-            for (uint32_t d = 0; d < Lc; d++) { const float lb = lane_below(t2); t2 = nrc_fmaf_(-l.y, inv, first ? tmid : lb); }
-            const float t = grp_bcast(t2, gb4, Lc - 1u);
-            const bool inc = on & (j < Lc);
-            const bool v1 = inc & (nn + j + 1u <= 128u) & !(t1 >= tm);
-            const bool v2 = inc & (nn + Lc + j + 1u <= 128u) & !(t2 >= tm);
-            const uint32_t Kin = grp_leading(__ballot(v1), __ballot(v2), gbase, Lc);      // collisions 1 .. Kin: flight made and inside the segment
-            const bool m1 = inc & (j < Kin), m2 = inc & (Lc + j < Kin);
-            const Addr2 ad = fetch2_addr(c, dv, o, t1, t2, m1, m2);
-            const Fetch2 fa = fetch2_load(c, ad);
-            const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
-            // rejected while dens <= a (path_trace.glsl:168): the walk accepts its first collision among 1 .. Kin that is not rejected
-            const bool r1 = m1 & !(dens.x > a1), r2 = m2 & !(dens.y > a2);
-            const uint32_t Krej = grp_leading(__ballot(r1), __ballot(r2), gbase, Lc);      // collisions 1 .. Krej were rejected (Krej <= Kin)
-            const bool accepted = Krej < Kin;
-            c.count((on & (j == 0u)) ? (accepted ? Krej + 1u : Kin) : 0u);
-            // how the chunk ends for the walk, and the draw that ended it:
-            //   accepted collision Krej + 1: its acceptance draw;  else flight Kin + 1 made (nn + Kin + 1 <= 128) and beyond the exit: that flight
-            //   draw, volume exit;  else the 128-collision cap with the chunk's collision Kin: its acceptance draw;  else the walk goes on
-            const bool whole = !accepted & (Kin == 2u * Lc);
-            const bool exits = !accepted & !whole & (nn + Kin + 1u <= 128u);
-            const uint32_t ci = accepted ? Krej : (exits ? Kin : Kin - 1u);      // 0-based collision whose draw is the last one
-            const uint32_t cj = whole ? 2u * Lc - 1u : ci;                       // (capped walk with Kin == 0 cannot happen: on => nn < 128)
-            const bool second = cj >= Lc;
-            const uint32_t src4 = gb4 + (second ? cj - Lc : cj) * 4u;
-            const float vs = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)nrc_f2u(second ? s2 : s1)));
-            const float va = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)nrc_f2u(second ? a2 : a1)));
-            const float vt = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)nrc_f2u(second ? t2 : t1)));
-            const bool cont = on & whole & (nn + 2u * Lc < 128u);
-            if (on & !cont & (j == 0u)) {
-                float4* o4 = reinterpret_cast<float4*>(res + owner * 4u);
-                *o4 = make_float4(exits ? vs : va, vt, nrc_u2f((accepted ? 1u : 0u) | (exits ? 2u : 0u)), 0.0f);
-            }
-            on = cont;
-            nn += 2u * Lc;
-            R0 = R;
-            t0 = t;
-            const unsigned long long lm = __ballot(on & (j == 0u));
-            ka = (uint32_t)__popcll(lm);
-            if (ka == 0u || (L < 32u && ka * 2u * L <= 64u)) {
-                if (ka != 0u && on && j == 0u) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    float4* w4 = reinterpret_cast<float4*>(rec + rank * kGrpRecWords);
-                    w4[0] = make_float4(R0, t0, nrc_u2f(owner), tm);
-                    w4[1] = make_float4(nrc_u2f(nn), o.x, o.y, o.z);
-                    w4[2] = make_float4(dv.x, dv.y, dv.z, 0.0f);
-                }
-                break;
-            }
-        }
-        if (ka == 0u) break;
-        k = ka;
-    }
-    wave_lds_fence();
-    if (alive) {
-        const float4 r = *reinterpret_cast<const float4*>(res + lane * 4u);
-        const uint32_t fl = nrc_f2u(r.z);
-        rng = r.x;
-        hit = (fl & 1u) != 0u;
-        t_hit = hit ? r.y : t_hit;
-        vexit = (fl & 2u) != 0u;
-    }
-}
-
-
+// Round 5 measured the next step of that idea and took it out again (commit 4f700df has the code; DESIGN.md section 4 "Lane groups"): every
+// surviving walk on a GROUP of L = 2^floor(log2(64 / walks alive)) lanes, chunks of 2 Lc collisions per iteration, the walk's serial
+// recurrences (hash chain, free-flight sums, transmittance product) as DPP wave_shr:1 scans along the group (tools/scan_probe.hip,
+// tools/dpp_probe.hip).  Bit-exact at the first run of every oracle comparison -- and slower than the pair tail on every preset
+// (k_gen_rays alone 0.2111 -> 0.2138 ... 0.2181 ms by entry threshold, frame - 5 %, configs[4] - 4.7 %, Monte-Carlo renderer - 1.5 %).
 #if NRC_TRACK_MASKS
 template <bool UNI = false, class C>
 __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
@@ -1030,14 +719,7 @@ __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid 
 #else
         if (alive_m == 0ull) break;
 #endif
-#if NRC_GROUP_TAIL
-        if constexpr (UNI) {
-            if (__popcll(alive_m) <= (NRC_GROUP_ENTER)) {        // few walks left: a group of lanes each (ratio_groups)
-                ratio_groups(c, alive_m, start, dir, t_max, inv, bs, bt, i, tr, rng);
-                break;
-            }
-        }
-#elif NRC_PAIR_TAIL
+#if NRC_PAIR_TAIL
         if constexpr (UNI) {
             if (__popcll(alive_m) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
                 ratio_pairs(c, alive_m, lane_bool(alive_m), start, dir, t_max, inv, bs, bt, i, tr, rng);
@@ -1419,17 +1101,7 @@ __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit,
 #else
         if (alive_m == 0ull) break;
 #endif
-#if NRC_GROUP_TAIL
-        if constexpr (UNI) {
-            if (__popcll(alive_m) <= (NRC_GROUP_ENTER)) {        // few walks left: a group of lanes each (delta_groups)
-                bool hit = lane_bool(hit_m), vexit = lane_bool(vexit_m);
-                delta_groups(c, alive_m, ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
-                hit_m = lane_mask(hit);
-                vexit_m = lane_mask(vexit);
-                break;
-            }
-        }
-#elif NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
+#if NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
         if constexpr (UNI) {
             if (__popcll(alive_m) <= 31) {        // few walks left: two lanes each (delta_pairs)
                 bool hit = lane_bool(hit_m), vexit = lane_bool(vexit_m);
@@ -1933,7 +1605,6 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     bool inside, hot_wave;
     uint32_t part = 0;
     if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave, &part)) return;
-    __shared__ __align__(16) float s_grp[CAMERA_WAVES_PER_BLOCK][kGrpWords];
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
@@ -1989,7 +1660,6 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         }
     }
     c.occ = load_occupancy_per_wave(sc, s_occ);
-    c.grp = s_grp[threadIdx.x >> 6];
     // Wave-uniform control flow with per-lane predicates from here to the stores: a lane whose path has ended (or that has none)
     // stays in the instruction stream, so that the tracking loops can hand the last walks to lane pairs (ratio_pairs).
     V3 ro, rd;
@@ -2144,9 +1814,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave, &part)) return;
     CtxT<COUNT> c{sc, 0.0f, 0u};
     c.occ = occ;
-    __shared__ __align__(16) float s_grp[CAMERA_WAVES_PER_BLOCK][kGrpWords];
-    c.grp = s_grp[threadIdx.x >> 6];
-    // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane groups)
+    // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
     const uint32_t gx = global_x(fr, lx);
     const float u = (float)gx * fr.inv_gw, v = (float)y * fr.inv_gh;
     V3 ro, rd;
@@ -2433,8 +2101,6 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     const uint32_t i = in_grid ? ty * tg.tw + tx : 0u;
     CtxT<false> c{sc, 0.0f, 0u};
     c.occ = occ;
-    __shared__ __align__(16) float s_grp[4][kGrpWords];
-    c.grp = s_grp[wave];
     // seed from TRAIN coordinates over the render size (quirk Q6, prep_train_rays.comp:108); sharded: global column
     const uint32_t gx = global_x(fr, tx);
     init_random(c, (float)gx * fr.inv_gw, (float)ty * fr.inv_gh, fr.random);

@@ -2549,6 +2549,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
     // fragment entries, so they stay exactly 0 through ReLU and contribute exactly 0 downstream; the parameter vector, gradients
     // and optimizer see the true 16-wide shapes (half of the MFMA work is padding: the model is 10x cheaper than 6x64 anyway)
     kw_ = width_ < 32 ? 32 : width_;
+    xcd8_ = device_xcds() == 8;
     if (depth_ < 1 || depth_ > 16) fail("nnDepth must be in 1..16 (got " + std::to_string(depth_) + ")");
     if (std::strcmp(cfg.optimizer, "Adam") == 0) sgd_ = false;
     else if (std::strcmp(cfg.optimizer, "SGD") == 0) sgd_ = true;
@@ -2813,7 +2814,7 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
         dim3 g((uint32_t)num_cus() * 2u, n_slots);
         uint32_t xc = 0;
         static const bool level_major = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD gathers from every level
-        if (!level_major && n_slots % 8u == 0u) {      // a level's table is gathered from one XCD (see the kernel)
+        if (!level_major && xcd8_ && n_slots % 8u == 0u) {      // a level's table is gathered from one XCD (see the kernel)
             xc = (uint32_t)num_cus() * 2u;               // chunks of the list per slot: as many workgroups per slot as before
             g = dim3(8u * xc * (n_slots / 8u), 1);
         }
@@ -2830,7 +2831,8 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
         else hipLaunchKernelGGL(k_encode_hash_lm<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, sk);
         return;
     }
-    static const bool level_major2 = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;
+    static const bool level_major_env = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;
+    const bool level_major2 = level_major_env || !xcd8_;      // (the level-per-XCD mapping is written for eight XCDs)
     const dim3 g(level_major2 ? ceil_div(n * 16u, 256) : ceil_div(n, 128) * 8u);
     const int mode = (skip_zero ? 1 : 0) | (level_major2 ? 0 : 2);
     if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, mode);
@@ -3323,7 +3325,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
                     NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB_BIN * 8u)));
                     attr_gather_set_ = true;
                 }
-                static const bool level_major = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD works on every level
+                static const bool level_major_env = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD works on every level
+                const bool level_major = level_major_env || !xcd8_;
                 hipLaunchKernelGGL(k_grid_scatter, level_major ? dim3(ceil_div(n, 256), HG_LEVELS) : dim3(ceil_div(n, 256) * HG_LEVELS, 1), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (uint32_t*)d_grad16_, n, lv,
                                    gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_, skip_levels);
                 hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_), dim3(NRC_GB_GATHER_THREADS), GB_BIN * 8u, s, (uint32_t*)d_grad16_, grid_bin_cap_,

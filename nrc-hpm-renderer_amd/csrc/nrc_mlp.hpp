@@ -105,6 +105,7 @@ private:
     int infer_set_ = 0;          // which of the double-buffered inference (EMA) image / table sets is current
     uint32_t n_mlp_ = 0;         // matrix parameters; (posID 0) the hash-grid table [entry][2] follows them in every vector
     bool hash_ = false;
+    bool xcd8_ = true;           // the device has eight XCDs: the level-per-XCD launch mappings of the HashGrid kernels apply
     uint32_t hg_off_[17] = {0};  // per-level entry offsets
     uint32_t n_grid_entries_ = 0;
     void *d_t16_train_ = nullptr, *d_t16_ema_[2] = {nullptr, nullptr};   // half2-per-entry gather copies of the table

@@ -112,6 +112,9 @@ def test_bench_self_launches_its_ranks(torch_gpu):
     # hundreds of milliseconds when the host is busy --: the line's arithmetic and labels are what is checked)
     assert c4["scaling"] == "strong" and c4["value"] > 1 and "1920 columns per rank" in c4["workload"] and "8192 per rank" in c4["workload"]
     assert abs(c4["ms_per_step"] - 3840 * 2160 * 8 / c4["value"] / 1e3) < 1e-6 * c4["ms_per_step"] + 1e-9
+    s2 = d["strong_scaling_1080p"]                   # the metric's own 1920x1080 frame split over the two ranks
+    assert s2["scaling"] == "strong" and s2["value"] > 1 and "960 columns per rank" in s2["workload"] and "8192 per rank" in s2["workload"]
+    assert abs(s2["ms_per_step"] - 1920 * 1080 * 4 / s2["value"] / 1e3) < 1e-6 * s2["ms_per_step"] + 1e-9
 
 
 @pytest.mark.gpu
