@@ -1181,54 +1181,53 @@ __global__ __launch_bounds__(256) void k_encode_hash_list(const float* __restric
     }
 }
 
-// dL/d(table): every (sample, level) scatters weight * dL/d(feature) to its 8 corners with one packed fp16 atomic per corner
-// (global_atomic_pk_add_f16 on a half2-per-entry table: tiny-cuda-nn does the same for 2 features per level; the values carry
-// the loss scale).  The sum order, hence the last bits, vary from run to run -- unlike the MLP's slab reduction.
-// k_grid_grad_f32 then widens the table into the fp32 gradient vector (what the all-reduce and the optimizer read).
-__global__ __launch_bounds__(256) void k_grid_backward(const float* __restrict__ in, const half_t* __restrict__ d_enc,
-                                                      uint32_t* __restrict__ grad16, uint32_t n, HashLevels lv, uint32_t diag_skip_levels)
-{
-    NRC_RAISE_WAVE_PRIORITY(1);
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t sample = gid >> 4, level = gid & 15u;
-    if (sample >= n) return;
-    if ((diag_skip_levels >> level) & 1u) return;      // DIAGNOSTIC (NRC_DIAG_GRID_SKIP_LEVELS, wrong gradients): what a level's atomics cost
-    const float de0 = (float)d_enc[(size_t)sample * 32u + 2u * level], de1 = (float)d_enc[(size_t)sample * 32u + 2u * level + 1u];
-    if (de0 == 0.0f && de1 == 0.0f) return;
-    const float* p = in + (size_t)sample * 5u;
-    const float x[3] = {p[0], p[1], p[2]};
-    uint32_t idx[8];
-    float w8[8];
-    hg_corners(lv, level, x, idx, w8);
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const float2v g = {w8[c] * de0, w8[c] * de1};
-        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(grad16 + idx[c]),
-                                                  __builtin_convertvector(g, half2v));
-    }
-}
-
-// ---- round 4: the table gradient of the large levels without memory-side atomics (k_grid_scatter + k_grid_gather).
-// k_grid_backward's 2.1 M packed-fp16 atomics per step execute at the memory side -- 112 us alone, and beside the frame they cost it 41 %
-// (NRC_DIAG_GRID_SKIP_LEVELS=0xffff: 3 060 -> 4 320 Msamples/s; gen_rays 0.62 -> 0.46 ms).  A level of at least 8 x 4 096 entries is cut
-// into BINS of 4 096 entries: pass 1 (one level and 256 samples per workgroup) appends its (entry, value) pairs to the level's bin
-// lists -- a per-workgroup LDS histogram, ONE global atomic per (workgroup, non-empty bin) to reserve the run --, pass 2 (one workgroup per
-// bin) adds a bin's pairs into 32 KB of fp32 accumulators in LDS and stores the entries that were touched.  The coarse levels (fewer than 8
-// bins) and whatever does not fit a bin's list keep the atomics.  Values are the same fp16-rounded products; they are summed in fp32 and
-// rounded once (the atomics round every partial sum to fp16).  The bin size is a residency matter: with bins of 16 384 entries (128 KB of
-// LDS per gather workgroup) the frame gained 2.6 %, with 4 096 another 6 % -- the workgroups find room on CUs that gen_rays occupies.
+// ---- dL/d(table): every (sample, level) sends weight * dL/d(feature) -- rounded to fp16 pairs, as tiny-cuda-nn's packed atomics do (the
+// values carry the loss scale) -- to its 8 corners.
+// Round 4 (k_grid_scatter + k_grid_gather): no memory-side float atomics for the large levels.  2.1 M packed-fp16 atomics per step took 112 us
+// alone and cost the frame beside them 41 %.  A level of at least 8 x 2 048 entries is cut into BINS of 2 048 entries (4 096 in round 4): pass 1 (one level and
+// 256 samples per workgroup) appends its (entry, value) pairs to the level's bin lists -- a per-workgroup LDS histogram, ONE global atomic per
+// (workgroup, non-empty bin) to reserve the run --, pass 2 (one workgroup per bin) adds a bin's pairs into accumulators in LDS and stores the
+// entries that were touched.  The bin size is a residency matter: with bins of 16 384 entries (128 KB of LDS per gather workgroup) the frame
+// gained 2.6 %, with 4 096 another 6 % -- the workgroups find room on CUs that gen_rays occupies.
+// Round 5: the sums are EXACT, hence independent of the order the pairs arrive in -- the table gradient, and with it HashGrid training, is
+// bitwise repeatable (test_backward_is_bitwise_reproducible[hashgrid]).  An fp16 value is an integer multiple of 2^-24 below
+// 2^16: as a 64-bit fixed-point number it adds without rounding, and integer addition is associative.  The LDS accumulators are int64 (bins
+// of 2 048 entries now: the same 32 KB), what does not go through a bin list -- the levels too small for bins, pairs
+// beyond a list's capacity -- is added with 64-bit integer atomics into a fixed-point shadow of the table (all zero between two steps: the
+// gather pass folds it into the entries it finishes and clears it), and every entry is rounded ONCE, from its exact sum, to the fp16 pair
+// the optimizer and the list exchange read (round 4 summed in fp32 in arrival order; tiny-cuda-nn's atomics round every partial sum).
+// A list holds twice the pairs the level sends a bin on average (a dense coarse level's bins are crowded: 16 384 pairs each for 32^3).
 #ifndef NRC_GB_BIN_LOG2
-#define NRC_GB_BIN_LOG2 12
+#define NRC_GB_BIN_LOG2 11
 #endif
 #ifndef NRC_GB_GATHER_THREADS
 #define NRC_GB_GATHER_THREADS 512
 #endif
 constexpr uint32_t GB_BIN_LOG2 = NRC_GB_BIN_LOG2, GB_BIN = 1u << GB_BIN_LOG2, GB_MAX_BINS = 1u << (20 - NRC_GB_BIN_LOG2), GB_MIN_BINS = 8;
 struct GridBins {
-    uint32_t first[HG_LEVELS], count[HG_LEVELS];      // per level: index of its first bin, number of bins (0: the level keeps the atomics)
-    uint32_t cap;                                     // pairs a bin's list holds
+    uint32_t first[HG_LEVELS], count[HG_LEVELS];      // per level: index of its first bin, number of bins (0: no lists, the level adds into the shadow)
+    uint32_t cap[HG_LEVELS], list0[HG_LEVELS];        // pairs a bin's list holds; pair offset of the level's first list
 };
-__global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ in, const half_t* __restrict__ d_enc, uint32_t* __restrict__ grad16,
+// fp16 bits -> value * 2^24 (exact; inf / nan read as 2^15 * 2^25: deterministic, and the loss is not finite then anyway)
+__device__ __forceinline__ long long half_to_fix(uint32_t h)
+{
+    const uint32_t e = (h >> 10) & 31u, f = h & 1023u;
+    const unsigned long long m = e ? (1024u | f) : f;
+    const long long v = (long long)(m << (e ? e - 1u : 0u));
+    return (h & 0x8000u) ? -v : v;
+}
+__device__ __forceinline__ uint32_t fix_to_half2(long long a0, long long a1)
+{
+    const float2v a = {(float)a0 * 5.9604644775390625e-8f, (float)a1 * 5.9604644775390625e-8f};      // x 2^-24
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(a, half2v));
+}
+__device__ __forceinline__ void fix_add_global(long long* __restrict__ fix, uint32_t entry, uint32_t hbits2)
+{
+    const uint32_t h0 = hbits2 & 0xffffu, h1 = hbits2 >> 16;
+    if ((h0 & 0x7fffu) != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(fix + 2 * (size_t)entry), (unsigned long long)half_to_fix(h0));
+    if ((h1 & 0x7fffu) != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(fix + 2 * (size_t)entry + 1), (unsigned long long)half_to_fix(h1));
+}
+__global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ in, const half_t* __restrict__ d_enc, long long* __restrict__ fix,
                                                      uint32_t n, HashLevels lv, GridBins gb, uint32_t* __restrict__ counters,
                                                      uint2* __restrict__ lists, uint32_t diag_skip_levels)
 {
@@ -1245,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ 
         level = blockIdx.y; sample = blockIdx.x * 256u + threadIdx.x;
     }
     const uint32_t nb = gb.count[level];              // (workgroup-uniform)
-    if (threadIdx.x < GB_MAX_BINS) s_cnt[threadIdx.x] = 0u;
+    for (uint32_t i = threadIdx.x; i < GB_MAX_BINS; i += 256u) s_cnt[i] = 0u;
     __syncthreads();
     bool act = sample < n && ((diag_skip_levels >> level) & 1u) == 0u;
     float de0 = 0.0f, de1 = 0.0f;
@@ -1267,56 +1266,92 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ 
             for (int c = 0; c < 8; c++) slot[c] = atomicAdd(&s_cnt[(idx[c] - lv.off[level]) >> GB_BIN_LOG2], 1u);
         }
         __syncthreads();
-        if (threadIdx.x < nb) {
-            const uint32_t k = s_cnt[threadIdx.x];
-            s_base[threadIdx.x] = k != 0u ? atomicAdd(&counters[gb.first[level] + threadIdx.x], k) : 0u;
+        for (uint32_t i = threadIdx.x; i < nb; i += 256u) {
+            const uint32_t k = s_cnt[i];
+            s_base[i] = k != 0u ? atomicAdd(&counters[gb.first[level] + i], k) : 0u;
         }
         __syncthreads();
     }
     if (!act) return;
+    const uint32_t cap = gb.cap[level];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const float2v g = {w8[c] * de0, w8[c] * de1};
-        const half2v gh = __builtin_convertvector(g, half2v);
+        const uint32_t gh = __builtin_bit_cast(uint32_t, __builtin_convertvector(g, half2v));
         if (nb != 0u) {
             const uint32_t bin = (idx[c] - lv.off[level]) >> GB_BIN_LOG2;
             const uint32_t pos = s_base[bin] + slot[c];
-            if (pos < gb.cap) {
-                lists[(size_t)(gb.first[level] + bin) * gb.cap + pos] = make_uint2(idx[c], __builtin_bit_cast(uint32_t, gh));
+            if (pos < cap) {      // (which pairs of a crowded bin miss its list depends on the order of arrival; the entry's exact sum does not)
+                lists[(size_t)gb.list0[level] + (size_t)bin * cap + pos] = make_uint2(idx[c], gh);
                 continue;
             }
         }
-        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(grad16 + idx[c]), gh);
+        fix_add_global(fix, idx[c], gh);
     }
 }
-// pass 2: one workgroup per bin; bin_entry0[b] = table entry of the bin's first slot; resets the bin's counter for the next step
-__global__ __launch_bounds__(NRC_GB_GATHER_THREADS) void k_grid_gather(uint32_t* __restrict__ grad16, uint32_t cap, const uint32_t* __restrict__ bin_entry0,
-                                                    uint32_t* __restrict__ counters, const uint2* __restrict__ lists)
+// pass 2.  Workgroups 0 .. n_bins - 1: one bin each -- bin_info[b] = {table entry of the bin's first slot, pair offset of its list, the list's
+// capacity, 0}; resets the bin's counter for the next step.  The workgroups behind them walk the entries of the levels WITHOUT bins
+// (loose[k] = {first entry, count}, n_loose ranges, GB_BIN entries per workgroup) and turn their shadow sums into the gradient.
+struct LooseRanges {
+    uint32_t first[HG_LEVELS], count[HG_LEVELS], n;
+};
+__global__ __launch_bounds__(NRC_GB_GATHER_THREADS) void k_grid_gather(uint32_t* __restrict__ grad16, const uint4* __restrict__ bin_info, uint32_t n_bins,
+                                                    uint32_t* __restrict__ counters, const uint2* __restrict__ lists, long long* __restrict__ fix,
+                                                    LooseRanges loose)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
-    extern __shared__ float s_acc[];      // [GB_BIN][2]
+    extern __shared__ long long s_acc[];      // [GB_BIN][2]
     const uint32_t b = blockIdx.x;
+    if (b >= n_bins) {      // entries of the levels without bins: shadow -> gradient
+        uint32_t chunk = b - n_bins;
+        for (uint32_t r = 0; r < loose.n; r++) {
+            const uint32_t chunks = (loose.count[r] + GB_BIN - 1u) / GB_BIN;
+            if (chunk < chunks) {
+                const uint32_t end = loose.first[r] + loose.count[r];
+                for (uint32_t e = loose.first[r] + chunk * GB_BIN + threadIdx.x; e < min(end, loose.first[r] + (chunk + 1u) * GB_BIN); e += (uint32_t)NRC_GB_GATHER_THREADS) {
+                    const long long a0 = fix[2 * (size_t)e], a1 = fix[2 * (size_t)e + 1];
+                    if ((a0 | a1) == 0) continue;
+                    fix[2 * (size_t)e] = 0;
+                    fix[2 * (size_t)e + 1] = 0;
+                    grad16[e] = fix_to_half2(a0, a1);
+                }
+                return;
+            }
+            chunk -= chunks;
+        }
+        return;
+    }
     const uint32_t total = counters[b];
-    if (total == 0u) return;              // (workgroup-uniform)
-    for (uint32_t i = threadIdx.x; i < GB_BIN * 2u; i += (uint32_t)NRC_GB_GATHER_THREADS) s_acc[i] = 0.0f;
+    if (total == 0u) return;              // (workgroup-uniform; nothing was added to the shadow for this bin either: a list fills before it overflows)
+    const uint4 info = bin_info[b];
+    const uint32_t e0 = info.x, cap = info.z;
+    const uint32_t cnt = total < cap ? total : cap;
+    const bool overflow = total > cap;    // some of the bin's pairs went to the shadow
+    const uint2* L = lists + info.y;
+    for (uint32_t i = threadIdx.x; i < GB_BIN * 2u; i += (uint32_t)NRC_GB_GATHER_THREADS) s_acc[i] = 0;
     __syncthreads();
-    const uint32_t cnt = total < cap ? total : cap, e0 = bin_entry0[b];
-    const uint2* L = lists + (size_t)b * cap;
     for (uint32_t i = threadIdx.x; i < cnt; i += (uint32_t)NRC_GB_GATHER_THREADS) {
         const uint2 pr = L[i];
-        const half2v h = __builtin_bit_cast(half2v, pr.y);
-        const uint32_t local = (pr.x - e0) & (GB_BIN - 1u);
-        atomicAdd(&s_acc[2u * local], (float)h[0]);
-        atomicAdd(&s_acc[2u * local + 1u], (float)h[1]);
+        const uint32_t li = (pr.x - e0) & (GB_BIN - 1u);
+        const uint32_t h0 = pr.y & 0xffffu, h1 = pr.y >> 16;
+        if ((h0 & 0x7fffu) != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(&s_acc[2u * li]), (unsigned long long)half_to_fix(h0));
+        if ((h1 & 0x7fffu) != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(&s_acc[2u * li + 1u]), (unsigned long long)half_to_fix(h1));
     }
     __syncthreads();
-    const bool overflow = total > cap;    // some of the bin's pairs went to the table with atomics: add, do not store
     for (uint32_t i = threadIdx.x; i < GB_BIN; i += (uint32_t)NRC_GB_GATHER_THREADS) {
-        const float2v a = {s_acc[2u * i], s_acc[2u * i + 1u]};
-        if (a[0] == 0.0f && a[1] == 0.0f) continue;
-        const half2v gh = __builtin_convertvector(a, half2v);
-        if (overflow) __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(grad16 + e0 + i), gh);
-        else grad16[e0 + i] = __builtin_bit_cast(uint32_t, gh);
+        const uint32_t e = e0 + i;
+        long long a0 = s_acc[2u * i], a1 = s_acc[2u * i + 1u];
+        if (overflow) {
+            const long long f0 = fix[2 * (size_t)e], f1 = fix[2 * (size_t)e + 1];
+            if ((f0 | f1) != 0) {
+                fix[2 * (size_t)e] = 0;
+                fix[2 * (size_t)e + 1] = 0;
+                a0 += f0;
+                a1 += f1;
+            }
+        }
+        if ((a0 | a1) == 0) continue;
+        grad16[e] = fix_to_half2(a0, a1);
     }
     if (threadIdx.x == 0u) counters[b] = 0u;
 }
@@ -2742,7 +2777,7 @@ Mlp::~Mlp()
     if (d_dst_) dev_free(d_dst_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
                     d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_tasks_, d_feat_[0], d_feat_[1], d_t16_train_,
-                    d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_, d_grid_lists_, d_grid_counters_, d_grid_bin_entry0_};
+                    d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_, d_grid_lists_, d_grid_counters_, d_grid_bin_entry0_, d_grid_fix_};
     for (void* p : ptrs)
         if (p) dev_free(p);
 }
@@ -3138,29 +3173,43 @@ void Mlp::ensure_train_workspace(uint32_t n)
         if (d_denc_) dev_free(d_denc_);
         d_denc_ = nullptr;
         dev_alloc(&d_denc_, (size_t)n * 32 * 2, "d_denc_");
-        // bin lists of the table gradient (k_grid_scatter): levels of at least GB_MIN_BINS bins of GB_BIN entries; a list holds twice what a
-        // uniformly hashed level of 2^19 entries sends a bin (n * 8 / 128 pairs), the rest -- a dense level's crowded bins -- goes on with atomics
+        // bin lists of the table gradient (k_grid_scatter): levels of at least GB_MIN_BINS bins of GB_BIN entries; a level's lists hold twice
+        // what the level sends a bin on average (n * 8 / bins pairs); the rest goes into the fixed-point shadow
         if (d_grid_lists_) dev_free(d_grid_lists_);
         d_grid_lists_ = nullptr;
+        if (d_grid_bin_entry0_) dev_free(d_grid_bin_entry0_);
+        d_grid_bin_entry0_ = nullptr;
+        if (d_grid_counters_) dev_free(d_grid_counters_);
+        d_grid_counters_ = nullptr;
         grid_bins_total_ = 0;
-        std::vector<uint32_t> entry0;
+        const bool no_bins = getenv("NRC_GRID_NO_BINS") != nullptr;      // tests: every pair through the fixed-point shadow
+        std::vector<uint32_t> info;      // uint4 per bin: {first entry, pair offset of the list, capacity, 0}
+        size_t pairs = 0;
         for (uint32_t l = 0; l < HG_LEVELS; l++) {
             const uint32_t cnt = hg_off_[l + 1] - hg_off_[l];
             const uint32_t bins = (cnt % GB_BIN == 0u) ? cnt / GB_BIN : 0u;
             grid_bin_first_[l] = grid_bins_total_;
-            grid_bin_count_[l] = (bins >= GB_MIN_BINS && bins <= GB_MAX_BINS) ? bins : 0u;
-            for (uint32_t b = 0; b < grid_bin_count_[l]; b++) entry0.push_back(hg_off_[l] + b * GB_BIN);
+            grid_bin_count_[l] = (bins >= GB_MIN_BINS && bins <= GB_MAX_BINS && !no_bins) ? bins : 0u;
+            grid_bin_cap_[l] = grid_bin_count_[l] ? std::max(1024u, (uint32_t)std::min<uint64_t>(2ull * n * 8ull / grid_bin_count_[l], 1u << 24)) : 0u;
+            grid_list0_[l] = (uint32_t)pairs;
+            for (uint32_t b = 0; b < grid_bin_count_[l]; b++) {
+                info.insert(info.end(), {hg_off_[l] + b * GB_BIN, (uint32_t)(pairs + (size_t)b * grid_bin_cap_[l]), grid_bin_cap_[l], 0u});
+            }
+            pairs += (size_t)grid_bin_count_[l] * grid_bin_cap_[l];
             grid_bins_total_ += grid_bin_count_[l];
         }
-        grid_bin_cap_ = std::max(1024u, n / (GB_MAX_BINS / 32u));      // twice the mean of a uniformly hashed level of 2^19 entries
+        if (pairs > 0xffffffffull) fail("train batch too large for the table gradient's bin lists");
         if (grid_bins_total_ != 0u) {
-            dev_alloc(&d_grid_lists_, (size_t)grid_bins_total_ * grid_bin_cap_ * 8, "d_grid_lists_");
-            if (!d_grid_counters_) {
-                dev_alloc(&d_grid_counters_, (size_t)grid_bins_total_ * 4, "d_grid_counters_");
-                NRC_HIP(hipMemset(d_grid_counters_, 0, (size_t)grid_bins_total_ * 4));
-                dev_alloc(&d_grid_bin_entry0_, entry0.size() * 4, "d_grid_bin_entry0_");
-                NRC_HIP(hipMemcpy(d_grid_bin_entry0_, entry0.data(), entry0.size() * 4, hipMemcpyHostToDevice));
-            }
+            dev_alloc(&d_grid_lists_, pairs * 8, "d_grid_lists_");
+            dev_alloc(&d_grid_counters_, (size_t)grid_bins_total_ * 4, "d_grid_counters_");
+            NRC_HIP(hipMemset(d_grid_counters_, 0, (size_t)grid_bins_total_ * 4));
+            dev_alloc(&d_grid_bin_entry0_, info.size() * 4, "d_grid_bin_info_");
+            NRC_HIP(hipMemcpy(d_grid_bin_entry0_, info.data(), info.size() * 4, hipMemcpyHostToDevice));
+        }
+        // the fixed-point shadow of the table: two int64 per entry, all zero between two steps (k_grid_gather clears what it folds in)
+        if (!d_grid_fix_) {
+            dev_alloc(&d_grid_fix_, (size_t)n_grid_entries_ * 16, "d_grid_fix_");
+            NRC_HIP(hipMemset(d_grid_fix_, 0, (size_t)n_grid_entries_ * 16));
         }
     }
     dev_alloc(&d_loss_part_, (size_t)(n / 32) * 4, "d_loss_part_");
@@ -3316,24 +3365,33 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
             static const uint32_t skip_levels = getenv("NRC_DIAG_GRID_SKIP_LEVELS") ? (uint32_t)strtoul(getenv("NRC_DIAG_GRID_SKIP_LEVELS"), nullptr, 0) : 0u;
-            if (grid_bins_total_ != 0u && getenv("NRC_GRID_BACKWARD_ATOMICS") == nullptr) {
-                // the large levels through bin lists and LDS accumulators, the coarse ones with atomics (k_grid_scatter / k_grid_gather)
+            {
+                // bin lists + exact LDS sums for the large levels, the fixed-point shadow for the rest (k_grid_scatter / k_grid_gather)
                 GridBins gb;
-                for (uint32_t l = 0; l < HG_LEVELS; l++) { gb.first[l] = grid_bin_first_[l]; gb.count[l] = grid_bin_count_[l]; }
-                gb.cap = grid_bin_cap_;
+                LooseRanges loose;
+                loose.n = 0;
+                uint32_t loose_chunks = 0;
+                for (uint32_t l = 0; l < HG_LEVELS; l++) {
+                    gb.first[l] = grid_bin_first_[l]; gb.count[l] = grid_bin_count_[l]; gb.cap[l] = grid_bin_cap_[l]; gb.list0[l] = grid_list0_[l];
+                    if (grid_bin_count_[l] == 0u) {
+                        loose.first[loose.n] = hg_off_[l];
+                        loose.count[loose.n] = hg_off_[l + 1] - hg_off_[l];
+                        loose_chunks += ceil_div(loose.count[loose.n], GB_BIN);
+                        loose.n++;
+                    }
+                }
+                for (uint32_t r = loose.n; r < HG_LEVELS; r++) loose.first[r] = loose.count[r] = 0u;
                 if (!attr_gather_set_) {
-                    NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB_BIN * 8u)));
+                    NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB_BIN * 16u)));
                     attr_gather_set_ = true;
                 }
                 static const bool level_major_env = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD works on every level
                 const bool level_major = level_major_env || !xcd8_;
-                hipLaunchKernelGGL(k_grid_scatter, level_major ? dim3(ceil_div(n, 256), HG_LEVELS) : dim3(ceil_div(n, 256) * HG_LEVELS, 1), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (uint32_t*)d_grad16_, n, lv,
+                hipLaunchKernelGGL(k_grid_scatter, level_major ? dim3(ceil_div(n, 256), HG_LEVELS) : dim3(ceil_div(n, 256) * HG_LEVELS, 1), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (long long*)d_grid_fix_, n, lv,
                                    gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_, skip_levels);
-                hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_), dim3(NRC_GB_GATHER_THREADS), GB_BIN * 8u, s, (uint32_t*)d_grad16_, grid_bin_cap_,
-                                   (const uint32_t*)d_grid_bin_entry0_, (uint32_t*)d_grid_counters_, (const uint2*)d_grid_lists_);
-            } else
-            hipLaunchKernelGGL(k_grid_backward, dim3(ceil_div(n * 16u, 256)), dim3(256), 0, s, d_in, (const half_t*)d_denc_,
-                               (uint32_t*)d_grad16_, n, lv, skip_levels);
+                hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_ + loose_chunks), dim3(NRC_GB_GATHER_THREADS), GB_BIN * 16u, s, (uint32_t*)d_grad16_,
+                                   (const uint4*)d_grid_bin_entry0_, grid_bins_total_, (uint32_t*)d_grid_counters_, (const uint2*)d_grid_lists_, (long long*)d_grid_fix_, loose);
+            }
             // the fp32 copy in the gradient vector is for whoever reads the vector (exchange, hook, debug read-back): the
             // optimizer takes the table gradient from grad16 itself (k_grid_opt)
             grid16_valid_ = fused_opt_;

@@ -111,9 +111,10 @@ private:
     void *d_t16_train_ = nullptr, *d_t16_ema_[2] = {nullptr, nullptr};   // half2-per-entry gather copies of the table
     void* d_denc_ = nullptr;     // fp16 [n][32] dL/d(grid features)
     void* d_grad16_ = nullptr;   // half2 per table entry: target of the packed gradient atomics
-    // bin lists of the table gradient (k_grid_scatter / k_grid_gather): (entry, value) pairs per bin of 16 384 entries, pair counters, first entries
-    void *d_grid_lists_ = nullptr, *d_grid_counters_ = nullptr, *d_grid_bin_entry0_ = nullptr;
-    uint32_t grid_bin_first_[16] = {}, grid_bin_count_[16] = {}, grid_bins_total_ = 0, grid_bin_cap_ = 0;
+    // bin lists of the table gradient (k_grid_scatter / k_grid_gather): (entry, value) pairs per bin of 4 096 entries, pair counters, per-bin
+    // {first entry, list offset, capacity}; d_grid_fix_: the table's fixed-point shadow (two int64 per entry) for what bypasses the lists
+    void *d_grid_lists_ = nullptr, *d_grid_counters_ = nullptr, *d_grid_bin_entry0_ = nullptr, *d_grid_fix_ = nullptr;
+    uint32_t grid_bin_first_[16] = {}, grid_bin_count_[16] = {}, grid_bin_cap_[16] = {}, grid_list0_[16] = {}, grid_bins_total_ = 0;
     bool attr_gather_set_ = false;
 
     float *d_w_ = nullptr, *d_ema_ = nullptr, *d_m_ = nullptr, *d_v_ = nullptr, *d_grad_ = nullptr, *d_loss_ = nullptr;
