@@ -1,6 +1,7 @@
 // nrc_common.hpp -- shared host-side helpers of libnrc_hpm (error convention, HIP checks, config parsing).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -34,6 +35,35 @@ struct CommError : std::runtime_error {
 };
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- events as part of a launch.  A hipEventRecord costs the host 3.5 us, a kernel launch 2.2 us -- and a launch that carries its own
+// start / stop event (hipExtLaunchKernelGGL) 1.6 us (tools/ext_launch_probe.hip: the stop event orders other streams and carries a time
+// stamp exactly like a recorded one).  A frame has eleven events behind ten launches.  The frame graph ARMS the event that marks the end of
+// a stage (arm_launch_tail), the stage's LAST kernel launch goes through launch_last() and takes it along; a stage whose last launch does
+// not (a path nobody marked) leaves it armed and finish_launch_tail() records it the ordinary way -- marking is an optimisation, never a
+// condition of correctness.  One thread drives one renderer: the slot is thread-local.
+struct LaunchTail {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchTail& launch_tail();      // (nrc_api.hip)
+inline void arm_launch_tail(hipEvent_t stop, hipEvent_t start = nullptr) { launch_tail() = LaunchTail{start, stop}; }
+template <class K, class... A>
+inline void launch_last(K kernel, dim3 grid, dim3 block, uint32_t shmem, hipStream_t s, A... args)
+{
+    LaunchTail& t = launch_tail();
+    if (t.start != nullptr || t.stop != nullptr) {
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, s, t.start, t.stop, 0u, args...);
+        t = LaunchTail{};
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
+    }
+}
+inline void finish_launch_tail(hipStream_t s)
+{
+    LaunchTail& t = launch_tail();
+    if (t.stop != nullptr) NRC_HIP(hipEventRecord(t.stop, s));
+    t = LaunchTail{};
+}
 
 // XCDs (accelerator complex dies, each with its own L2) of the current device.  Several launch mappings hand the work of one table level /
 // one screen band to the workgroups of ONE XCD (workgroup b runs on XCD b mod count: round-robin dispatch) -- a placement for speed only,

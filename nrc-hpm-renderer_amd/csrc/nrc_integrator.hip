@@ -2419,9 +2419,10 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
     if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     DevFrame fa = fr;
     fa.raise_priority = (g_host_raise_wave_priority != 0 && fr.camera_priority_low == 0u) ? 1u : 0u;
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc, cam, fa,
-                       primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
-                       fetch_counter, tg, full_vertex_images ? 1 : 0);
+    // (launch_last: the frame's start / "gen_rays done" events ride on the launch when the frame graph armed them -- nrc_common.hpp)
+    launch_last(kernel, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0u, s, sc, cam, fa,
+                primary_ray_length, primary_ray_prob, (float4*)primary, info, (float4*)origin, (float4*)dir, infer_in,
+                fetch_counter, tg, full_vertex_images ? 1 : 0);
     NRC_HIP(hipGetLastError());
 }
 
@@ -2492,8 +2493,8 @@ void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& 
     hipLaunchKernelGGL(k_prep_train, pixel_grid(tg.tw, tg.th), dim3(256), 0, s, sc, fr, tg, (const float4*)origin,
                        (const float4*)dir, (const uint32_t*)ring, (const uint32_t*)scratch, train_in, train_target);
     NRC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_ring_push, dim3(ceil_div(T, 256)), dim3(256), 0, s, fr, tg, (const float4*)origin,
-                       (const float4*)dir, ring, (const uint32_t*)scratch);
+    launch_last(k_ring_push, dim3(ceil_div(T, 256)), dim3(256), 0u, s, fr, tg, (const float4*)origin,
+                (const float4*)dir, ring, (const uint32_t*)scratch);
     NRC_HIP(hipGetLastError());
 }
 
@@ -2508,8 +2509,8 @@ void integrator_set_wave_priority_raise(int on)
 void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary, const float* info,
                       const float* infer_out, float* out_rgba, hipStream_t s, uint32_t* live_count_reset)
 {
-    hipLaunchKernelGGL(k_composite, pixel_grid(fr.w, fr.h), dim3(256), 0, s, fr, show_nrc, blend_factor,
-                       (const float4*)primary, info, infer_out, (float4*)out_rgba, live_count_reset);
+    launch_last(k_composite, pixel_grid(fr.w, fr.h), dim3(256), 0u, s, fr, show_nrc, blend_factor,
+                (const float4*)primary, info, infer_out, (float4*)out_rgba, live_count_reset);
     NRC_HIP(hipGetLastError());
 }
 

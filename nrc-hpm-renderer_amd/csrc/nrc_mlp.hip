@@ -2900,15 +2900,15 @@ static void launch_infer(uint32_t blocks, size_t lds, hipStream_t s, const float
                          const uint32_t* live_count = nullptr)
 {
     if (composite != nullptr) {
-        hipLaunchKernelGGL((k_infer<6, THREADS, NT, 0, true>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
-                           (unsigned long long*)nullptr, skip_zero, *composite);
+        launch_last(k_infer<6, THREADS, NT, 0, true>, dim3(blocks), dim3(THREADS), (uint32_t)lds, s, d_in, d_out, n, img,
+                    (unsigned long long*)nullptr, skip_zero, *composite, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         return;
     }
     if (live_list != nullptr)
-        hipLaunchKernelGGL((k_infer<6, THREADS, NT, 0, false, true>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
+        launch_last(k_infer<6, THREADS, NT, 0, false, true>, dim3(blocks), dim3(THREADS), (uint32_t)lds, s, d_in, d_out, n, img,
                            (unsigned long long*)nullptr, skip_zero, CompositeArgs{}, live_list, live_count);
     else
-        hipLaunchKernelGGL((k_infer<6, THREADS, NT>), dim3(blocks), dim3(THREADS), lds, s, d_in, d_out, n, img,
+        launch_last(k_infer<6, THREADS, NT>, dim3(blocks), dim3(THREADS), (uint32_t)lds, s, d_in, d_out, n, img,
                            (unsigned long long*)nullptr, skip_zero, CompositeArgs{}, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 }
 
@@ -2943,8 +2943,8 @@ void Mlp::infer(const float* d_in, float* d_out, uint32_t n, bool use_ema, hipSt
         uint32_t blocks = ceil_div(ceil_div(n, 32), 8);
         auto launch = [&](auto kernel, uint32_t threads, size_t lds, uint32_t per_cu) {
             const uint32_t cap = (uint32_t)num_cus() * per_cu;
-            hipLaunchKernelGGL(kernel, dim3(blocks > cap ? cap : blocks), dim3(threads), lds, s, feat, d_out, n, img, (int)depth_, ks0, skip_in, d_in,
-                               list, list != nullptr ? live_count : nullptr);
+            launch_last(kernel, dim3(blocks > cap ? cap : blocks), dim3(threads), (uint32_t)lds, s, feat, d_out, n, img, (int)depth_, ks0, skip_in, d_in,
+                        list, list != nullptr ? live_count : nullptr);      // (the stage's last launch: takes the armed event along, nrc_common.hpp)
         };
         if (kw_ == 32) {
             if (enc80) launch(k_infer_gen<32, 256, false, 2, true>, 256, 2 * 5 * 1024, 4);
@@ -3464,12 +3464,20 @@ bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* l
     if (fused_opt_) {
         const int next = infer_set_ ^ 1;
         const PackDst d{d_dst_, d_dst_ + n_mlp_, d_dst_ + 2 * (size_t)n_mlp_, (half_t*)d_pk_fwd_, (half_t*)d_pk_infer_[next], (half_t*)d_pk_bwd_};
-        if (sgd_)
-            hipLaunchKernelGGL(k_opt_pack<true>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
-                               cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+        // (the step's last launch takes the armed event along -- launch_last, nrc_common.hpp: k_opt_pack, or the table's optimizer behind it)
+        if (hash_) {
+            if (sgd_)
+                hipLaunchKernelGGL(k_opt_pack<true>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
+                                   cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+            else
+                hipLaunchKernelGGL(k_opt_pack<false>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
+                                   cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+        } else if (sgd_)
+            launch_last(k_opt_pack<true>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
+                        cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
         else
-            hipLaunchKernelGGL(k_opt_pack<false>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
-                               cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
+            launch_last(k_opt_pack<false>, dim3(ceil_div(n_mlp_, 256)), dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, n_mlp_,
+                        cfg_.learning_rate, a, d, (const float*)d_loss_, loss_seq, loss_cell);
         if (hash_) {
             const dim3 g(ceil_div(n_grid_entries_, 256));
             uint32_t *tt = (uint32_t*)d_t16_train_, *te = (uint32_t*)d_t16_ema_[next];
@@ -3480,22 +3488,22 @@ bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* l
                 const uint32_t np = n_grid_entries_ / 2u;
                 const dim3 g2(ceil_div(np, 256));
                 if (sgd_ && grid16_valid_)
-                    hipLaunchKernelGGL((k_grid_opt2<true, true>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                    launch_last(k_grid_opt2<true, true>, g2, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
                 else if (sgd_)
-                    hipLaunchKernelGGL((k_grid_opt2<true, false>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                    launch_last(k_grid_opt2<true, false>, g2, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
                 else if (grid16_valid_)
-                    hipLaunchKernelGGL((k_grid_opt2<false, true>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                    launch_last(k_grid_opt2<false, true>, g2, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
                 else
-                    hipLaunchKernelGGL((k_grid_opt2<false, false>), g2, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
+                    launch_last(k_grid_opt2<false, false>, g2, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, np, cfg_.learning_rate, a, tt, te);
             } else
             if (sgd_ && grid16_valid_)
-                hipLaunchKernelGGL((k_grid_opt<true, true>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+                launch_last(k_grid_opt<true, true>, g, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
             else if (sgd_)
-                hipLaunchKernelGGL((k_grid_opt<true, false>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+                launch_last(k_grid_opt<true, false>, g, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
             else if (grid16_valid_)
-                hipLaunchKernelGGL((k_grid_opt<false, true>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+                launch_last(k_grid_opt<false, true>, g, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
             else
-                hipLaunchKernelGGL((k_grid_opt<false, false>), g, dim3(256), 0, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
+                launch_last(k_grid_opt<false, false>, g, dim3(256), 0u, s, d_w_, d_ema_, d_m_, d_v_, d_grad_, g16, n_mlp_, n_grid_entries_, cfg_.learning_rate, a, tt, te);
         }
         NRC_HIP(hipGetLastError());
         infer_set_ = next;
