@@ -386,6 +386,7 @@ def main():
     if mc_keep is not None:
         mc_keep.Destroy()
     stats = job.stats
+    schedule = ren.GetSchedule()
     value, ms_per_step = res["value"], res["ms_per_step"]
     loss = nrc.GetLoss() if args.train else None
     # what the host spends enqueueing one frame (through the Python mirror, queues empty, nothing awaited): the launch path is on
@@ -569,6 +570,7 @@ def main():
             "exchange": exchange,
             "stage_ms": {k: stats[k] for k in ("gen_rays", "prep_train", "train", "infer", "render", "total")},
             "loss": loss,
+            "schedule": schedule,      # what the renderer's tuner chose on this run's own frames (nrc_schedule; placement only)
             "build_id": api.build_id(),
             "roofline": roof_gen if dominant_is_gen else roof_mlp,
             "roofline_mlp": roof_mlp,

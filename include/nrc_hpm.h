@@ -327,6 +327,23 @@ int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on);
  * a counting sort turns that into the order the following frames start their tiles in (the long walks through the cloud first,
  * the cheap rim in the tail of the launch).  The order is a permutation of the tiles and nothing else: frames are bit-identical
  * with and without.  tile_order copies the permutation in use (n = nrc_renderer_tile_order(r, NULL, 0) entries) to the host. */
+/* The SCHEDULE of a renderer's frame graph: where and in which order work is placed -- no value changes a pixel or a weight (the tests render
+ * under every combination and compare bit for bit).  The library chooses these itself: it starts from neutral values and, once the pipeline
+ * has run for 64 frames, tries the alternatives on the caller's own frames against its frame timeline (one knob at a time, 24 frames per value,
+ * the current value timed before and after the alternatives; ~250 frames in all) and keeps what is more than 1.5 % faster.  A caller that
+ * knows better pins a knob with a value >= 0; -1 hands it (back) to the library.
+ *   camera_priority_low  1: the camera kernels run at the default wave priority under the library's other kernels (pays where the
+ *                        inference -> training chain bounds the frame: wide dense models), 0: at the common priority
+ *   cost_order_lag       frames between a tile-cost sample and the first launch ordered by it (1..64; 2 or 3 are what the tuner tries)
+ *   xcd_window           XCD-aware finish of the costliest-first launch order: tiles of a window of 32 x M ranks are dealt to the eight XCDs by
+ *                        screen row (0 = off; the tuner tries 0, 2, 16); ignored on a device that does not have eight XCDs
+ *   composite_defer      1: the compositing of the frames inside one nrc_renderer_render_frames call runs on the train-ray stream (not tuned) */
+typedef struct nrc_schedule {
+    int32_t camera_priority_low, cost_order_lag, xcd_window, composite_defer;
+} nrc_schedule;
+int nrc_renderer_set_schedule(nrc_renderer_t* r, const nrc_schedule* schedule);
+/* the values in use now; *tuning_done (may be NULL) = 1 once nothing is left to choose */
+int nrc_renderer_get_schedule(nrc_renderer_t* r, nrc_schedule* current, int* tuning_done);
 int nrc_renderer_set_cost_order(nrc_renderer_t* r, int on);
 size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t capacity);
 /* Hot tiles (on by default): a pixel whose RNG state can run into DeltaTrack's cap of 128 collisions inside a tile the empty-space

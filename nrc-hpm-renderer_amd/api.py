@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "nrc_cache_get_loss_blocking", "nrc_cache_get_loss_async", "nrc_cache_comm_info", "nrc_cache_comm_time_exchange", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
     "nrc_cache_set_collective_hooks", "nrc_renderer_gather_frame", "nrc_renderer_export_exr_gathered", "nrc_compare_images_sharded",
-    "nrc_renderer_set_cost_order", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order", "nrc_renderer_set_hot_tiles", "nrc_renderer_hot_tiles",
+    "nrc_renderer_set_cost_order", "nrc_renderer_set_schedule", "nrc_renderer_get_schedule", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order", "nrc_renderer_set_hot_tiles", "nrc_renderer_hot_tiles",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -582,6 +582,18 @@ class NrcHpmRenderer:
             _check(self.L.nrc_renderer_export_exr_gathered(self.h, filePath.encode(), C.c_int(root)))
         else:
             _check(self.L.nrc_renderer_export_exr(self.h, filePath.encode()))
+
+    def SetSchedule(self, camera_priority_low=-1, cost_order_lag=-1, xcd_window=-1, composite_defer=-1):
+        """nrc_renderer_set_schedule: pin scheduling knobs (values >= 0) or hand them back to the library's tuner (-1); no knob changes a pixel"""
+        v = (C.c_int32 * 4)(int(camera_priority_low), int(cost_order_lag), int(xcd_window), int(composite_defer))
+        _check(self.L.nrc_renderer_set_schedule(self.h, v))
+
+    def GetSchedule(self):
+        """the schedule in use now: dict(camera_priority_low, cost_order_lag, xcd_window, composite_defer, tuning_done)"""
+        v = (C.c_int32 * 4)()
+        done = C.c_int(0)
+        _check(self.L.nrc_renderer_get_schedule(self.h, v, C.byref(done)))
+        return dict(camera_priority_low=v[0], cost_order_lag=v[1], xcd_window=v[2], composite_defer=v[3], tuning_done=bool(done.value))
 
     def GatherFrame(self, stream=None):
         """the whole [global_h, global_w, 4] frame of a sharded renderer as a new torch CUDA tensor, on every rank (collective: one

@@ -1353,19 +1353,12 @@ __host__ __device__ inline size_t query_index(uint32_t w, uint32_t lx, uint32_t 
     return ((size_t)((y >> 3) * tiles_x + (lx >> 3)) << 6) + ((y & 7u) << 3) + (lx & 7u);
 }
 // launch slot (workgroup * 4 + wave) -> the wave's pixel
-__device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_t d, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr,
-                                                     uint32_t* part_ = nullptr)
+__device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_t d, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (fr.w + 7u) >> 3, tiles_y = (fr.h + 7u) >> 3;
     const uint32_t row_blocks = camera_row_blocks(fr.w);
-    uint32_t part = 0u;
-    if (fr.tile_order != nullptr) {      // costliest tiles first; the costliest of all as two half tiles (DevFrame::order_extra)
-        const uint32_t e = scalar_load(fr.tile_order + d);
-        part = e >> kOrderPartShift;
-        d = e & kOrderSlotMask;          // (kOrderNone: a slot beyond the grid)
-    }
-    if (part_ != nullptr) *part_ = part;
+    if (fr.tile_order != nullptr) d = scalar_load(fr.tile_order + d);      // costliest tiles first
     if (slot) *slot = d;
     const uint32_t bd = d / CAMERA_WAVES_PER_BLOCK;
     const uint32_t k = bd / row_blocks, jb = bd - k * row_blocks;
@@ -1375,9 +1368,7 @@ __device__ __forceinline__ bool pixel_of_launch_slot(const DevFrame& fr, uint32_
     const uint32_t ty = (k & 1u) ? mid - ((k + 1u) >> 1) : mid + (k >> 1);      // mid, mid-1, mid+1, ...: a bijection
     *lx = tx * 8u + (lane & 7u);
     *y = ty * 8u + (lane >> 3);
-    // a half tile: lanes 0..31 (part 1) or 32..63 (part 2) have a pixel
-    const bool mine = part == 0u || (part == 1u) == (lane < 32u);
-    return mine && *lx < fr.w && *y < fr.h;
+    return *lx < fr.w && *y < fr.h;
 }
 __device__ __forceinline__ bool pixel_of_wave_tile(const DevFrame& fr, uint32_t* lx, uint32_t* y, uint32_t* slot = nullptr)
 {
@@ -1482,10 +1473,9 @@ __global__ __launch_bounds__(64) void k_hot_tiles(DevFrame fr, uint32_t* __restr
 
 // The tile of a camera kernel's wave.  With a hot-tile list (DevFrame::hot_tiles) the launch has kHotTilesMax waves in front of the
 // ordered ones: wave k traces hot tile k, and the wave the order gives that tile to leaves.  false: the wave has nothing to do.
-__device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* lx_, uint32_t* y_, uint32_t* slot_, bool* inside_, bool* hot_wave_,
-                                                 uint32_t* part_ = nullptr)
+__device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* lx_, uint32_t* y_, uint32_t* slot_, bool* inside_, bool* hot_wave_)
 {
-    uint32_t lx = 0, y = 0, slot = 0, part = 0;
+    uint32_t lx = 0, y = 0, slot = 0;
     bool inside;
     bool hot_wave = false;
     {
@@ -1517,7 +1507,7 @@ __device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* l
                 inside = lx < fr.w && y < fr.h;
                 hot_wave = true;
             } else {
-                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot, &part);
+                inside = pixel_of_launch_slot(fr, d - kHotTilesMax, &lx, &y, &slot);
                 const uint32_t t = __builtin_amdgcn_readfirstlane(((y >> 3) << 16) | (lx >> 3));
                 bool is_hot = false;
 #pragma unroll
@@ -1525,20 +1515,16 @@ __device__ __forceinline__ bool camera_wave_tile(const DevFrame& fr, uint32_t* l
                 if (is_hot) return false;
             }
         } else {
-            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot, &part);
+            inside = pixel_of_launch_slot(fr, d, &lx, &y, &slot);
         }
     }
-    if (part_ != nullptr) *part_ = part;
     *lx_ = lx; *y_ = y; *slot_ = slot; *inside_ = inside; *hot_wave_ = hot_wave;
     return true;
 }
 
 // what a tile cost in this launch, kept as a decaying maximum over the sampled launches (DevFrame::tile_cost_keep)
-// (a half tile's wave stores 13/8 of its own cycles -- roughly what the whole tile costs on one wave --, so that a tile keeps its
-// rank in the order whether it is split or not; the two halves race for the cell and either estimate will do)
-__device__ __forceinline__ void store_tile_cost(const DevFrame& fr, uint32_t slot, unsigned long long cycles, uint32_t part = 0u)
+__device__ __forceinline__ void store_tile_cost(const DevFrame& fr, uint32_t slot, unsigned long long cycles)
 {
-    if (part != 0u) cycles = (cycles * 13ull) >> 3;
     uint32_t c = (uint32_t)min(cycles, 0xffffffffull);
     if (fr.tile_cost_keep != 0u) {
         const uint32_t old = fr.tile_cost[slot];
@@ -1603,8 +1589,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     __shared__ uint32_t s_occ[kOccMaxWords];
     uint32_t lx = 0, y = 0, slot = 0;
     bool inside, hot_wave;
-    uint32_t part = 0;
-    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave, &part)) return;
+    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave)) return;
 #ifdef NRC_LOOP_PROFILE
     const uint32_t wave_id = blockIdx.x * CAMERA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) {
@@ -1651,7 +1636,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                     for (int k = 0; k < 5; k++) out_store(&qo[k], 0.0f);
                 }
             }
-            if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start, part);
+            if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
 #ifdef NRC_LOOP_PROFILE
             if (inside && full_vertex_images != 0) reinterpret_cast<float*>(origin)[4 * ((size_t)y * fr.w + lx) + 3] = 0.0f;
             if ((threadIdx.x & 63u) == 0 && wave_id < 65536u) g_wave_times[4 * wave_id + 1] = wall_clock64();
@@ -1789,7 +1774,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
     // what this tile cost (shader cycles): next frames launch the costliest tiles first (k_tile_order).  (Not for a hot wave: what
     // it measured is this frame's one pixel in a capped state, not the tile.)
-    if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start, part);
+    if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0) store_tile_cost(fr, slot, __builtin_amdgcn_s_memtime() - t_start);
 #if defined(NRC_LOOP_PROFILE) && !defined(NRC_NO_LOOP_COUNTERS)
     for (int k = 0; k < 8; k++) { count_fetches(&g_loop_prof[k], c.useful[k]); count_fetches(&g_loop_prof[8 + k], c.issued[k]); }
 #endif
@@ -1810,8 +1795,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     const uint32_t* occ = load_occupancy(sc, s_occ);
     uint32_t lx = 0, y = 0, slot = 0;
     bool inside, hot_wave;
-    uint32_t part = 0;
-    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave, &part)) return;
+    if (!camera_wave_tile(fr, &lx, &y, &slot, &inside, &hot_wave)) return;
     CtxT<COUNT> c{sc, 0.0f, 0u};
     c.occ = occ;
     // wave-uniform control flow with per-lane predicates, as in k_gen_rays (the thin trips of the 32 x 3 tracking loops go to lane pairs)
@@ -1857,7 +1841,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
     }
     if constexpr (COUNT) count_fetches(fetch_counter, c.fetches);
     if (fr.tile_cost != nullptr && !hot_wave && (threadIdx.x & 63u) == 0)      // see k_gen_rays / k_tile_order (a longer walk: 8 192-cycle classes)
-        store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4, part);
+        store_tile_cost(fr, slot, (__builtin_amdgcn_s_memtime() - t_start) >> 4);
 }
 
 // ------------------------------------------------------------------------------------------------ costliest-first launch order
@@ -1866,34 +1850,16 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_CAMERA_WAVES_PER_S
 // launch and a third of its duration is a thinning tail (tools/loop_profile.py).  Tile costs repeat from frame to frame
 // (correlation 0.95), so the waves are launched in order of decreasing cost of an earlier frame: a counting sort over 1024
 // cost classes of 512 cycles, one workgroup, order within a class arbitrary -- any permutation gives the same frame.
-// row_len > 0: a tile is ranked by the largest cost among itself and its four neighbours (row_len = slots per tile row).  What ends
-// a launch is a tile whose cost was under-estimated -- a long walk is a rare event of a pixel, and a tile at the cloud's rim has
-// one in some frames only --, and its neighbours see the same medium: their maximum is the better estimate of what it CAN cost.
-// split_max > 0: the costliest tiles -- at most split_max of them, cost class >= split_min_class -- are listed as two half tiles
-// (DevFrame::order_extra): the order has n + split_max entries, the unused ones at its end say kOrderNone.
-__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order, uint32_t row_len,
-                                                    uint32_t split_max, uint32_t split_min_class)
+// (Measured and taken out again, rounds 2-4: ranking a tile by the maximum over its four neighbours; listing the costliest tiles as two
+// half tiles -- DESIGN.md section 4.)
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order)
 {
     NRC_RAISE_WAVE_PRIORITY(16);
     __shared__ uint32_t hist[1024];
     const uint32_t tid = threadIdx.x;
     hist[tid] = 0u;
     __syncthreads();
-    auto key_of = [=](uint32_t i) {
-        uint32_t c = cost[i];
-        if (row_len != 0u) {
-            // slot -> (row k, position in the row); the rows alternate around the middle one (pixel_of_launch_slot): the vertical
-            // neighbours of row k are rows k - 2 and k + 2, and rows 0 and 1 are neighbours of each other
-            const uint32_t k = i / row_len, j = i - k * row_len;
-            if (j > 0u) c = max(c, cost[i - 1u]);
-            if (j + 1u < row_len) c = max(c, cost[i + 1u]);
-            if (i + 2u * row_len < n) c = max(c, cost[i + 2u * row_len]);
-            if (k >= 2u) c = max(c, cost[i - 2u * row_len]);
-            if (k == 0u && i + row_len < n) c = max(c, cost[i + row_len]);
-            if (k == 1u) c = max(c, cost[i - row_len]);
-        }
-        return 1023u - min(c >> 9, 1023u);      // descending cost
-    };
+    auto key_of = [=](uint32_t i) { return 1023u - min(cost[i] >> 9, 1023u); };      // descending cost
     for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[key_of(i)], 1u);
     __syncthreads();
     // exclusive prefix sum over the 1024 classes (wave scans + wave totals)
@@ -1912,26 +1878,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
     __syncthreads();
     hist[tid] = woff + incl - v;
     __syncthreads();
-    // tiles in the classes [0, 1023 - split_min_class] (descending cost) are candidates for the split: the first n_split ranks
-    __shared__ uint32_t s_split;
-    if (tid == 0u) {
-        const uint32_t last = 1023u - min(split_min_class, 1023u);      // the last key that qualifies
-        const uint32_t cand = last == 1023u ? n : hist[last + 1u];      // exclusive prefix of the key behind it
-        s_split = min(split_max, cand);
-    }
-    __syncthreads();
-    const uint32_t n_split = s_split;
-    __syncthreads();      // (s_split is read before the scatter below advances hist)
-    for (uint32_t i = tid; i < n; i += 1024u) {
-        const uint32_t r = atomicAdd(&hist[key_of(i)], 1u);
-        if (r < n_split) {
-            order[2u * r] = i | (1u << kOrderPartShift);
-            order[2u * r + 1u] = i | (2u << kOrderPartShift);
-        } else {
-            order[r + n_split] = i;
-        }
-    }
-    for (uint32_t i = n + n_split + tid; i < n + split_max; i += 1024u) order[i] = kOrderNone;
+    for (uint32_t i = tid; i < n; i += 1024u) order[atomicAdd(&hist[key_of(i)], 1u)] = i;
 }
 
 // XCD-aware finish of the order (round 4; xcd_row_len = slots per tile row).  The hardware deals workgroups to the eight XCDs round-robin, so
@@ -2416,7 +2363,6 @@ void launch_gen_rays(const DevScene& sc, const DevCamera& cam, const DevFrame& f
 #endif
     dim3 grid = wave_tile_grid(fr.w, fr.h);
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
-    if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     DevFrame fa = fr;
     fa.raise_priority = (g_host_raise_wave_priority != 0 && fr.camera_priority_low == 0u) ? 1u : 0u;
     // (launch_last: the frame's start / "gen_rays done" events ride on the launch when the frame graph armed them -- nrc_common.hpp)
@@ -2434,15 +2380,16 @@ void launch_hot_tiles(const DevFrame& fr, uint32_t* hot, hipStream_t s)
 
 uint32_t camera_slots(uint32_t w, uint32_t h) { return camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK * ceil_div(h, 8); }
 
-void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, uint32_t split_max,
-                       uint32_t split_min_cycles, hipStream_t s, uint32_t xcd_window, uint32_t workgroups_in_front)
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, hipStream_t s, uint32_t xcd_window, uint32_t workgroups_in_front)
 {
     const uint32_t row_len = camera_row_blocks(w) * CAMERA_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order, neighbours ? row_len : 0u,
-                       split_max, split_min_cycles >> 9);
-    if (xcd_window != 0u && split_max == 0u && CAMERA_WAVES_PER_BLOCK == 4u && n_slots % row_len == 0u) {
+    // (the sort's last launch carries the "order ready" event when the frame graph armed one -- nrc_common.hpp, LaunchTail)
+    const bool xcd = xcd_window != 0u && CAMERA_WAVES_PER_BLOCK == 4u && n_slots % row_len == 0u;
+    if (!xcd) launch_last(k_tile_order, dim3(1), dim3(1024), 0u, s, cost, n_slots, order);
+    else {
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cost, n_slots, order);
         const uint32_t S = 32u * std::min(32u, xcd_window);
-        hipLaunchKernelGGL(k_tile_order_xcd, dim3((n_slots + workgroups_in_front * 4u + S - 1u) / S), dim3(S), 0, s, order, n_slots, row_len, workgroups_in_front);
+        launch_last(k_tile_order_xcd, dim3((n_slots + workgroups_in_front * 4u + S - 1u) / S), dim3(S), 0u, s, order, n_slots, row_len, workgroups_in_front);
     }
     NRC_HIP(hipGetLastError());
 }
@@ -2475,7 +2422,6 @@ void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& 
 {
     dim3 grid = wave_tile_grid(fr.w, fr.h);
     if (fr.hot_tiles != nullptr) grid.x += kHotTilesMax / CAMERA_WAVES_PER_BLOCK;
-    if (fr.tile_order != nullptr) grid.x += fr.order_extra / CAMERA_WAVES_PER_BLOCK;
     DevFrame fa = fr;
     fa.raise_priority = (g_host_raise_wave_priority != 0 && fr.camera_priority_low == 0u) ? 1u : 0u;
     hipLaunchKernelGGL(fetch_counter ? k_mc_render<true> : k_mc_render<false>, grid, dim3(64 * CAMERA_WAVES_PER_BLOCK), 0, s, sc,

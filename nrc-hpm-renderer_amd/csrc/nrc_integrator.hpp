@@ -53,14 +53,7 @@ struct DevFrame {
     // launch order of the camera kernels' 8x8 tiles: launch slot (workgroup * 4 + wave) -> default slot (the centre-out order of
     // pixel_of_wave_tile), costliest first (k_tile_order); nullptr: default order.  tile_cost: cycles each default slot's wave
     // took in this launch (written by k_gen_rays when non-null)
-    // Split tiles: the order buffer holds order_extra entries more than there are slots, and an entry's top four bits say which
-    // part of the tile the wave renders (kOrderPart*: 0 the whole 8x8 tile, 1 / 2 its upper / lower four pixel rows = lanes 0..31 /
-    // 32..63; the other lanes have no pixel and help the walks of those that do: ratio_pairs).  k_tile_order lists the costliest
-    // tiles as two halves: what ends a launch is its longest waves, and a half tile's walks run two lanes per walk from the
-    // first trip.  An entry of 0xffffffff is a wave without work.  Every pixel is still traced exactly once, by the same
-    // arithmetic, whatever the split.
     const uint32_t* tile_order;
-    uint32_t order_extra;
     uint32_t* tile_cost;
     // 0: tile_cost[slot] = this launch's cycles; k > 0: max(this launch's cycles, old - (old >> k)) -- a decaying maximum over the
     // sampled launches: the costliest-first order is hurt by tiles it under-estimates (a long tile started late ends the launch),
@@ -93,7 +86,7 @@ struct DevFrame {
     // kernel or from the list).  0: every slot of the query buffer is written, dead pixels with zeros (the reference's zero-filled buffer)
     uint32_t skip_dead_queries;
 };
-constexpr uint32_t kOrderSlotMask = 0x00ffffffu, kOrderPartShift = 28u, kOrderNone = 0xffffffffu;
+constexpr uint32_t kOrderSlotMask = 0x00ffffffu;      // (most tiles a launch order can address)
 constexpr uint32_t kHotTilesMax = 8;      // = the waves of the two workgroups the launch gains in front
 
 // forward camera transform for the tile mask: clip = m * (x, y, z, 1), column-major like DevCamera::m
@@ -129,12 +122,7 @@ void launch_flight_table(float* table, hipStream_t s);
 void launch_flight_select(const float* table, float lambda, uint32_t* count_and_list, uint32_t* bits, hipStream_t s);
 // launch slots of the camera kernels (rows padded to an odd number of workgroups) and the costliest-first order over them
 uint32_t camera_slots(uint32_t w, uint32_t h);
-// split_max: at most that many of the costliest tiles (cost >= split_min_cycles) are listed as two half tiles; `order` holds
-// n_slots + split_max entries
-// xcd_window = M > 0: inside every window of 32 M consecutive ranks (8 M workgroups that start together, M per XCD) the tiles are handed to the
-// XCDs by screen row (k_tile_order_xcd); workgroups_in_front: workgroups the launch puts in front of the ordered ones (the hot tiles')
-void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, bool neighbours, uint32_t split_max,
-                       uint32_t split_min_cycles, hipStream_t s, uint32_t xcd_window = 0, uint32_t workgroups_in_front = 0);
+void launch_tile_order(const uint32_t* cost, uint32_t n_slots, uint32_t* order, uint32_t w, hipStream_t s, uint32_t xcd_window = 0, uint32_t workgroups_in_front = 0);
 
 void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& fr, uint32_t path_length,
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);

@@ -587,10 +587,6 @@ __device__ __forceinline__ void loss_terms(uint32_t loss_id, const float (&y)[3]
     }
 }
 
-// 1: the fused training step runs k_train_fwd_bwd_light (round 4: two phases, 54 KB of LDS, <= 128 registers); 0: k_train_fwd_bwd (round 3)
-#ifndef NRC_TRAIN_LIGHT
-#define NRC_TRAIN_LIGHT 1
-#endif
 struct TrainArgs {
     const float* in;
     const float* target;
@@ -602,119 +598,12 @@ struct TrainArgs {
     float* loss_part;     // [n/32]
 };
 
-template <int DEPTH, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_train_fwd_bwd(TrainArgs a, const uint4* __restrict__ img_fwd,
-                                                          const uint4* __restrict__ img_bwd)
-{
-    NRC_RAISE_WAVE_PRIORITY(1);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* lw = reinterpret_cast<uint4*>(smem);
-    uint4* lb = lw + n_frag_fwd(DEPTH) * 64;
-    stage_lds(lw, img_fwd, n_frag_fwd(DEPTH) * 64, threadIdx.x, THREADS);
-    stage_lds(lb, img_bwd, n_frag_bwd(DEPTH) * 64, threadIdx.x, THREADS);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const uint32_t n_tiles = a.n >> 5;               // host guarantees n % 32 == 0
-    const uint32_t stride = gridDim.x * (THREADS / 64);
-    for (uint32_t tile = blockIdx.x * (THREADS / 64) + wave; tile < n_tiles; tile += stride) {
-        asm volatile("" ::: "memory");   // see k_infer: no hoisting of LDS fragment reads
-        const uint32_t sidx = tile * 32u + r;
-        const float* p = a.in + (size_t)sidx * 5u;
-        float x[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) x[i] = p[i];
-        FwdState<DEPTH, true> st;
-        encode80(x, h, st.enc);
-        f32x16 y = forward_tile<DEPTH, true>(lw, lane, st);
-
-        // ---- activations -> HBM in [sample/8][row][8] order: the 16-byte k-groups the weight-gradient GEMM reads;
-        //      row offsets are compile-time immediates on two per-lane bases (+8h / +4h rows).  (The generic kernel's LDS
-        //      transposition, store_kgroups, makes this kernel faster alone -- 24 instead of 31 us -- but 1-3 % slower inside
-        //      the frame, where its wait chains stretch beside gen_rays; these fire-and-forget 2-byte stores stayed.)
-        constexpr int ROWS_A = ENC + DEPTH * WIDTH;
-        constexpr int ROWS_D = DEPTH * WIDTH + 8;
-        half_t* const pa = a.acts + ((size_t)(sidx >> 3) * ROWS_A) * 8 + (sidx & 7u);
-        half_t* const pa8 = pa + 64 * h;      // rows + 8h
-        half_t* const pa4 = pa + 32 * h;      // rows + 4h
-#pragma unroll
-        for (int s = 0; s < KS0; s++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (s < 4) pa8[(16 * s + j) * 8] = st.enc[s][j];
-                else pa4[(j < 4 ? 64 + j : 72 + (j - 4)) * 8] = st.enc[s][j];
-            }
-#pragma unroll
-        for (int l = 0; l < DEPTH; l++)
-#pragma unroll
-            for (int s = 0; s < KSH; s++)
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    pa4[(ENC + WIDTH * l + kperm(s, 0, j)) * 8] = st.act[l][s][j];
-        half_t* const pd = a.deltas + ((size_t)(sidx >> 3) * ROWS_D) * 8 + (sidx & 7u);
-        half_t* const pd4 = pd + 32 * h;
-
-        // ---- loss + dL/dy (lanes h==0 hold y); tiny-cuda-nn RelativeL2Luminance / L2 / RelativeL2
-        float loss_v = 0.0f;
-        half8 bo;
-#pragma unroll
-        for (int j = 0; j < 8; j++) bo[j] = (half_t)0.0f;
-        if (h == 0) {
-            const float* t = a.target + (size_t)sidx * 3u;
-            const float yv[3] = {y[0], y[1], y[2]};
-            float dy[3];
-            loss_terms(a.loss_id, yv, t, a.inv_n_total, loss_v, dy);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                bo[c] = (half_t)dy[c];
-                pd[(DEPTH * WIDTH + c) * 8] = bo[c];
-            }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) loss_v += __shfl_xor(loss_v, off);
-        if (lane == 0) a.loss_part[tile] = loss_v;
-
-        // ---- dgrad chain: delta_{l-1} = relu'(a_{l-1}) * (W_l^T delta_l)
-        const int bout = (DEPTH - 1) * MT * KSH;
-        f32x16 d0 = mfma(ld_frag(lb, bout + 0, lane), bo, zero16());
-        f32x16 d1 = mfma(ld_frag(lb, bout + 1, lane), bo, zero16());
-#pragma unroll
-        for (int l = DEPTH - 1; l >= 0; l--) {
-            half8 dl[KSH];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                dl[0][j] = (st.act[l][0][j] > (half_t)0.0f) ? (half_t)d0[j] : (half_t)0.0f;
-                dl[1][j] = (st.act[l][1][j] > (half_t)0.0f) ? (half_t)d0[8 + j] : (half_t)0.0f;
-                dl[2][j] = (st.act[l][2][j] > (half_t)0.0f) ? (half_t)d1[j] : (half_t)0.0f;
-                dl[3][j] = (st.act[l][3][j] > (half_t)0.0f) ? (half_t)d1[8 + j] : (half_t)0.0f;
-            }
-#pragma unroll
-            for (int s = 0; s < KSH; s++)
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    pd4[(WIDTH * l + kperm(s, 0, j)) * 8] = dl[s][j];
-            if (l > 0) {
-                d0 = zero16();
-                d1 = zero16();
-                const int base = (l - 1) * MT * KSH;
-#pragma unroll
-                for (int s = 0; s < KSH; s++) {
-                    d0 = mfma(ld_frag(lb, base + s, lane), dl[s], d0);
-                    d1 = mfma(ld_frag(lb, base + KSH + s, lane), dl[s], d1);
-                }
-            }
-        }
-    }
-}
-
 // Round 4: the same arithmetic in two phases per round of tiles, so that the workgroup needs ONE weight image in LDS at a time
 // (54 KB instead of 98: a CU that holds a k_infer workgroup beside gen_rays' five has 66 KB free) and 128 registers instead of 272:
 //   phase 1 (forward image staged): encode, forward chain -- every layer's activations go to HBM the moment they exist and ONE BIT per
 //           activation (is it positive: all the dgrad chain needs of it) stays in registers --, loss and dL/dy;
 //   phase 2 (W^T image staged over the forward image): the dgrad chain from dL/dy and the bits.
-// Bit-identical to k_train_fwd_bwd (NRC_TRAIN_LIGHT=0 selects it; tests/test_gpu_mlp.py compares both with the oracle).
+// (Round 3's one-phase kernel, k_train_fwd_bwd -- both images in LDS, 272 registers -- was bit-identical and is gone: git history.)
 template <int DEPTH, int THREADS>
 __global__ __launch_bounds__(THREADS, 4) void k_train_fwd_bwd_light(TrainArgs a, const uint4* __restrict__ img_fwd,
                                                                    const uint4* __restrict__ img_bwd)
@@ -1229,7 +1118,7 @@ __device__ __forceinline__ void fix_add_global(long long* __restrict__ fix, uint
 }
 __global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ in, const half_t* __restrict__ d_enc, long long* __restrict__ fix,
                                                      uint32_t n, HashLevels lv, GridBins gb, uint32_t* __restrict__ counters,
-                                                     uint2* __restrict__ lists, uint32_t diag_skip_levels)
+                                                     uint2* __restrict__ lists)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     __shared__ uint32_t s_cnt[GB_MAX_BINS], s_base[GB_MAX_BINS];
@@ -1246,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float* __restrict__ 
     const uint32_t nb = gb.count[level];              // (workgroup-uniform)
     for (uint32_t i = threadIdx.x; i < GB_MAX_BINS; i += 256u) s_cnt[i] = 0u;
     __syncthreads();
-    bool act = sample < n && ((diag_skip_levels >> level) & 1u) == 0u;
+    bool act = sample < n;
     float de0 = 0.0f, de1 = 0.0f;
     if (act) {
         de0 = (float)d_enc[(size_t)sample * 32u + 2u * level];
@@ -1716,7 +1605,6 @@ struct TrainArgsGen {
     float* loss_part;
     int depth, ks0;
     half_t* d_enc;        // [n][32] dL/d(first 32 encoded dims) for a trainable encoding (HashGrid), or nullptr
-    int diag_no_store;    // DIAGNOSTIC (NRC_DIAG_SKIP & 16, k_train_gen2): activations and deltas are not written
 };
 
 // Generic training forward + loss + dgrad (any encoding, width 32 / 64 / 128, any depth).  Like k_infer_gen the workgroup streams the
@@ -2008,8 +1896,8 @@ __global__ __launch_bounds__(256, 2) void k_train_gen2(TrainArgsGen a, const uin
                 bn[(t * KSG + 2 * w) * 64 + lane] = __builtin_bit_cast(uint4, lo);
                 bn[(t * KSG + 2 * w + 1) * 64 + lane] = __builtin_bit_cast(uint4, hi);
                 half_t* const tl = ta[t] + (size_t)(e16 + (uint32_t)st * WIDTH) * 8;
-                if (!a.diag_no_store) store_kgroups<true>(kg, lo, lane, tl + (size_t)(16 * (2 * w)) * 8, rows_a);
-                if (!a.diag_no_store) store_kgroups<true>(kg, hi, lane, tl + (size_t)(16 * (2 * w + 1)) * 8, rows_a);
+                store_kgroups<true>(kg, lo, lane, tl + (size_t)(16 * (2 * w)) * 8, rows_a);
+                store_kgroups<true>(kg, hi, lane, tl + (size_t)(16 * (2 * w + 1)) * 8, rows_a);
                 const uint4v wl = __builtin_bit_cast(uint4v, lo), wh = __builtin_bit_cast(uint4v, hi);
                 uint32_t mk = 0u;
 #pragma unroll
@@ -2039,7 +1927,7 @@ __global__ __launch_bounds__(256, 2) void k_train_gen2(TrainArgsGen a, const uin
                 }
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
-                    if (k < ks0 && (k % MTG) == w && !a.diag_no_store) store_kgroups<false>(kg, f0[k], lane, ta[t] + (size_t)(16 * k) * 8, rows_a);
+                    if (k < ks0 && (k % MTG) == w) store_kgroups<false>(kg, f0[k], lane, ta[t] + (size_t)(16 * k) * 8, rows_a);
                     acc[t] = mfma(cur[k], f0[k], acc[t]);
                 }
             }
@@ -2131,7 +2019,7 @@ __global__ __launch_bounds__(256, 2) void k_train_gen2(TrainArgsGen a, const uin
                         }
                         const half8 bd = __builtin_bit_cast(half8, wv);
                         bn[(t * KSG + 2 * w + hf) * 64 + lane] = __builtin_bit_cast(uint4, wv);
-                        if (!a.diag_no_store) store_kgroups<true>(kg, bd, lane, tdl + (size_t)(16 * (2 * w + hf)) * 8, rows_d);
+                        store_kgroups<true>(kg, bd, lane, tdl + (size_t)(16 * (2 * w + hf)) * 8, rows_d);
                     }
                 }
             } else {
@@ -2848,8 +2736,7 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
         const uint32_t n_slots = enc_dims_ / 2;
         dim3 g((uint32_t)num_cus() * 2u, n_slots);
         uint32_t xc = 0;
-        static const bool level_major = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD gathers from every level
-        if (!level_major && xcd8_ && n_slots % 8u == 0u) {      // a level's table is gathered from one XCD (see the kernel)
+        if (xcd8_ && n_slots % 8u == 0u) {      // a level's table is gathered from one XCD (see the kernel)
             xc = (uint32_t)num_cus() * 2u;               // chunks of the list per slot: as many workgroups per slot as before
             g = dim3(8u * xc * (n_slots / 8u), 1);
         }
@@ -2866,8 +2753,7 @@ void Mlp::launch_features(const float* d_in, uint32_t n, bool use_ema, int slot,
         else hipLaunchKernelGGL(k_encode_hash_lm<2>, g, dim3(256), 0, s, d_in, tab, (uint32_t*)feat, n, lv, sk);
         return;
     }
-    static const bool level_major_env = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;
-    const bool level_major2 = level_major_env || !xcd8_;      // (the level-per-XCD mapping is written for eight XCDs)
+    const bool level_major2 = !xcd8_;      // (the level-per-XCD mapping is written for eight XCDs; otherwise every XCD gathers from every level)
     const dim3 g(level_major2 ? ceil_div(n * 16u, 256) : ceil_div(n, 128) * 8u);
     const int mode = (skip_zero ? 1 : 0) | (level_major2 ? 0 : 2);
     if (cfg_.dir_id == 0) hipLaunchKernelGGL(k_encode_hash<0>, g, dim3(256), 0, s, d_in, tab, feat, n, lv, mode);
@@ -3239,14 +3125,6 @@ void Mlp::ensure_train_workspace(uint32_t n)
     }
 }
 
-// DIAGNOSTIC (wrong results, timing only): NRC_DIAG_SKIP=<mask> leaves launches of the training step out -- 1 encode + forward/backward
-// chain, 2 weight-gradient GEMMs, 4 slab reduction, 8 optimizer -- to measure what each costs the FRAME (tools/ab_skip.sh)
-static int diag_skip()
-{
-    static const int m = getenv("NRC_DIAG_SKIP") ? atoi(getenv("NRC_DIAG_SKIP")) : 0;
-    return m;
-}
-
 void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad)
 {
     if (n == 0 || n % 32 != 0) fail("training batch must be a non-zero multiple of 32 samples");
@@ -3254,8 +3132,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
     const uint32_t n_tiles = n / 32;
     constexpr int THREADS = 256;
     uint32_t blocks = ceil_div(n_tiles, THREADS / 64);
-    if (diag_skip() & 1) {
-    } else if (fused_) {
+    if (fused_) {
         TrainArgs a;
         a.in = d_in;
         a.target = d_target;
@@ -3266,13 +3143,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.deltas = (half_t*)d_deltas_;
         a.loss_part = d_loss_part_;
         if (blocks > (uint32_t)num_cus()) blocks = (uint32_t)num_cus();
-#if NRC_TRAIN_LIGHT
         const size_t lds = (size_t)std::max(n_frag_fwd_, n_frag_bwd_) * 1024;      // one image at a time
         auto kernel = k_train_fwd_bwd_light<6, THREADS>;
-#else
-        const size_t lds = ((size_t)n_frag_fwd_ + n_frag_bwd_) * 1024;
-        auto kernel = k_train_fwd_bwd<6, THREADS>;
-#endif
         if (!attr_train_set_) {
             NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_train_set_ = true;
@@ -3294,7 +3166,6 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         a.depth = (int)depth_;
         a.ks0 = (int)enc_dims_ / 16;
         a.d_enc = hash_ ? (half_t*)d_denc_ : nullptr;
-        a.diag_no_store = (diag_skip() & 16) ? 1 : 0;
         // a training batch is a few hundred 32-sample tiles (16 384 rays = 512): four-wave workgroups (128 of them) stream each
         // layer once per four tiles; large batches use eight waves, two workgroups per CU
         const bool small = n_tiles <= (uint32_t)num_cus() * 8u;
@@ -3364,7 +3235,6 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         if (hash_) {
             HashLevels lv;
             for (uint32_t l = 0; l <= HG_LEVELS; l++) lv.off[l] = hg_off_[l];
-            static const uint32_t skip_levels = getenv("NRC_DIAG_GRID_SKIP_LEVELS") ? (uint32_t)strtoul(getenv("NRC_DIAG_GRID_SKIP_LEVELS"), nullptr, 0) : 0u;
             {
                 // bin lists + exact LDS sums for the large levels, the fixed-point shadow for the rest (k_grid_scatter / k_grid_gather)
                 GridBins gb;
@@ -3385,10 +3255,9 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
                     NRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB_BIN * 16u)));
                     attr_gather_set_ = true;
                 }
-                static const bool level_major_env = getenv("NRC_HASH_LEVEL_MAJOR") != nullptr;      // A/B: every XCD works on every level
-                const bool level_major = level_major_env || !xcd8_;
+                const bool level_major = !xcd8_;
                 hipLaunchKernelGGL(k_grid_scatter, level_major ? dim3(ceil_div(n, 256), HG_LEVELS) : dim3(ceil_div(n, 256) * HG_LEVELS, 1), dim3(256), 0, s, d_in, (const half_t*)d_denc_, (long long*)d_grid_fix_, n, lv,
-                                   gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_, skip_levels);
+                                   gb, (uint32_t*)d_grid_counters_, (uint2*)d_grid_lists_);
                 hipLaunchKernelGGL(k_grid_gather, dim3(grid_bins_total_ + loose_chunks), dim3(NRC_GB_GATHER_THREADS), GB_BIN * 16u, s, (uint32_t*)d_grad16_,
                                    (const uint4*)d_grid_bin_entry0_, grid_bins_total_, (uint32_t*)d_grid_counters_, (const uint2*)d_grid_lists_, (long long*)d_grid_fix_, loose);
             }
@@ -3403,8 +3272,7 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
     NRC_HIP(hipGetLastError());
     const uint32_t chunk = wgrad_chunk(n);
     const uint32_t n_chunks = ceil_div(n, chunk);
-    if (diag_skip() & 2) {
-    } else if (wgrad_old_)
+    if (wgrad_old_)
         hipLaunchKernelGGL(k_wgrad, dim3(n_chunks), dim3(WGRAD_WAVES * 64), 0, s, (const half_t*)d_deltas_, (const half_t*)d_acts_, n,
                            depth_ * kw_ + 8, enc_dims_ + depth_ * kw_, (const WgradTile*)d_tiles_, n_wgrad_tiles_, d_slabs_,
                            n_mlp_);
@@ -3413,9 +3281,8 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
                            (const half_t*)d_deltas_, (const half_t*)d_acts_, n, chunk, depth_ * kw_ + 8, enc_dims_ + depth_ * kw_,
                            (const WgradTask*)d_tasks_, n_wgrad_tasks_, d_slabs_, n_mlp_);
     NRC_HIP(hipGetLastError());
-    if (!(diag_skip() & 4))
-        hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_mlp_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_mlp_,
-                           d_grad_, d_loss_part_, n_tiles, d_loss_);
+    hipLaunchKernelGGL(k_reduce_grads, dim3(ceil_div(n_mlp_, 64)), dim3(256), 0, s, d_slabs_, n_chunks, n_mlp_,
+                       d_grad_, d_loss_part_, n_tiles, d_loss_);
     NRC_HIP(hipGetLastError());
 }
 
@@ -3451,7 +3318,6 @@ void Mlp::grid_grad_apply(const uint32_t* d_lists, uint32_t n_lists, uint32_t ca
 bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* loss_cell)
 {
     step += 1;
-    if (diag_skip() & 8) return false;
     const double b1 = 0.9, b2 = 0.999;
     const double t = (double)step;
     const double d = (double)cfg_.ema_decay;
@@ -3483,8 +3349,7 @@ bool Mlp::optimizer_step(hipStream_t s, uint32_t loss_seq, unsigned long long* l
             uint32_t *tt = (uint32_t*)d_t16_train_, *te = (uint32_t*)d_t16_ema_[next];
             uint32_t* g16 = (uint32_t*)d_grad16_;
             if (grid16_valid_) grad16_clean_ = true;      // k_grid_opt<., true> clears the entries it reads
-            static const bool one_entry_per_thread = getenv("NRC_GRID_OPT_SCALAR") != nullptr;      // A/B: round 3's kernel
-            if (!one_entry_per_thread && n_mlp_ % 4u == 0u && n_grid_entries_ % 2u == 0u) {
+            if (n_mlp_ % 4u == 0u && n_grid_entries_ % 2u == 0u) {      // (two entries per thread, 16-byte accesses; else round 3's kernel)
                 const uint32_t np = n_grid_entries_ / 2u;
                 const dim3 g2(ceil_div(np, 256));
                 if (sgd_ && grid16_valid_)

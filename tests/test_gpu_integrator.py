@@ -443,9 +443,8 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
     scene = sc.make_scene(cloud16, scene_id=4)
     frs = sc.frame_randoms(8, seed=21)
     results = []
-    for mode in ("NRC_SINGLE_STREAM", "NRC_TWO_STREAMS", None, None, None, None):     # the full graph several times: races are rare
-        for k in ("NRC_SINGLE_STREAM", "NRC_TWO_STREAMS"):
-            monkeypatch.delenv(k, raising=False)
+    for mode in ("NRC_SINGLE_STREAM", None, None, None, None):     # the full graph several times: races are rare
+        monkeypatch.delenv("NRC_SINGLE_STREAM", raising=False)
         if mode:
             monkeypatch.setenv(mode, "1")
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
@@ -467,25 +466,29 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
         assert np.array_equal(base[4].view(np.uint32), other[4].view(np.uint32))
 
 
-def test_scheduling_choices_of_the_wide_models_change_no_pixel(api, sc, cloud16, torch_gpu, monkeypatch):
-    """what a 128-wide dense model's renderer does differently (end of round 4) is scheduling only: camera kernels at the default wave
-    priority under the library's other kernels (NRC_CAMERA_PRIORITY_LOW), three frames between a cost sample and the launch order made of
-    it (NRC_COST_ORDER_LAG), the XCD-aware finish of that order (NRC_NO_XCD_ROWS / NRC_XCD_WINDOW), round 4's training kernels
-    (NRC_TRAIN_GEN_OLD / NRC_WGRAD_OLD = 1: round 3's) -- after 10 trained, blended frames the framebuffer, the loss and the parameters are
-    the same bit for bit whichever way they are set (the weight-gradient kernels differ in their chunk sums: not toggled here)"""
+def test_no_value_of_the_schedule_changes_a_pixel(api, sc, cloud16, torch_gpu, monkeypatch):
+    """nrc_schedule is scheduling only: camera kernels at the default wave priority under the library's other kernels or at the common one,
+    two or three frames between a cost sample and the launch order made of it, the XCD-aware finish of that order off / narrow / wide,
+    round 3's or round 4's training kernels (NRC_TRAIN_GEN_OLD / NRC_WGRAD_OLD) -- after 10 trained, blended frames the framebuffer, the loss
+    and the parameters are the same bit for bit whichever way they are set (the weight-gradient kernels differ in their chunk sums: not
+    toggled here), and a renderer left to itself reports the neutral start values"""
     W, H = 256, 160
     scene = sc.make_scene(cloud16, scene_id=4)
     frs = sc.frame_randoms(10, seed=33)
-    switches = ("NRC_CAMERA_PRIORITY_LOW", "NRC_COST_ORDER_LAG", "NRC_NO_XCD_ROWS", "NRC_XCD_WINDOW", "NRC_TRAIN_GEN_OLD")
     results = []
-    for env in ({}, {"NRC_CAMERA_PRIORITY_LOW": "0"}, {"NRC_COST_ORDER_LAG": "2"}, {"NRC_NO_XCD_ROWS": "1"}, {"NRC_XCD_WINDOW": "16"},
-                {"NRC_TRAIN_GEN_OLD": "1"}):
-        for k in switches:
-            monkeypatch.delenv(k, raising=False)
+    for sched, env in ((None, {}), (dict(camera_priority_low=1), {}), (dict(cost_order_lag=3), {}), (dict(xcd_window=0), {}),
+                       (dict(xcd_window=16), {}), (dict(camera_priority_low=1, cost_order_lag=3, xcd_window=16), {}), (None, {"NRC_TRAIN_GEN_OLD": "1"})):
+        monkeypatch.delenv("NRC_TRAIN_GEN_OLD", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=3, dir_id=0, nn_width=128, nn_depth=3, train_batch_count=1,
                                         log2_train_batch_size=10)
+        if sched is None:
+            assert ren.GetSchedule() == dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2, composite_defer=0, tuning_done=False)
+        else:
+            ren.SetSchedule(**sched)
+            got = ren.GetSchedule()
+            assert all(got[k] == v for k, v in sched.items())
         ren.SetBlend(True)
         for f in range(10):               # the cost order is sampled at frame 0, 4, 8 and in use from frame 2 / 3 on
             ren.SetFrameRandom(frs[f])
@@ -493,8 +496,7 @@ def test_scheduling_choices_of_the_wide_models_change_no_pixel(api, sc, cloud16,
         results.append((ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy()))
         ren.Destroy()
         nrc.Destroy()
-    for k in switches:
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("NRC_TRAIN_GEN_OLD", raising=False)
     base = results[0]
     assert np.isfinite(base[0]).all() and base[0].max() > 0.0
     for other in results[1:]:
@@ -503,10 +505,51 @@ def test_scheduling_choices_of_the_wide_models_change_no_pixel(api, sc, cloud16,
         assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
 
 
+def test_the_renderer_chooses_its_schedule_on_live_frames_without_changing_them(api, sc, cloud16, torch_gpu):
+    """the Tuner (nrc_api.hip): with the pipeline kept full (render_frames, no host synchronisation) the renderer tries the alternatives of
+    each knob on the caller's own frames and settles -- tuning_done -- within ~330 frames (128 to warm up, 8 trials of 20, the wait for the last); the frames are those of a renderer whose
+    schedule is pinned, bit for bit; pinned knobs keep their values; a host that synchronises after every frame never tunes.  (1080p: the
+    GPU, not the host's enqueue, must bound the frame -- a renderer whose host cannot keep the pipeline full has nothing to measure)"""
+    W, H = 1920, 1080
+    scene = sc.make_scene(sc.cached_volume("cloud", 256, seed=1337), scene_id=4, env=sc.procedural_sky())      # the bench scene: 0.25 ms per frame
+    frs = sc.frame_randoms(640, seed=5)
+
+    def run(pin, feed):
+        cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, log2_train_batch_size=10)
+        if pin:
+            ren.SetSchedule(**pin)
+        ren.SetBlend(True)
+        if feed == "batches":
+            for k in range(0, 640, 32):
+                ren.RenderFrames(frs[k:k + 32], True)
+        else:
+            for f in range(96):
+                ren.SetFrameRandom(frs[f])
+                ren.Render(None, True)
+                torch_gpu.cuda.synchronize()
+        out = (ren.GetImage().cpu().numpy().copy(), nrc.GetParams(0).copy(), ren.GetSchedule())
+        ren.Destroy()
+        nrc.Destroy()
+        return out
+
+    pinned = run(dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2), "batches")
+    free = run(None, "batches")
+    part = run(dict(cost_order_lag=3), "batches")
+    assert pinned[2]["tuning_done"] and free[2]["tuning_done"] and part[2]["tuning_done"]
+    assert part[2]["cost_order_lag"] == 3
+    assert free[2]["camera_priority_low"] in (0, 1) and free[2]["cost_order_lag"] in (2, 3) and free[2]["xcd_window"] in (0, 2, 16)
+    for other in (free, part):
+        assert np.array_equal(pinned[0].view(np.uint32), other[0].view(np.uint32))
+        assert np.array_equal(pinned[1].view(np.uint32), other[1].view(np.uint32))
+    starved = run(None, "sync")
+    assert not starved[2]["tuning_done"] or starved[2] == dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2, composite_defer=0, tuning_done=True)
+    assert (starved[2]["camera_priority_low"], starved[2]["cost_order_lag"], starved[2]["xcd_window"]) == (0, 2, 2)
+
+
 @pytest.mark.parametrize("model", [(2, 2, 64, 3), (3, 0, 128, 2), (3, 0, 64, 6)], ids=["generic-64", "generic-128", "fused"])
 def test_deferred_compositing_inside_render_frames_changes_no_pixel(api, sc, cloud16, torch_gpu, model, monkeypatch):
     """nrc_renderer_render_frames composites every frame but its last on the train-ray stream, one frame late (round 4: stream C --
-    inference, then compositing -- bounds the frame of a heavy model; NRC_COMPOSITE_DEFER=0/1): pure scheduling -- after 3 calls of 4
+    inference, then compositing -- bounds the frame of a heavy model; nrc_schedule.composite_defer): pure scheduling -- after 3 calls of 4
     trained, blended frames the framebuffer, the loss, the parameters and the frame timeline's shape equal the undeferred order and the
     frame-by-frame Render loop bit for bit"""
     W, H = 256, 160
@@ -514,9 +557,9 @@ def test_deferred_compositing_inside_render_frames_changes_no_pixel(api, sc, clo
     frs = sc.frame_randoms(12, seed=27)
     results = []
     for mode in ("0", "1", "1", "1", "loop"):
-        monkeypatch.setenv("NRC_COMPOSITE_DEFER", "1" if mode == "loop" else mode)
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
                                         log2_train_batch_size=10)
+        ren.SetSchedule(composite_defer=0 if mode == "0" else 1)
         ren.SetBlend(True)
         if mode == "loop":
             for f in range(12):
@@ -975,44 +1018,6 @@ def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, tor
         assert same_bits(out[True][k], out[False][k])
     assert out[True][3] == out[False][3]
     assert out[True][0][..., :3].std() > 0.01 and (out[True][0][..., 3] == 1.0).all()
-
-
-def test_split_tiles_change_no_pixel(api, sc, cloud16, torch_gpu, monkeypatch):
-    """NRC_SPLIT_TILES (measured and rejected in round 4, kept as a diagnostic): the costliest tiles launch as two half tiles -- 32
-    pixels on 64 lanes, the ratio walks on lane pairs from the first trip.  The order then lists such a tile twice (upper / lower four
-    rows), every other tile once, and every frame is bit-identical to the unsplit launch"""
-    W, H = 328, 200
-    scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
-    cam = sc.make_camera(aspect=W / H)
-    cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=8, log2_infer_batch_size=14)
-    frs = sc.frame_randoms(8, seed=5)
-    out = {}
-    for split in (64, 0):
-        monkeypatch.setenv("NRC_SPLIT_TILES", str(split))
-        monkeypatch.setenv("NRC_SPLIT_MIN_CYCLES", "20000")
-        nrc = api.NeuralRadianceCache(cfg)
-        ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
-        frames = []
-        for f in range(8):               # the first sort (after frame 0) is in use from frame 2
-            ren.SetFrameRandom(frs[f])
-            ren.Render(None, True)
-            frames.append([ren.Buffer(k).cpu().numpy().copy() for k in ("primary", "info", "infer_input", "train_input", "train_target")])
-        out[split] = (frames, ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), ren.TileOrder())
-        ren.Destroy()
-        nrc.Destroy()
-    for fa, fb in zip(out[64][0], out[0][0]):
-        for a, b in zip(fa, fb):
-            assert same_bits(a, b)
-    assert same_bits(out[64][1], out[0][1]) and out[64][2] == out[0][2]
-    order = out[64][3]
-    n_slots = len(out[0][3])
-    assert len(order) == n_slots + 64
-    live = order[order != 0xFFFFFFFF]
-    slot, part = live & 0x00FFFFFF, live >> 28
-    halves = np.sort(slot[part == 1])
-    assert 0 < len(halves) <= 64 and np.array_equal(halves, np.sort(slot[part == 2])) and len(np.unique(halves)) == len(halves)
-    whole = slot[part == 0]
-    assert np.array_equal(np.sort(np.concatenate([whole, halves])), np.arange(n_slots, dtype=np.uint32))      # every tile exactly once
 
 
 def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc, cloud16, torch_gpu):

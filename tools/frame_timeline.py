@@ -36,7 +36,7 @@ print("mean after start: gen_rays %.3f  train rays %.3f  training %.3f  inferenc
       % (d[:, 1].mean(), d[:, 2].mean(), d[:, 5].mean(), d[:, 3].mean(), d[:, 4].mean(), (tl[6:, 0] - tl[5:-1, 1]).mean()))
 # per-stream busy time per frame: from the moment a stream's work for the frame COULD start (its predecessor on the stream and the events
 # it waits for are done) to its end; columns of tl: 0 gen start, 1 gen done, 2 train rays done, 3 inference done, 4 composite done, 5 training done
-deferred = os.environ.get("NRC_COMPOSITE_DEFER") == "1"
+deferred = False      # (nrc_schedule.composite_defer: off unless the caller sets it)
 busy = {"A gen_rays": [], "D train rays": [], "B training": [], "C inference": [], "composite": []}
 for f in range(6, n):
     busy["A gen_rays"].append(tl[f, 1] - tl[f, 0])
