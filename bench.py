@@ -209,6 +209,50 @@ def cpu_baseline(scene, W, H, budget_s=float(os.environ.get("NRC_BENCH_CPU_BUDGE
                        "same 256^3 cloud/scene/camera, %.1f s" % (threads, sample, t_all))
 
 
+def issue_roofline(gen_ms, kernel="k_gen_rays<false>"):
+    """the ruler the integrator is actually bound by: vector-instruction ISSUE.  From the newest committed counter
+    passes of this command (profiles/rNN_pmc_sq_counters.txt: SQ_INSTS_VALU per launch), the measured issue rate of a SIMD at the kernel's
+    occupancy (profiles/rNN_micro_issue_mix.txt: clocks per vector instruction at five waves per SIMD, tools/issue_mix.hip) and the loop
+    profile of the counter build (profiles/rNN_loop_profile.txt: lanes doing useful work per issued tracking-loop trip).  Constants read from
+    profiles/, labelled with their files; only the kernel's duration is this run's."""
+    import glob
+    import re
+
+    def newest(pattern):
+        hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return hits[-1] if hits else None
+
+    f_sq, f_mix, f_loop = newest("r[0-9][0-9]_pmc_sq_counters.txt"), newest("r[0-9][0-9]_micro_issue_mix.txt"), newest("r[0-9][0-9]_loop_profile.txt")
+    if not f_sq or not f_mix:
+        return None
+    valu = None
+    block = False
+    for ln in open(f_sq):
+        if not ln.startswith(" "):
+            block = ln.startswith(kernel)
+        elif block and ln.split()[0] == "SQ_INSTS_VALU":
+            valu = float(ln.split()[1])
+    m = re.search(r"v_fma_f32, 8 chains.*?5w\s+([0-9.]+)", open(f_mix).read())
+    if valu is None or not m:
+        return None
+    clk_per_inst = float(m.group(1))
+    simds, clock_ghz = 1024, 2.1      # 256 CUs x 4 SIMDs; the clock this kernel holds under load (tools/loop_profile.py stamps, +-5 % by box)
+    floor_ms = valu * clk_per_inst / simds / (clock_ghz * 1e9) * 1e3
+    out = dict(bound="valu-issue", valu_wave_instructions_per_launch=valu, clocks_per_instruction_at_5_waves_per_simd=clk_per_inst,
+               simds=simds, clock_ghz_assumed=clock_ghz, issue_floor_ms=floor_ms, frac=floor_ms / gen_ms if gen_ms > 0 else None,
+               source="%s (SQ_INSTS_VALU per launch), %s (issue rate) -- committed, not measured in this run" % (os.path.basename(f_sq), os.path.basename(f_mix)))
+    if f_loop:
+        util = {}
+        for ln in open(f_loop):
+            mm = re.match(r"(delta_track step|ratio_track step)\s+(\d+)\s+(\d+)\s+([0-9.]+)", ln)
+            if mm:
+                util[mm.group(1).split("_")[0]] = float(mm.group(4))
+        if util:
+            out["tracking_loop_lane_utilisation"] = util
+            out["lane_utilisation_source"] = os.path.basename(f_loop) + " (tools/loop_profile.py, counter build)"
+    return out
+
+
 class Job:
     """one preset on this rank: scene, cache, renderer, exchange; `timed(steps, warmup)` is the contract's timed region"""
 
@@ -543,7 +587,8 @@ def main():
                                       note="look-ups walked by the timed kernel (early-out on); those answered from the LDS occupancy bits included"),
                         traffic=traffic.get("k_gen_rays"), traffic_source=traffic_source, algorithmic_bytes=gen_bytes,
                         bytes_per_pixel="fetches x 1 B + 16 B framebuffer + 32 B query I/O (SURVEY 8d)", stored_bytes=gen_store_bytes,
-                        ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px, fetches_executed_per_pixel=n_fetch_executed / n_px)
+                        ms_per_launch=gen_ms, fetches_per_pixel=n_fetch / n_px, fetches_executed_per_pixel=n_fetch_executed / n_px,
+                        issue=issue_roofline(gen_ms) if (W, H, args.volume, world, args.config) == (1920, 1080, 256, 1, "c2") and north_star else None)
         model = "NRC %dx%d %s+%s" % (args.nn_depth, args.nn_width, {0: "HashGrid(16x2,2^19)", 1: "Identity", 2: "TriangleWave(12)", 3: "Frequency(12)"}[args.pos_id],
                                      {0: "OneBlob(4)", 1: "Identity", 2: "TriangleWave(4)"}[args.dir_id])
         volume = "%d^3 seeded %s" % (args.volume, "smoke plume" if args.smoke_volume else "fBm cloud")
