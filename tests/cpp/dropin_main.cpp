@@ -79,7 +79,25 @@ int main(int argc, char** argv)
         const float loss = nrc.GetLoss();
         nrcHpmRenderer.EvaluateTimestampQueries();
         std::vector<float> image((size_t)W * H * 4);
-        const float* d_image = nrcHpmRenderer.GetImage();
+        const float* d_image = nrcHpmRenderer.GetImageView();      // (the UI's view of the image, src/main.cu:375: the same device pointer)
+        if (d_image != nrcHpmRenderer.GetImage()) throw std::runtime_error("GetImageView != GetImage");
+        // round 5: the parameters in tiny-cuda-nn's own layout and the checkpoint file, through the C++ surface -- a cache of another seed
+        // loaded from this one's checkpoint holds the same 26 624-style vectors, bit for bit
+        {
+            const std::string ckpt = std::string(argv[2]) + ".ckpt";
+            nrc.SaveCheckpoint(ckpt);
+            en::AppConfig other = appConfig;
+            other.c.seed = 4242;
+            en::NeuralRadianceCache nrc2(other);
+            nrc2.LoadCheckpoint(ckpt);
+            if (nrc2.ParamCountTcnn() != nrc.ParamCountTcnn() || nrc.ParamCountTcnn() == 0) throw std::runtime_error("ParamCountTcnn");
+            for (int which = 0; which < 4; which++)
+                if (nrc2.GetParamsTcnn(which) != nrc.GetParamsTcnn(which)) throw std::runtime_error("checkpoint round trip differs");
+            nrc2.SetParamsTcnn(0, nrc.GetParamsTcnn(1));
+            if (nrc2.GetParamsTcnn(0) != nrc.GetParamsTcnn(1)) throw std::runtime_error("SetParamsTcnn / GetParamsTcnn");
+            nrc2.Destroy();
+            std::remove(ckpt.c_str());
+        }
         if (hipMemcpy(image.data(), d_image, image.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
             throw std::runtime_error("hipMemcpy failed");
         FILE* o = std::fopen(argv[2], "wb");
@@ -95,6 +113,9 @@ int main(int argc, char** argv)
             const en::Reference::Result nrcResult = reference.CompareNrc(nrcHpmRenderer, &camera, nullptr);
             en::McHpmRenderer mcHpmRenderer(W, H, 32, true, &camera, hpmScene);                      // src/main.cu:212
             const en::Reference::Result mcResult = reference.CompareMc(mcHpmRenderer, &camera, nullptr);
+            mcHpmRenderer.EvaluateTimestampQueries();                                                // src/main.cu:284
+            if (!(mcHpmRenderer.GetFrameTimeMS() > 0.0f) || mcHpmRenderer.GetImageView() != mcHpmRenderer.GetImage())
+                throw std::runtime_error("McHpmRenderer::EvaluateTimestampQueries / GetFrameTimeMS / GetImageView");
             en::Reference again(W, H, appConfig, hpmScene, nullptr, refRoot, 1u << 30);               // the folder exists: loaded, not rendered
             // (pinned random numbers: CompareMc ends with SetCamera(oldCamera), which clears the accumulation image, so the frame
             // it compared is rendered once more below for the dump)
