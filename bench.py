@@ -511,7 +511,11 @@ def main():
         # (FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 corrections of MI355X_MICROARCH.md) -- a constant read from that
         # file, not measured in this run; quoted only when this run is the profiled workload, and labelled with its source.
         traffic, traffic_source = {}, None
-        for tf in ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json"):
+        def committed(name):      # profiles/rNN_<name>, newest round first
+            import glob
+            return [os.path.relpath(f, ROOT) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)), reverse=True)]
+
+        for tf in committed("pmc_traffic.json"):
             if os.path.exists(os.path.join(ROOT, tf)) and (W, H, args.volume, world, args.config) == (1920, 1080, 256, 1, "c2"):
                 with open(os.path.join(ROOT, tf)) as f:
                     traffic = {k: v["traffic_bytes"] for k, v in json.load(f)["kernels"].items()}
@@ -547,11 +551,11 @@ def main():
 
         mlp_trace, mlp_tail = None, None
         if n_inf == 2073600 and north_star:
-            mlp_trace = trace_duration(("profiles/r04_mlp_kernel_stats.csv", "profiles/r03_mlp_kernel_stats.csv", "profiles/r02_mlp_kernel_stats.csv"), "k_infer")
-            mlp_tail = trace_tail(("profiles/r04_mlp_kernel_trace_tail.txt", "profiles/r03_mlp_kernel_trace_tail.txt"))
+            mlp_trace = trace_duration(committed("mlp_kernel_stats.csv"), "k_infer")
+            mlp_tail = trace_tail(committed("mlp_kernel_trace_tail.txt"))
         elif n_inf == 2073600 and (args.pos_id, args.dir_id, args.nn_width, args.nn_depth) == (3, 0, 128, 8):
-            mlp_trace = trace_duration(("profiles/r04_mlp128_kernel_stats.csv", "profiles/r03_mlp128_kernel_stats.csv", "profiles/r02_mlp128_kernel_stats.csv"), "k_infer_gen")
-            mlp_tail = trace_tail(("profiles/r04_mlp128_kernel_trace_tail.txt", "profiles/r03_mlp128_kernel_trace_tail.txt"))
+            mlp_trace = trace_duration(committed("mlp128_kernel_stats.csv"), "k_infer_gen")
+            mlp_tail = trace_tail(committed("mlp128_kernel_trace_tail.txt"))
         dominant_is_gen = gen_ms >= mlp_ms
         enc_inside = (args.pos_id, args.dir_id) == (3, 0)      # Frequency + OneBlob: encoded inside the MLP kernel
         mlp_kernel = ("k_infer (fused encode + 6x64 MLP)" if north_star else
