@@ -1,7 +1,7 @@
 """Lane-utilisation model of k_gen_rays' tracking loops from the ORACLE's per-walk free-flight counts (analysis tool, not a test:
 `python tests/walk_model.py [W H N]`; it lives under tests/ because it calls the oracle).  For the bench view it prints, per loop of
 the kernel (delta / dir-light / environment walk of vertex 1 and 2), the lane utilisation of today's lock-step loops, and the
-instruction-slot cost of a few wave organisations ("flat loop")."""
+instruction-slot cost of a few wave organisations."""
 import os
 import sys
 import time
