@@ -88,34 +88,36 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// nrc_logf (nrc_math.h) on two arguments
+// ---- the free-flight log (nrc_math.h: nrc_logf).  Its 128-bin table lives in LDS: one instance per kernel that uses it (a file-scope
+// __shared__ object), filled by every wave for itself -- identical values to identical addresses, no workgroup barrier, like
+// load_occupancy_per_wave -- from the constant copy in device memory.
+__device__ const NrcLogBin g_log_tab[128] = {
+#include "nrc_log_table.inc"
+};
+__shared__ NrcLogBin s_log_tab[128];
+__device__ __forceinline__ void fill_log_table()
+{
+    const uint4* src = reinterpret_cast<const uint4*>(g_log_tab);
+    uint4* dst = reinterpret_cast<uint4*>(s_log_tab);
+    dst[threadIdx.x & 63u] = src[threadIdx.x & 63u];      // 64 lanes x 16 bytes = the 1 KB table
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// nrc_logf on two arguments: the table reads and the integer part per argument, the arithmetic packed (bit-identical, see above)
 __device__ __forceinline__ f2 logf2(f2 x)
 {
     const uint32_t i0 = nrc_f2u(x.x), i1 = nrc_f2u(x.y);
-    int e0 = (int)(i0 >> 23) - 126, e1 = (int)(i1 >> 23) - 126;
-    f2 m = f2{nrc_u2f((i0 & 0x007fffffu) | 0x3f000000u), nrc_u2f((i1 & 0x007fffffu) | 0x3f000000u)};
-    const bool lo0 = m.x < 0.707106769084930420f, lo1 = m.y < 0.707106769084930420f;
-    e0 -= lo0 ? 1 : 0;
-    e1 -= lo1 ? 1 : 0;
-    m = (m + f2{lo0 ? m.x : 0.0f, lo1 ? m.y : 0.0f}) - splat(1.0f);      // (m + m) - 1 or (m + 0) - 1 == m - 1
-    f2 z = m * m;
-    f2 y = splat(7.0376836292E-2f);
-    y = fma2(y, m, splat(-1.1514610310E-1f));
-    y = fma2(y, m, splat(1.1676998740E-1f));
-    y = fma2(y, m, splat(-1.2420140846E-1f));
-    y = fma2(y, m, splat(1.4249322787E-1f));
-    y = fma2(y, m, splat(-1.6668057665E-1f));
-    y = fma2(y, m, splat(2.0000714765E-1f));
-    y = fma2(y, m, splat(-2.4999993993E-1f));
-    y = fma2(y, m, splat(3.3333331174E-1f));
-    y = y * m;
-    y = y * z;
-    const f2 fe = f2{(float)e0, (float)e1};
-    y = fma2(splat(-2.12194440e-4f), fe, y);
-    y = fma2(splat(-0.5f), z, y);
-    z = m + y;
-    z = fma2(splat(0.693359375f), fe, z);
-    return z;
+    const f2 fe = f2{(float)__builtin_amdgcn_frexp_expf(x.x), (float)__builtin_amdgcn_frexp_expf(x.y)};     // == ((i >> 23) & 255) - 126 for normal x
+    const f2 m = f2{__builtin_amdgcn_frexp_mantf(x.x), __builtin_amdgcn_frexp_mantf(x.y)};                 // == (i & 0x7fffff) | 0x3f000000
+    const f2 t0 = *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(s_log_tab) + ((i0 >> 13) & 0x3f8u));      // {inv_c, log_c}
+    const f2 t1 = *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(s_log_tab) + ((i1 >> 13) & 0x3f8u));
+    // (the two table entries arrive in two register pairs: the steps that take them are scalar, or each would cost a move to re-pair)
+    const f2 r = f2{nrc_fmaf_(m.x, t0.x, -1.0f), nrc_fmaf_(m.y, t1.x, -1.0f)};
+    f2 q = fma2(r, splat(NRC_THIRD), splat(-0.5f));
+    q = fma2(q, r, splat(1.0f));
+    const f2 s = f2{nrc_fmaf_(fe.x, NRC_LN2, t0.y), nrc_fmaf_(fe.y, NRC_LN2, t1.y)};
+    return fma2(q, r, s);
 }
 
 // correctly rounded sqrt for x == 0 or normal x: v_sqrt_f32 (1 ulp) + the one-ulp fix-up hipcc's own sqrtf lowering uses,
@@ -200,6 +202,7 @@ struct CtxT {
 // construction: the bit says that the byte the gather would have fetched is 0.
 __device__ __forceinline__ const uint32_t* load_occupancy(const DevScene& sc, uint32_t* s_occ)
 {
+    fill_log_table();      // (every kernel that walks the volume draws free flights; the __syncthreads below covers it)
     if (sc.occ_bits == nullptr) return nullptr;
     for (uint32_t i = threadIdx.x; i < sc.occ_words; i += blockDim.x) s_occ[i] = sc.occ_bits[i];
     __syncthreads();
@@ -210,6 +213,7 @@ __device__ __forceinline__ const uint32_t* load_occupancy(const DevScene& sc, ui
 // no workgroup barrier.  occ_words is a multiple of 4 (Scene::build_occupancy_bits).
 __device__ __forceinline__ const uint32_t* load_occupancy_per_wave(const DevScene& sc, uint32_t* s_occ)
 {
+    fill_log_table();
     if (sc.occ_bits == nullptr) return nullptr;
     const uint4* src = reinterpret_cast<const uint4*>(sc.occ_bits);
     uint4* dst = reinterpret_cast<uint4*>(s_occ);
@@ -1419,12 +1423,13 @@ __device__ __forceinline__ bool tile_is_empty(const DevFrame& fr, uint32_t lx, u
 // float_construct(m) and rejects every tentative collision: draws alternate flight, acceptance (path_trace.glsl:163-170)
 __global__ __launch_bounds__(256) void k_flight_table(float* __restrict__ table)
 {
+    fill_log_table();
     const uint32_t m = blockIdx.x * 256u + threadIdx.x;
     float r = float_construct(m);
     float d = 0.0f;
     for (int k = 0; k < 128; k++) {
         const float s = random1(r);
-        d = d - nrc_logf(1.0f - s);
+        d = d - nrc_logf(1.0f - s, s_log_tab);
         r = random1(s);
     }
     table[m] = d;
@@ -2311,11 +2316,12 @@ __global__ __launch_bounds__(256) void k_pad_columns(const float4* __restrict__ 
 __global__ void k_test_math(int fn, const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
                             float* __restrict__ out, float* __restrict__ out2)
 {
+    fill_log_table();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.0f, c = 0.0f;
     switch (fn) {
-    case 0: s = nrc_logf(a[i]); break;
+    case 0: s = nrc_logf(a[i], s_log_tab); break;
     case 1: nrc_sincosf(a[i], &s, &c); break;
     case 2: s = nrc_acosf(a[i]); break;
     case 3: s = nrc_asinf(a[i]); break;

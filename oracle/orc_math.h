@@ -29,32 +29,28 @@ static inline float orc_fmaf_(float a, float b, float c) { return fmaf(a, b, c);
 static inline uint32_t orc_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float orc_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* natural log for normal positive x (call sites pass 1-u, u in [0,1) => [2^-23, 1]) */
+/* natural log for normal positive x (call sites pass 1-u, u in [0,1) => [2^-23, 1]).
+ * Spec (round 5): x = m * 2^e with m in [0.5, 1); bin i = top seven mantissa bits; {inv_c, log_c} = ORC_LOG_TAB[i] (tools/make_log_table.py:
+ * inv_c = RN32(1/c_i), log_c = RN32(-ln(inv_c)), c the bin's centre, the edges for the first and last bin);
+ *   r = fma(m, inv_c, -1);  q = fma(fma(r, 1/3, -1/2), r, 1);  log(x) = fma(q, r, fma(e, LN2, log_c)).
+ * e * LN2 and log(m) are both <= 0 on (0, 1): no cancellation; log(1) = fma(1, LN2, -LN2) + 0 = 0 exactly.  At most 1 ulp from the correctly
+ * rounded value on all 2^23 arguments the integrator can pass (tests/test_oracle_math.py, exhaustive); GLSL asks for 3 ulp / 2^-21. */
+static const float ORC_LOG_TAB[128][2] = {
+#include "orc_log_table.inc"
+};
+#define ORC_LN2 0x1.62e430p-1f
+#define ORC_THIRD 0x1.555556p-2f
 static inline float orc_logf(float x)
 {
     uint32_t ix = orc_f2u(x);
-    int e = (int)(ix >> 23) - 126;
+    int e = (int)((ix >> 23) & 0xffu) - 126;
     float m = orc_u2f((ix & 0x007fffffu) | 0x3f000000u); /* [0.5,1) */
-    if (m < 0.707106769084930420f) { e -= 1; m = (m + m) - 1.0f; }
-    else { m = m - 1.0f; }
-    float z = m * m;
-    float y = 7.0376836292E-2f;
-    y = orc_fmaf_(y, m, -1.1514610310E-1f);
-    y = orc_fmaf_(y, m, 1.1676998740E-1f);
-    y = orc_fmaf_(y, m, -1.2420140846E-1f);
-    y = orc_fmaf_(y, m, 1.4249322787E-1f);
-    y = orc_fmaf_(y, m, -1.6668057665E-1f);
-    y = orc_fmaf_(y, m, 2.0000714765E-1f);
-    y = orc_fmaf_(y, m, -2.4999993993E-1f);
-    y = orc_fmaf_(y, m, 3.3333331174E-1f);
-    y = y * m;
-    y = y * z;
-    float fe = (float)e;
-    y = orc_fmaf_(-2.12194440e-4f, fe, y);
-    y = orc_fmaf_(-0.5f, z, y);
-    z = m + y;
-    z = orc_fmaf_(0.693359375f, fe, z);
-    return z;
+    const float* t = ORC_LOG_TAB[(ix >> 16) & 127u];
+    float r = orc_fmaf_(m, t[0], -1.0f);
+    float q = orc_fmaf_(r, ORC_THIRD, -0.5f);
+    q = orc_fmaf_(q, r, 1.0f);
+    float s = orc_fmaf_((float)e, ORC_LN2, t[1]);
+    return orc_fmaf_(q, r, s);
 }
 
 /* sin and cos of x (radians), |x| up to a few thousand */

