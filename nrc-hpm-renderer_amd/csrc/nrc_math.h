@@ -4,8 +4,8 @@
  * The reference calls GLSL built-ins (log, sin, cos, acos, asin, atan: data/shader/include/path_trace.glsl:36,163,
  * dir_gen.glsl:11-12,49, path_trace.glsl:83, nrc/prep_infer_rays.comp:13-15) whose results are implementation
  * defined.  To make per-pixel control flow reproducible between the CPU oracle and the HIP kernels this build
- * defines them: Cephes-style single-precision polynomials whose Horner steps are explicit single-rounding fused
- * multiply-adds (v_fma_f32 == fmaf on the host); translation units that include this header are compiled with
+ * defines them: Cephes-style single-precision polynomials (log: a 128-bin table reduction and a cubic, see nrc_logf) whose Horner
+ * steps are explicit single-rounding fused multiply-adds (v_fma_f32 == fmaf on the host); translation units that include this header are compiled with
  * -ffp-contract=off so that nothing else is contracted; hipcc's default correctly rounded fp32 / and sqrt are relied upon.  tests/test_gpu_math.py checks these bit-for-bit against the oracle's own statement.
  */
 #ifndef NRC_MATH_H

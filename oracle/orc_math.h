@@ -6,7 +6,7 @@
  * dir_gen.glsl:11-12,49; path_trace.glsl:83; nrc/prep_infer_rays.comp:13-15).
  *
  * GLSL built-ins are implementation defined (no bit-exact spec), so this build *defines* them:
- * Cephes-style single-precision polynomials whose Horner steps are explicit single-rounding
+ * Cephes-style single-precision polynomials (log: a 128-bin table reduction and a cubic, see orc_logf) whose Horner steps are explicit single-rounding
  * fused multiply-adds (fmaf on the host == v_fma_f32 on the device), correctly rounded / and sqrt.  The HIP product carries its own statement of
  * the same polynomials (nrc-hpm-renderer_amd/csrc/nrc_math.h); tests/test_gpu_math.py checks
  * the two bit-for-bit on the GPU.  Compile with -ffp-contract=off.
