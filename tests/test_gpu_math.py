@@ -58,6 +58,20 @@ def test_packed_log_matches_scalar_spec(orc, api, torch_gpu):
     assert np.array_equal(_bits(out2.cpu().numpy()), _bits(orc.math_eval(0, b)[0]))
 
 
+def test_log_is_bit_exact_on_every_argument_the_integrator_can_pass(orc, api, torch_gpu):
+    """the free-flight log is only ever taken of 1 - k * 2^-23: all 2^23 arguments, scalar form and both halves of the packed form, against
+    the oracle's statement (the table in LDS, the frexp instructions and the packed FMAs against integer field extraction and fmaf)"""
+    x = (np.arange(1, 2 ** 23 + 1, dtype=np.float64) * 2.0 ** -23).astype(np.float32)
+    ref = _bits(orc.math_eval(0, x)[0])
+    xs = torch_gpu.from_numpy(x).cuda()
+    out, _ = api.test_math(0, xs)
+    assert np.array_equal(_bits(out.cpu().numpy()), ref)
+    rev = torch_gpu.flip(xs, dims=[0]).contiguous()
+    out, out2 = api.test_math(9, xs, rev)
+    assert np.array_equal(_bits(out.cpu().numpy()), ref)
+    assert np.array_equal(_bits(out2.cpu().numpy()), ref[::-1])
+
+
 def test_box_sdf_sqrt_is_correctly_rounded(orc, api, torch_gpu):
     """sky_sdf's lean sqrt (v_sqrt_f32 + one-ulp fix-up, no denormal path) == the oracle's sqrtf on zero and normal inputs"""
     rng = np.random.default_rng(5)
