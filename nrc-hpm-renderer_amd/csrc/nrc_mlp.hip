@@ -1828,7 +1828,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_train_gen(TrainArgsGen a, const 
 // (one tile per sample group; 179 and 53 KB with two) for an 8-layer net.  Every output element is the same sequence of MFMAs as in k_train_gen: activations, deltas and loss are
 // bit-identical (tests/test_gpu_mlp.py::test_training_kernels_agree).
 template <int WIDTH, int NT>
-__global__ __launch_bounds__(256, 2) void k_train_gen2(TrainArgsGen a, const uint4* __restrict__ img_fwd, const uint4* __restrict__ img_bwd)
+#ifndef NRC_TRAIN_GEN2_MIN_WAVES
+#define NRC_TRAIN_GEN2_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(256, NRC_TRAIN_GEN2_MIN_WAVES) void k_train_gen2(TrainArgsGen a, const uint4* __restrict__ img_fwd, const uint4* __restrict__ img_bwd)
 {
     NRC_RAISE_WAVE_PRIORITY(1);
     constexpr int MTG = WIDTH / 32, KSG = WIDTH / 16, WAVES = 4, SG = WAVES / MTG;      // SG sample groups of MTG waves
@@ -2664,7 +2667,7 @@ Mlp::~Mlp()
     if (d_src_inf_ != d_src_fwd_ && d_src_inf_) dev_free(d_src_inf_);
     if (d_dst_) dev_free(d_dst_);
     void* ptrs[] = {d_w_, d_ema_, d_m_, d_v_, d_grad_, d_pk_infer_[0], d_pk_infer_[1], d_pk_fwd_, d_pk_bwd_, d_src_fwd_,
-                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_tasks_, d_feat_[0], d_feat_[1], d_t16_train_,
+                    d_src_bwd_, d_acts_, d_deltas_, d_slabs_, d_loss_part_, d_tiles_, d_tasks_, d_feat_[0], d_feat_[1], d_feat_[2], d_feat_[3], d_t16_train_,
                     d_t16_ema_[0], d_t16_ema_[1], d_denc_, d_grad16_, d_grid_lists_, d_grid_counters_, d_grid_bin_entry0_, d_grid_fix_};
     for (void* p : ptrs)
         if (p) dev_free(p);
@@ -3125,7 +3128,15 @@ void Mlp::ensure_train_workspace(uint32_t n)
     }
 }
 
-void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad)
+const void* Mlp::pre_encode(const float* d_in, uint32_t n, int parity, hipStream_t s)
+{
+    if (!can_pre_encode()) fail("pre_encode: the model's encoding is trainable or computed inside its kernels");
+    const int slot = 2 + (parity & 1);
+    launch_features(d_in, n, false, slot, s, false);
+    return d_feat_[slot];
+}
+
+void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad, const void* features_ready)
 {
     if (n == 0 || n % 32 != 0) fail("training batch must be a non-zero multiple of 32 samples");
     ensure_train_workspace(n);
@@ -3151,11 +3162,11 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
         }
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, s, a, (const uint4*)d_pk_fwd_, (const uint4*)d_pk_bwd_);
     } else {
-        launch_features(d_in, n, false, 1, s, false);
+        if (features_ready == nullptr) launch_features(d_in, n, false, 1, s, false);
         if (hash_ && !grad16_clean_) NRC_HIP(hipMemsetAsync(d_grad16_, 0, (size_t)n_grid_entries_ * 4, s));      // (k_grid_opt leaves it clean)
         grad16_clean_ = false;
         TrainArgsGen a;
-        a.feat = (const half_t*)d_feat_[1];
+        a.feat = features_ready != nullptr ? (const half_t*)features_ready : (const half_t*)d_feat_[1];
         a.target = d_target;
         a.n = n;
         a.inv_n_total = (float)(1.0 / (3.0 * (double)n_norm));      // 3 * n_norm can exceed 32 bits

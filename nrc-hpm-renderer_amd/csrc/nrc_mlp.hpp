@@ -47,7 +47,15 @@ public:
     // forward (training weights) + loss + backward -> gradient vector (x loss_scale) and loss cell
     // widen_grid_grad (models with a trainable table): also write the table gradient into the fp32 gradient vector -- needed only
     // by readers of the vector (dense exchange, gradient hook, debug read-back); the optimizer reads the packed fp16 table itself
-    void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad = true);
+    // features_ready (generic models): the batch's fp16 features, encoded earlier by pre_encode -- backward() then launches no encoder
+    void backward(const float* d_in, const float* d_target, uint32_t n, uint32_t n_norm, hipStream_t s, bool widen_grid_grad = true,
+                  const void* features_ready = nullptr);
+    // Encodings without trainable state (everything but HashGrid) do not depend on the weights: a caller that has the training inputs
+    // before the training stream is free may encode them elsewhere (the renderer: on the train-ray stream, behind the rays).  Two
+    // buffers of their own, by the caller's parity (not the one backward() encodes into: a step that encodes for itself may still be
+    // reading that one); returns the features of the n samples at d_in.
+    bool can_pre_encode() const { return !fused_ && !hash_; }
+    const void* pre_encode(const float* d_in, uint32_t n, int parity, hipStream_t s);
     // the gradient vector was written from outside (exchange result, hook, nrc_cache_set_params): it is what the optimizer reads
     void grad_vector_is_source() { grid16_valid_ = false; }
     // EMA{Adam} step + re-pack of the fp16 MFMA fragment images.  loss_cell (host-mapped, may be null): where the step's
@@ -100,8 +108,8 @@ private:
     bool sgd_ = false;           // nested optimizer: Adam (default) or SGD
     bool fused_ = false;         // north-star model (Frequency+OneBlob, 6x64): fully fused kernels; otherwise the generic path
     std::vector<MlpLayer> layers_;
-    void* d_feat_[2] = {nullptr, nullptr};     // generic path: fp16 features [n][enc_dims]; [0] inference, [1] training
-    uint32_t feat_n_[2] = {0, 0};
+    void* d_feat_[4] = {nullptr, nullptr, nullptr, nullptr};     // generic path: fp16 features [n][enc_dims]; [0] inference, [1] training (encoded by backward), [2] [3] training (pre_encode, by parity)
+    uint32_t feat_n_[4] = {0, 0, 0, 0};
     int infer_set_ = 0;          // which of the double-buffered inference (EMA) image / table sets is current
     uint32_t n_mlp_ = 0;         // matrix parameters; (posID 0) the hash-grid table [entry][2] follows them in every vector
     bool hash_ = false;

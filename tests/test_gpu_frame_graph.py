@@ -159,3 +159,40 @@ def test_two_renderers_share_one_cache_without_host_sync(api, sc, cloud16, torch
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
     assert a[2] == b[2] and np.array_equal(a[3], b[3])
     assert np.isfinite(a[1]).all() and a[1][..., :3].max() > 0
+
+
+def test_training_features_encoded_ahead_survive_changes_of_the_cache_owner(api, sc, cloud16, torch_gpu):
+    """A generic model whose encoding has no trainable state gets its training batch encoded on the train-ray stream, ahead of the
+    backward pass (Mlp::pre_encode) -- only for a renderer that has held the cache for its last two frames, because a change of owner
+    orders the new owner's inference and training streams behind the old one's work, not the stream the features are written on.  Two
+    renderers that both train one 4x32 cache, in runs of several frames and in alternation, nothing synchronised on the host: the same
+    frames, loss and weights as with a device-wide synchronisation after every Render, bit for bit."""
+    W, H = 256, 160
+    scene = sc.make_scene(cloud16, scene_id=4)
+    order = [0] * 4 + [1] + [0] * 4 + [1] * 4 + [0, 1] * 3 + [0] * 3      # which renderer renders (and trains on) frame f
+    frs = sc.frame_randoms(len(order), seed=73)
+    cam_b = sc.make_camera(pos=(0.0, 10.0, 64.0), view_dir=(0.0, -0.1, -1.0), aspect=W / H)
+
+    def run(sync):
+        cfg, nrc, cam, ren_a = _nrc_setup(api, sc, scene, W, H, pos_id=2, dir_id=2, nn_width=32, nn_depth=4, train_batch_count=2,
+                                          log2_train_batch_size=9)
+        ren_b = api.NrcHpmRenderer(W, H, False, cam_b, cfg, scene, nrc)
+        rens = (ren_a, ren_b)
+        for f, who in enumerate(order):
+            rens[who].SetFrameRandom(frs[f])
+            rens[who].Render(None, True)
+            if sync:
+                torch_gpu.cuda.synchronize()
+        out = (ren_a.GetImage().cpu().numpy().copy(), ren_b.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy(),
+               nrc.GetParams(1).copy())
+        ren_b.Destroy()
+        ren_a.Destroy()
+        nrc.Destroy()
+        return out
+
+    a = run(True)
+    for _ in range(3):      # (races are rare: the free-running sequence several times)
+        b = run(False)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert a[2] == b[2] and np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
+    assert np.isfinite(a[0]).all() and a[0][..., :3].max() > 0

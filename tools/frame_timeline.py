@@ -1,5 +1,5 @@
 """Per-frame event timeline of the four-stream frame graph on one bench preset (nrc_renderer_frame_timeline): which stream does a
-pipelined frame wait for?   python3 tools/frame_timeline.py [bench args] [--frames K]
+pipelined frame wait for?   python3 tools/frame_timeline.py [bench args] [--frames K] [--settle STEPS]
 prints, per frame: the start of gen_rays and, relative to it, the end of gen_rays / train rays / training / inference / compositing,
 plus the idle time of the render stream in front of the launch."""
 import os, sys
@@ -11,12 +11,15 @@ argv = sys.argv[1:]
 frames = 12
 if "--frames" in argv:
     i = argv.index("--frames"); frames = int(argv[i + 1]); del argv[i:i + 2]
+settle = 40      # steps in front of the recorded ones (--settle 300: behind the renderer's schedule trials)
+if "--settle" in argv:
+    i = argv.index("--settle"); settle = int(argv[i + 1]); del argv[i:i + 2]
 args = bench.parse_args(argv)
 strong = bench.apply_preset(args)
 import torch
 job = bench.Job(args, strong, 0, 1, False, False)
 job.prepare(200, 10)
-for _ in range(40):
+for _ in range(settle):
     job.step()
 torch.cuda.synchronize()
 job.ren.ResetStageStats()
@@ -46,4 +49,5 @@ for f in range(6, n):
     busy["composite"].append(tl[f, 4] - max(tl[f, 3], tl[f - 1, 4]))
 iv = (tl[-1, 0] - tl[5, 0]) / (n - 6)
 print("busy per frame (ms; interval %.4f): " % iv + "  ".join("%s %.3f" % (k, float(np.mean(v))) for k, v in busy.items()))
+print("schedule:", job.ren.GetSchedule())
 job.close()
