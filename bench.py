@@ -59,6 +59,11 @@ def parse_args(argv=None):
     ap.add_argument("--nn-width", type=int, default=64)
     ap.add_argument("--nn-depth", type=int, default=6)
     ap.add_argument("--smoke-volume", action="store_true", help="configs[4]: seeded smoke plume instead of the fBm cloud")
+    ap.add_argument("--compat-fix", type=int, default=0,
+                    help="nrc_config.compat_fix: 0 = the reference's behaviour as shipped (quirk Q2: training targets are single-vertex estimates, "
+                         "the CLI's trainRayLength 32 is ignored, src/NrcHpmRenderer.cu:991-994 vs :1036-1055), 2 = Q2 fixed (train ray length 32: "
+                         "the algorithm the CLI asks for), 1 / 3 = Q1 (TRAIN_Y_DIST) fixed as well")
+    ap.add_argument("--no-quality", action="store_true", help="skip the untimed quality leg (the trained frame against this build's own MC ground truth)")
     ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="BASELINE.json preset (see the module docstring)")
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: the frame named by --config / --width / --height IS the global frame and the global train batch stays 16 384 "
@@ -253,6 +258,63 @@ def issue_roofline(gen_ms, kernel="k_gen_rays<false>"):
     return out
 
 
+def quality_leg(job, mc_ms_per_frame, trained_frames, train_to=512, eval_frames=32, gt_frames=256):
+    """What the timed path buys (VERDICT r05 "missing" 2), UNTIMED and after the timed region: the reference's own self-check --
+    Reference::CompareNrc (src/Reference.cpp:72-107: the NRC image rendered without training, compared through cmp1/cmp2.comp =
+    nrc_compare_images) -- of the cache this run trained, against this build's own ground truth of the bench scene generated like
+    Reference::GenRefImages (src/Reference.cpp:566-606: McHpmRenderer, PATH_LENGTH 64, blended).  (The reference's EXRs are of ITS cloud and
+    scenes: tools/convergence.py and tests/test_gpu_quality.py compare against those; profiles/r06_convergence_*.txt.)  One evaluation frame
+    is one path per pixel -- its MSE is the primary path's noise -- so `eval_frames` evaluation frames are blended; the same wall time of
+    plain Monte-Carlo frames is evaluated beside it.  In the faithful mode (quirk Q2) the cache can only learn the third vertex's direct
+    light: `faithful_limit` is the image McHpmRenderer renders with PATH_LENGTH 3, the frame the faithful path converges to."""
+    import math
+    torch, api, sc, args = job.torch, job.api, job.sc, job.args
+    W, H = job.local_w, job.gh
+
+    def result(ref, img):
+        r = api.CompareImages(ref, img)
+        return dict(mse=r["mse"], rel_bias=(r["own_mean"] - r["ref_mean"]) / r["ref_mean"] if r["ref_mean"] else None,
+                    cv=math.sqrt(max(r["own_var"], 0.0)) / r["own_mean"] if r["own_mean"] else None)
+
+    def mc_image(path_length, frames, seed):
+        mc = api.McHpmRenderer(W, H, path_length, True, job.cam, job.scene)
+        frs = sc.frame_randoms(frames, seed=seed)
+        for f in range(frames):
+            mc.SetFrameRandom(frs[f])
+            mc.Render()
+        img = mc.GetImage().clone()
+        torch.cuda.synchronize()
+        mc.Destroy()
+        return img
+
+    more = max(0, train_to - trained_frames)
+    if more and args.train:
+        job.ren.RenderFrames(sc.frame_randoms(more, seed=2024), True)
+        trained_frames += more
+    gt = mc_image(64, gt_frames, 31337)
+    ev = api.NrcHpmRenderer(W, H, True, job.cam, job.cfg, job.scene, job.nrc)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev.RenderFrames(sc.frame_randoms(eval_frames, seed=4242), False)
+    torch.cuda.synchronize()
+    eval_ms = (time.perf_counter() - t0) * 1e3
+    q = result(gt, ev.GetImage())
+    ev.Destroy()
+    n_mc = max(1, int(eval_ms / mc_ms_per_frame + 0.5))
+    mc_same = result(gt, mc_image(32, n_mc, 777))
+    limit = result(gt, mc_image(3, 64, 999))
+    return dict(what="Reference::CompareNrc on the trained cache: %d blended evaluation frames (train = false) vs own ground truth"
+                     % eval_frames,
+                reference="McHpmRenderer PATH_LENGTH 64, %d blended frames of the bench scene (its own noise, ~single-frame MC MSE / %d, is inside `mse`)"
+                          % (gt_frames, gt_frames),
+                frames=trained_frames, eval_frames=eval_frames, eval_ms=eval_ms, rel_bias=q["rel_bias"], mse=q["mse"], cv=q["cv"],
+                mc_equal_time=dict(frames=n_mc, mse=mc_same["mse"], rel_bias=mc_same["rel_bias"],
+                                   note="McHpmRenderer PATH_LENGTH 32 blended for the evaluation frames' wall time"),
+                faithful_limit=dict(rel_bias=limit["rel_bias"],
+                                    note="McHpmRenderer PATH_LENGTH 3 (64 frames): what the frame converges to while quirk Q2 keeps the training "
+                                         "targets single-vertex estimates; with --compat-fix 2 the limit is the ground truth itself"))
+
+
 class Job:
     """one preset on this rank: scene, cache, renderer, exchange; `timed(steps, warmup)` is the contract's timed region"""
 
@@ -278,7 +340,9 @@ class Job:
             self.log2_train = 14 - (world.bit_length() - 1)
         cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=self.log2_train, log2_infer_batch_size=21, scene_id=4,
                             primary_ray_length=1, primary_ray_prob=0.0, train_spp=1, train_ring_buf_size=1.0, seed=1337,
-                            pos_id=args.pos_id, dir_id=args.dir_id, nn_width=args.nn_width, nn_depth=args.nn_depth)
+                            pos_id=args.pos_id, dir_id=args.dir_id, nn_width=args.nn_width, nn_depth=args.nn_depth,
+                            train_ray_length=32, compat_fix=int(getattr(args, "compat_fix", 0)))      # (trainRayLength: src/main.cu:438)
+        self.cfg, self.cam = cfg, cam
         self.nrc = api.NeuralRadianceCache(cfg)
         self.ren = api.NrcHpmRenderer(self.local_w, self.gh, True, cam, cfg, self.scene, self.nrc, tile=tile)
         self.exchange = dict(path="none", rccl_rank=None, rccl_ranks=0)
@@ -459,6 +523,9 @@ def main():
     n_fetch = count(False)
     n_fetch_executed = count(True)
     n_px = local_w * gh
+    quality = None
+    if world == 1 and args.train and not args.no_quality:
+        quality = quality_leg(job, mc_baseline["ms_per_frame"], (args.steps + args.warmup) * spp + 8)
 
     out = None
     if rank == 0:
@@ -597,16 +664,20 @@ def main():
                                      {0: "OneBlob(4)", 1: "Identity", 2: "TriangleWave(4)"}[args.dir_id])
         volume = "%d^3 seeded %s" % (args.volume, "smoke plume" if args.smoke_volume else "fBm cloud")
         train_rays = 1 << log2_train
+        fix = int(args.compat_fix)
+        quirks = ("faithful to the reference as shipped: quirks Q1 (train-grid y stride) and Q2 (SINGLE-VERTEX training targets; the CLI's "
+                  "trainRayLength 32 is ignored)" if fix == 0 else
+                  "compat_fix %d: %s" % (fix, " + ".join(n for b, n in ((1, "Q1 fixed"), (2, "Q2 fixed (training targets of up to 32 vertices, as the CLI asks)")) if fix & b)))
         if args.config == "c4" or strong:
             workload = (("configs[3]" if args.config == "c4" else "configs[1]+[2] as strong scaling" if args.config == "c2" else "configs[4] as strong scaling") +
                         ": ONE %dx%d frame sharded into %d tiles of interleaved 8-column strips (%d columns on rank 0), %s, %d spp/step, %s, HDR sky "
-                        "env map, scene preset 4, train=%d (global batch 16384 rays = %d per rank + 1 Adam step per sub-frame)"
-                        % (gw, gh, world, local_w, volume, spp, model, args.train, train_rays))
+                        "env map, scene preset 4, train=%d (global batch 16384 rays = %d per rank + 1 Adam step per sub-frame); %s"
+                        % (gw, gh, world, local_w, volume, spp, model, args.train, train_rays, quirks))
         else:
             per_gpu = "%dx%d per GPU" % (W, H) if world == 1 else "1/%d of the same view at %dx%d (%d x %d pixels on rank 0; %dx%d on one GPU)" % (world, gw, gh, local_w, gh, W, H)
             workload = ("%s: %s (global %dx%d, tiles of interleaved 8-column strips), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
-                        "train=%d (%d train rays + 1 Adam step per sub-frame)"
-                        % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", per_gpu, gw, gh, volume, spp, model, args.train, train_rays))
+                        "train=%d (%d train rays + 1 Adam step per sub-frame); %s"
+                        % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", per_gpu, gw, gh, volume, spp, model, args.train, train_rays, quirks))
         exchange = dict(exchange, allreduce_us_per_step=allreduce_us, frame_assembly=assembly)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
@@ -614,7 +685,7 @@ def main():
             "ms_per_frame": ms_per_step / spp, "host_enqueue_ms_per_frame": host_enqueue_ms, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f16 (fp16 MFMA operands, fp32 accumulate; fp32 integrator)", "data": "synthetic",
             "config": {"workload": workload, "preset": args.config,
-                       "width": W, "height": H, "spp": spp, "volume": args.volume, "train": args.train,
+                       "width": W, "height": H, "spp": spp, "volume": args.volume, "train": args.train, "compat_fix": int(args.compat_fix),
                        "parallelism": "pixel-column tiles x%d%s" % (world, " + RCCL grad all-reduce" if use_dist and args.train else "")},
             "exchange": exchange,
             "stage_ms": {k: stats[k] for k in ("gen_rays", "prep_train", "train", "infer", "render", "total")},
@@ -625,6 +696,7 @@ def main():
             "roofline_mlp": roof_mlp,
             "roofline_integrator": roof_gen,
             "gpu_mc_baseline": mc_baseline,
+            "quality": quality,
         }
     job.close()
 

@@ -329,7 +329,7 @@ int nrc_renderer_set_empty_skip(nrc_renderer_t* r, int on);
  * with and without.  tile_order copies the permutation in use (n = nrc_renderer_tile_order(r, NULL, 0) entries) to the host. */
 /* The SCHEDULE of a renderer's frame graph: where and in which order work is placed -- no value changes a pixel or a weight (the tests render
  * under every combination and compare bit for bit).  The library chooses these itself: it starts from neutral values and, once the pipeline
- * has run for 64 frames, tries the alternatives on the caller's own frames against its frame timeline (one knob at a time, 24 frames per value,
+ * has run for 128 frames, tries the alternatives on the caller's own frames against its frame timeline (one knob at a time, 24 frames per value,
  * the current value timed before and after the alternatives; ~250 frames in all) and keeps what is more than 1.5 % faster.  A caller that
  * knows better pins a knob with a value >= 0; -1 hands it (back) to the library.
  *   camera_priority_low  1: the camera kernels run at the default wave priority under the library's other kernels (pays where the

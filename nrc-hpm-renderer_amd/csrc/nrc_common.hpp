@@ -61,9 +61,24 @@ inline void launch_last(K kernel, dim3 grid, dim3 block, uint32_t shmem, hipStre
 inline void finish_launch_tail(hipStream_t s)
 {
     LaunchTail& t = launch_tail();
-    if (t.stop != nullptr) NRC_HIP(hipEventRecord(t.stop, s));
-    t = LaunchTail{};
+    const LaunchTail left = t;
+    t = LaunchTail{};      // (cleared first: a failing record below must not leave the slot armed)
+    if (left.start != nullptr) NRC_HIP(hipEventRecord(left.start, s));      // nobody launched: an empty interval, but a recorded event
+    if (left.stop != nullptr) NRC_HIP(hipEventRecord(left.stop, s));
 }
+// An armed tail must not outlive the stage it was armed for: an exception between arm and finish would hand its events to the next
+// launch_last of this thread -- another stream, another renderer.  Stages therefore arm through a scope; its end records what no launch took.
+struct LaunchTailScope {
+    hipStream_t s;
+    bool open = false;
+    explicit LaunchTailScope(hipStream_t s_) : s(s_) {}
+    LaunchTailScope(hipStream_t s_, hipEvent_t stop, hipEvent_t start = nullptr) : s(s_) { arm(stop, start); }
+    LaunchTailScope(const LaunchTailScope&) = delete;
+    LaunchTailScope& operator=(const LaunchTailScope&) = delete;
+    void arm(hipEvent_t stop, hipEvent_t start = nullptr) { arm_launch_tail(stop, start); open = true; }
+    void finish() { if (open) { open = false; finish_launch_tail(s); } }
+    ~LaunchTailScope() { if (open) { try { finish_launch_tail(s); } catch (...) { launch_tail() = LaunchTail{}; } } }
+};
 
 // XCDs (accelerator complex dies, each with its own L2) of the current device.  Several launch mappings hand the work of one table level /
 // one screen band to the workgroups of ONE XCD (workgroup b runs on XCD b mod count: round-robin dispatch) -- a placement for speed only,

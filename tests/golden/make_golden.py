@@ -7,6 +7,9 @@ Inputs  (data, not source):  /root/reference/data/volume/wdas_cloud_sixteenth.vd
 Outputs: cloud_sixteenth_u8.npz   density volume quantised like src/Texture3D.cpp:106 (texture memory order [k][j][i])
          exr_stats.json           per-image statistics
          exr_{0,4}_240x135.npz    8x8 box-filtered RGBA of the two EXRs whose estimator matches the checked-in shaders
+         exr_{0,4}_1920x1080.npz  the same two EXRs at full size, lossless: the images are grey (R = G = B, asserted), so
+                                  {L = R, A} in fp32 is every number they hold (3.5 MB each) -- what Reference::CompareNrc
+                                  (src/Reference.cpp:72-107) compares a frame with; tools/convergence.py and the quality tests use them
 """
 import json
 import os
@@ -45,6 +48,8 @@ def main():
         if sid in (0, 4):
             ds = img.reshape(135, 8, 240, 8, 4).mean(axis=(1, 3)).astype(np.float32)
             np.savez_compressed(os.path.join(OUT, "exr_%d_240x135.npz" % sid), rgba=ds)
+            assert (img[..., 0] == img[..., 1]).all() and (img[..., 0] == img[..., 2]).all()
+            np.savez_compressed(os.path.join(OUT, "exr_%d_1920x1080.npz" % sid), L=img[..., 0].copy(), A=img[..., 3].copy())
     with open(os.path.join(OUT, "exr_stats.json"), "w") as f:
         json.dump(stats, f, indent=1, sort_keys=True)
     print(json.dumps(stats, indent=1))
