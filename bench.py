@@ -63,6 +63,9 @@ def parse_args(argv=None):
                     help="nrc_config.compat_fix: 0 = the reference's behaviour as shipped (quirk Q2: training targets are single-vertex estimates, "
                          "the CLI's trainRayLength 32 is ignored, src/NrcHpmRenderer.cu:991-994 vs :1036-1055), 2 = Q2 fixed (train ray length 32: "
                          "the algorithm the CLI asks for), 1 / 3 = Q1 (TRAIN_Y_DIST) fixed as well")
+    ap.add_argument("--exchange", choices=["f32", "f16"], default="f32",
+                    help="N > 1: what the per-step gradient all-reduce carries (nrc_cache_set_exchange_dtype): the fp32 vector (103 KB, default) or "
+                         "the gradients as fp16 numbers pre-scaled by loss_scale 128 (52 KB; BASELINE.json configs[3] words it so)")
     ap.add_argument("--no-quality", action="store_true", help="skip the untimed quality leg (the trained frame against this build's own MC ground truth)")
     ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="BASELINE.json preset (see the module docstring)")
     ap.add_argument("--strong", action="store_true",
@@ -352,7 +355,7 @@ class Job:
             try:
                 if shared_gpu:
                     raise RuntimeError("NRC_BENCH_SHARED_GPU=1: all ranks share one device, RCCL needs one device per rank")
-                parallel.attach_gradient_allreduce(self.nrc, world)
+                parallel.attach_gradient_allreduce(self.nrc, world, dtype=getattr(args, "exchange", "f32"))
                 r_, w_ = self.nrc.CommInfo()              # what ncclCommUserRank / ncclCommCount say
                 self.exchange = dict(path="native (nrc_cache_comm_init -> ncclAllReduce on the training stream)", rccl_rank=r_, rccl_ranks=w_,
                                      grid_gradient_lists=self.nrc.CommSparse())
@@ -360,7 +363,7 @@ class Job:
                     raise RuntimeError("RCCL communicator reports %d ranks, expected %d" % (w_, world))
             except RuntimeError as e:
                 print("warning: native RCCL exchange unavailable (%s); using the torch.distributed hook" % e, file=sys.stderr)
-                parallel.attach_gradient_allreduce(self.nrc, world, native=False)
+                parallel.attach_gradient_allreduce(self.nrc, world, native=False, dtype=getattr(args, "exchange", "f32"))
                 self.exchange = dict(path="torch.distributed hook (%s)" % dist.get_backend(), rccl_rank=rank, rccl_ranks=world)
                 if world > 1 and dist.get_backend() == "nccl":
                     api.set_wave_priority_raise(False)      # torch's RCCL kernels run beside the library's: one priority for all (nrc_hpm.h)
@@ -507,6 +510,7 @@ def main():
     torch.cuda.synchronize()
     ren.StageStats(reset=True)
     allreduce_us = job.allreduce_us() if use_dist and args.train else None
+    nrc_dtype = nrc.GetExchangeDtype()
     assembly = job.frame_assembly_ms()
 
     # ---- integrator traffic model: density look-ups counted on the device for extra (untimed) sub-frames of the same seed --
@@ -678,7 +682,10 @@ def main():
             workload = ("%s: %s (global %dx%d, tiles of interleaved 8-column strips), %s, %d spp/step, %s, HDR sky env map, scene preset 4, "
                         "train=%d (%d train rays + 1 Adam step per sub-frame); %s"
                         % ("configs[4]" if args.config == "c5" else "configs[1]+[2]", per_gpu, gw, gh, volume, spp, model, args.train, train_rays, quirks))
-        exchange = dict(exchange, allreduce_us_per_step=allreduce_us, frame_assembly=assembly)
+        exchange = dict(exchange, dtype=nrc_dtype, allreduce_us_per_step=allreduce_us, frame_assembly=assembly)
+        if world > 1 and args.train:
+            # an N-GPU line is a line about N ranks exchanging gradients: refuse to print one whose exchange saw another number of ranks
+            assert exchange["rccl_ranks"] == world, "the gradient exchange ran over %r ranks, the line says %d GPUs" % (exchange["rccl_ranks"], world)
         out = {
             "metric": "Msamples/s + ms/frame at 1080p, 256^3 cloud (NRC path)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

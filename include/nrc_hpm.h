@@ -130,6 +130,19 @@ float* nrc_cache_loss_ptr(nrc_cache_t* c);
  * gradient vector + loss cell with ncclAllReduce on the training stream and normalises the loss by the global batch. */
 int nrc_comm_unique_id(void* out128);
 int nrc_cache_comm_init(nrc_cache_t* c, const void* unique_id128, int rank, int world);
+/* What travels in that exchange (BASELINE.json configs[3]: "RCCL fp16 grad all-reduce"; SURVEY.md 8e recommends both):
+ *   NRC_EXCHANGE_F32 (default)  the fp32 gradient vector + loss cell, one ncclAllReduce(ncclFloat) of param_count + 2 words (103 KB for 6 x 64)
+ *   NRC_EXCHANGE_F16            the gradients as tiny-cuda-nn holds them -- fp16, pre-scaled by loss_scale 128 (the local sum is accumulated in
+ *                               fp32 and rounded ONCE) -- summed by ncclAllReduce(ncclHalf) (52 KB), widened back into the fp32 vector the
+ *                               optimizer reads; the loss cell stays fp32, grouped with it.  A HashGrid model's matrices travel the same way,
+ *                               its table lists carry fp16 values in either mode.  Replicas stay bit-identical (every rank receives the same
+ *                               sum).  A gradient hook (nrc_cache_set_grad_hook) is handed fp16-rounded values in the fp32 vector and its
+ *                               result is rounded again: for two ranks exactly the fp16 sum.
+ * Set on every rank alike, before the first training step; nrc_cache_get_exchange_dtype returns the mode in use. */
+#define NRC_EXCHANGE_F32 0
+#define NRC_EXCHANGE_F16 1
+int nrc_cache_set_exchange_dtype(nrc_cache_t* c, int dtype);
+int nrc_cache_get_exchange_dtype(nrc_cache_t* c);
 /* rank / size as the library's own RCCL communicator reports them (ncclCommUserRank / ncclCommCount); world = 0: none */
 int nrc_cache_comm_info(nrc_cache_t* c, int* rank, int* world);
 /* Failure detection on the exchange ("RCCL error -> status code").  An enqueued collective reports nothing by itself:

@@ -330,6 +330,9 @@ public:
     void CommInit(const void* uniqueId128, int rank, int world) { nrc_check(nrc_cache_comm_init(h_, uniqueId128, rank, world)); }
     void CommInfo(int* rank, int* world) const { nrc_check(nrc_cache_comm_info(h_, rank, world)); }
     bool CommSparse() const { return nrc_cache_comm_sparse(h_) != 0; }      // HashGrid table gradient exchanged as lists
+    // what the exchange carries: NRC_EXCHANGE_F32 (default) or NRC_EXCHANGE_F16 -- the gradients as fp16 numbers pre-scaled by loss_scale
+    void SetExchangeDtype(int dtype) { nrc_check(nrc_cache_set_exchange_dtype(h_, dtype)); }
+    int GetExchangeDtype() const { return nrc_cache_get_exchange_dtype(h_); }
     // frame gather / metric reduction over a transport of the host's own (a cache without CommInit): include/nrc_hpm.h
     void SetCollectiveHooks(int rank, int world, nrc_allreduce_f64_fn allreduce, nrc_allgather_fn allgather, void* user)
     {

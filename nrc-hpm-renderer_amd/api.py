@@ -71,6 +71,7 @@ ABI_SYMBOLS = [
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
     "nrc_comm_unique_id", "nrc_cache_comm_init", "nrc_cache_comm_sparse", "nrc_cache_grid_list_capacity",
+    "nrc_cache_set_exchange_dtype", "nrc_cache_get_exchange_dtype",
     "nrc_cache_grid_grad_pack", "nrc_cache_grid_grad_apply",
     "nrc_cache_set_stream", "nrc_cache_set_grad_hook", "nrc_cache_get_params", "nrc_cache_set_params",
     "nrc_cache_get_step", "nrc_cache_set_step", "nrc_cache_param_count_tcnn", "nrc_cache_get_params_tcnn", "nrc_cache_set_params_tcnn",
@@ -383,6 +384,14 @@ class NeuralRadianceCache:
         """(debug) gradient vector's table part := sum of the lists (GridGradPack layout), added in the order given"""
         v = np.ascontiguousarray(np.stack(lists), np.uint32)
         _check(self.L.nrc_cache_grid_grad_apply(self.h, v.ctypes.data_as(C.c_void_p), C.c_uint32(v.shape[0])))
+
+    def SetExchangeDtype(self, dtype):
+        """nrc_cache_set_exchange_dtype: "f32" (default) or "f16" -- the gradients summed over the ranks as fp16 numbers pre-scaled by
+        loss_scale 128 (BASELINE.json configs[3]); every rank alike"""
+        _check(self.L.nrc_cache_set_exchange_dtype(self.h, C.c_int({"f32": 0, "f16": 1}[dtype])))
+
+    def GetExchangeDtype(self):
+        return "f16" if self.L.nrc_cache_get_exchange_dtype(self.h) == 1 else "f32"
 
     def SetLossNormFactor(self, factor):
         _check(self.L.nrc_cache_set_loss_norm_factor(self.h, C.c_uint32(factor)))

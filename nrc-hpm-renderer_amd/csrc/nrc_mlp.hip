@@ -1105,9 +1105,19 @@ __device__ __forceinline__ long long half_to_fix(uint32_t h)
     const long long v = (long long)(m << (e ? e - 1u : 0u));
     return (h & 0x8000u) ? -v : v;
 }
+// the exact 64-bit sum -> fp16, rounded ONCE (int64 -> fp32 -> fp16 were two roundings, and a sum within half an fp32 ulp of an
+// fp16 tie could land on the wrong side).  The fp32 step rounds to ODD -- truncate, then set the last bit if anything was cut off -- which
+// keeps every sum strictly between two fp16 candidates strictly between them, and exactly representable sums exact; fp32's 24 bits are 13
+// more than fp16 keeps, so the final round-to-nearest-even sees what the infinitely precise value would have shown it.
+__device__ __forceinline__ float fix_to_float_odd(long long a)
+{
+    const float f = __ll2float_rz(a);
+    const uint32_t sticky = ((long long)f != a) ? 1u : 0u;      // (|f| <= |a| < 2^63: the conversion back is exact)
+    return __uint_as_float(__float_as_uint(f) | sticky) * 5.9604644775390625e-8f;      // x 2^-24 (exact)
+}
 __device__ __forceinline__ uint32_t fix_to_half2(long long a0, long long a1)
 {
-    const float2v a = {(float)a0 * 5.9604644775390625e-8f, (float)a1 * 5.9604644775390625e-8f};      // x 2^-24
+    const float2v a = {fix_to_float_odd(a0), fix_to_float_odd(a1)};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(a, half2v));
 }
 __device__ __forceinline__ void fix_add_global(long long* __restrict__ fix, uint32_t entry, uint32_t hbits2)

@@ -108,17 +108,43 @@ def apply_grid_lists(lists, n_entries):
     return g.reshape(-1)
 
 
-def attach_gradient_allreduce(nrc, world, group=None, native=True):
+# ---- the fp16 gradient exchange (nrc_cache_set_exchange_dtype, BASELINE.json configs[3]), host restatement for the gloo tests:
+# the fp32 gradient vector (a local sum, already times loss_scale 128) is rounded to fp16 once, the ranks' vectors are summed in fp16
+# (every partial sum rounded), and the sum is widened back to fp32.  For two ranks the result does not depend on the order.
+LOSS_SCALE = 128.0
+
+
+def half_exchange_send(grad_f32):
+    """what a rank puts on the wire: the gradient vector as fp16 numbers"""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        return np.asarray(grad_f32, np.float32).astype(np.float16)
+
+
+def half_exchange_sum(sent):
+    """ncclAllReduce(ncclHalf, sum) of the ranks' vectors in rank order, widened to the fp32 vector the optimizer reads"""
+    import numpy as np
+    acc = np.asarray(sent[0], np.float16).copy()
+    with np.errstate(over="ignore"):
+        for v in sent[1:]:
+            acc = (acc + np.asarray(v, np.float16)).astype(np.float16)
+    return acc.astype(np.float32)
+
+
+def attach_gradient_allreduce(nrc, world, group=None, native=True, dtype="f32"):
     """Installs the exchange step of the training path on a NeuralRadianceCache: the loss normaliser becomes the global
     batch (3 * trainBatchSize * world) and the fp32 gradient vector + loss cell are all-reduced (sum) between backward and
     the optimizer of every train batch, on the stream the training kernels run on.
 
     native=True (default): the library calls ncclAllReduce itself (RCCL communicator created from a unique id that rank 0
     broadcasts through torch.distributed) -- no Python in the per-frame path.
-    native=False: a Python hook calls torch.distributed.all_reduce (used by the CPU/gloo-style tests of the logic)."""
+    native=False: a Python hook calls torch.distributed.all_reduce (used by the CPU/gloo-style tests of the logic).
+    dtype "f16": the gradients travel as fp16 numbers (nrc_cache_set_exchange_dtype; the default fp32 vector is 103 KB, this one 52 KB)."""
     import torch
     import torch.distributed as dist
     from . import api
+    if dtype != "f32":
+        nrc.SetExchangeDtype(dtype)      # (the hook below is then handed fp16-rounded values and its sum is rounded again)
     if native:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")

@@ -116,3 +116,70 @@ def test_grid_gradient_list_exchange_equals_dense_allreduce():
     assert 5000 < res["count"] <= 6000 and res["cap"] == 64 * 128 and res["padding_ok"]
     assert res["equals_dense"] and res["replicas_equal"]
     assert 8000 < res["touched"] <= 9000
+
+
+def _half_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nrc_hpm_renderer_amd import parallel
+    from oracle import Oracle
+    orc = Oracle()
+    nn = orc.nn_create()
+    rng = np.random.default_rng(11)
+    n = 256
+    x = rng.random((n, 5), dtype=np.float32)
+    x[:, :3] += 31.0
+    t = rng.random((n, 3), dtype=np.float32)
+    sl = parallel.shard_train_batch(n, rank, world)
+    loss_local = nn.backward(x[sl], t[sl], n_norm=n)
+    g_local = np.array(nn.buffer(4)) * parallel.LOSS_SCALE                    # the device vector carries loss_scale
+    sent = parallel.half_exchange_send(g_local)
+    # the transport: every rank's fp16 vector to every rank (what a ring all-reduce amounts to for two ranks), summed in rank order
+    gathered = [torch.zeros(sent.size * 2, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(sent.view(np.uint8)))
+    total = parallel.half_exchange_sum([g.numpy().view(np.float16) for g in gathered])
+    loss = torch.tensor([loss_local, 0.0])
+    dist.all_reduce(loss, op=dist.ReduceOp.SUM)                                # the loss cell stays fp32
+    nn.buffer(4)[:] = total / parallel.LOSS_SCALE
+    nn.optimizer_step()
+    w = np.array(nn.buffer(0))
+    everyone = [torch.zeros(w.size) for _ in range(world)]
+    dist.all_gather(everyone, torch.from_numpy(w))
+    if rank == 0:
+        full = orc.nn_create()
+        loss_full = full.backward(x, t)
+        g_full = np.array(full.buffer(4)) * parallel.LOSS_SCALE
+        full.optimizer_step()
+        halves = [g.numpy().view(np.float16).astype(np.float64) for g in gathered]
+        q.put(dict(g_err=float(np.linalg.norm(total - g_full) / np.linalg.norm(g_full)),
+                   representable=bool(np.array_equal(total, total.astype(np.float16).astype(np.float32))),
+                   one_rounding=bool(np.array_equal(total, (halves[0] + halves[1]).astype(np.float16).astype(np.float32))),
+                   finite=bool(np.isfinite(total).all()), max_abs=float(np.abs(total).max()),
+                   loss=float(loss[0]), loss_full=loss_full,
+                   replicas_equal=bool(all(torch.equal(everyone[0], e) for e in everyone)),
+                   w_err=float(np.linalg.norm(w - np.array(full.buffer(0))) / np.linalg.norm(w))))
+    dist.destroy_process_group()
+
+
+def test_fp16_gradient_exchange_keeps_replicas_identical():
+    """nrc_cache_set_exchange_dtype(NRC_EXCHANGE_F16), the host statement of the protocol (parallel.half_exchange_*): gradients pre-scaled by
+    loss_scale 128, rounded to fp16 once per rank, summed in fp16 -- within fp16's resolution of the full-batch gradient (2^-11 per
+    addend), every replica bit-identical after the optimizer step, nothing near fp16's range limits"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_half_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["finite"] and res["max_abs"] < 6.0e4 and res["representable"] and res["one_rounding"]
+    assert res["g_err"] < 1e-3                       # 2^-11 relative per number, three roundings
+    assert abs(res["loss"] - res["loss_full"]) < 1e-5 * max(1.0, abs(res["loss_full"]))
+    assert res["replicas_equal"]
+    assert res["w_err"] < 2e-3                       # Adam turns a rounded gradient into a step of the same size: a few weights move the other way

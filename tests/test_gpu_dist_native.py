@@ -29,6 +29,11 @@ def test_native_rccl_exchange_under_torch_distributed_run(torch_gpu, tmp_path):
     assert res["finite"] and res["step"] == 5 and len(res["losses"]) == 5
     assert res["native_equals_no_communicator"]
     assert res["native_equals_hook"]
+    # the fp16 exchange (nrc_cache_set_exchange_dtype): RCCL's ncclHalf all-reduce gives the bits the hook path's statement of the protocol
+    # gives, trains to finite losses within fp16's resolution of the fp32 run, and is a different run (the rounding happened)
+    assert res["fp16_native_equals_hook"] and res["fp16_finite"] and res["fp16_differs_from_fp32"]
+    assert res["fp16_weight_rel_diff"] < 2e-2 and all(abs(a - b) <= 2e-2 * abs(b) for a, b in zip(res["fp16_losses"], res["losses"]))
+    assert res["hashgrid_fp16_finite"] and res["hashgrid_fp16_weight_rel_diff"] < 2e-2
     # HashGrid model: the sparse list exchange is the one in use (and not for the dense run or the model without a table), it
     # trains to the same losses and weights as the dense all-reduce up to the run-to-run noise of the packed-fp16 atomics
     assert res["hashgrid_sparse_flags"] == [True, False, False] and res["hashgrid_finite"]

@@ -1,5 +1,6 @@
 """Parity of the fused encode+MLP HIP kernels (inference, backward, optimizer) against the oracle, through the C ABI.
-Tolerances: MLP fp16 path vs oracle fp16-storage mode: rel-L2 <= 2e-3 on outputs; gradients rel-L2 <= 1e-2;
+Tolerances: MLP fp16 path vs oracle fp16-storage mode: rel-L2 <= 2e-3 on outputs; gradients: the bulk of a batch <= 3e-5,
+overall <= 2e-3 with at most a handful of rays whose ReLU decision is a tie (gradient_agreement below; profiles/r06_grad_drift.txt);
 weights after a step rel-L2 <= 1e-3.  (fp32 MFMA accumulation order differs from the oracle's wide accumulate, and a
 1-ulp fp16 rounding flip of an activation propagates.)"""
 import numpy as np
@@ -146,9 +147,44 @@ def test_infer_and_train_batch_slicing_and_filter(api, orc, torch_gpu):
     c.Destroy()
 
 
+def gradient_agreement(c, onn, x, t, torch, max_flip_tiles=4):
+    """How the kernels' gradient of batch (x, t) agrees with the oracle's.  Both round at the same points (weights, activations, deltas to
+    fp16) and sum wider (fp32 MFMA accumulators / double), so they agree to ~7e-6 -- EXCEPT for a ray with a pre-activation within fp32
+    accumulation error of zero: its ReLU decision can fall either way, and the neuron's whole delta row for that ray appears or vanishes
+    (one such ray in 1 024 moves the batch's gradient by 1e-4..1e-3; profiles/r06_grad_drift.txt: present for about half of the seeds).
+    Returns (overall rel-L2, per-layer rel-L2, rel-L2 of the BULK = the batch without the 32-ray tiles that hold such a ray, their count)."""
+    n = x.shape[0]
+    d_x, d_t = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    c.Backward(d_x, d_t)
+    loss = c.GetLoss()
+    g = c.GetParams(4).astype(np.float64) / 128.0                            # the device vector carries loss_scale
+    loss_ref = onn.backward(x, t)
+    g_ref = np.array(onn.buffer(4), np.float64)
+    per_layer, off = [], 0
+    for o, i in [(64, 80)] + [(64, 64)] * 5 + [(3, 64)]:
+        per_layer.append(rel(g[off:off + o * i], g_ref[off:off + o * i]))
+        off += o * i
+    tiles = []
+    for a in range(0, n, 32):
+        c.Backward(d_x[a:a + 32].contiguous(), d_t[a:a + 32].contiguous(), nNorm=n)
+        gt = c.GetParams(4).astype(np.float64) / 128.0
+        onn.backward(x[a:a + 32], t[a:a + 32], n_norm=n)
+        gr = np.array(onn.buffer(4), np.float64)
+        tiles.append((float(np.linalg.norm(gt - gr)), gt, gr))
+    med = float(np.median([e for e, _, _ in tiles]))
+    flips = [k for k, (e, _, _) in enumerate(tiles) if e > 8.0 * med]
+    keep = [k for k in range(len(tiles)) if k not in flips]
+    bulk, bulk_ref = sum(tiles[k][1] for k in keep), sum(tiles[k][2] for k in keep)
+    assert len(flips) <= max_flip_tiles, "%d tiles disagree: not a handful of ReLU ties" % len(flips)
+    return dict(overall=rel(g, g_ref), per_layer=per_layer, bulk=rel(bulk, bulk_ref), flip_tiles=len(flips), loss=loss, loss_ref=loss_ref)
+
+
 @pytest.mark.parametrize("loss_fn,loss_id", [("RelativeL2Luminance", 0), ("L2", 1), ("RelativeL2", 2), ("L1", 3), ("Mape", 4), ("Smape", 5),
                                              ("LogL1", 6)])
 def test_backward_matches_oracle(api, orc, torch_gpu, loss_fn, loss_id):
+    """SURVEY 8c asks for a stated tolerance; measured (profiles/r06_grad_drift.txt, 13 seeds x 2 batches): 6e-6..9e-6 when no ray's ReLU
+    decision is a tie, up to 9.7e-4 overall / 9e-3 in the first layer with one to three such rays.  Bounds: the bulk of the batch <= 3e-5 (the
+    arithmetic itself: 4 x the measured floor), at most four tiles with a tie, overall <= 2e-3, any layer <= 1e-2, loss <= 2e-5 relative."""
     c = api.NeuralRadianceCache(api.AppConfig(loss_fn=loss_fn))
     onn = orc.nn_create(loss_id=loss_id)
     randomize(c, onn, seed=7, scale=1.0)
@@ -156,17 +192,12 @@ def test_backward_matches_oracle(api, orc, torch_gpu, loss_fn, loss_id):
     x = queries(n, seed=21)
     rng = np.random.default_rng(22)
     t = (rng.random((n, 3), dtype=np.float32) * 2).astype(np.float32)
-    c.Backward(torch_gpu.from_numpy(x).cuda(), torch_gpu.from_numpy(t).cuda())
-    loss_ref = onn.backward(x, t)
-    g = c.GetParams(4) / 128.0                            # the device vector carries loss_scale
-    g_ref = np.array(onn.buffer(4))
-    assert abs(c.GetLoss() - loss_ref) < 2e-3 * abs(loss_ref)
-    assert rel(g, g_ref) < 1e-2
+    a = gradient_agreement(c, onn, x, t, torch_gpu)
+    assert abs(a["loss"] - a["loss_ref"]) < 2e-5 * abs(a["loss_ref"]), a
+    assert a["bulk"] < 3e-5, a
+    assert a["overall"] < 2e-3, a
     # per-layer check: a transposed or permuted weight-gradient tile would show up as O(1) error in one layer
-    off = 0
-    for o, i in [(64, 80)] + [(64, 64)] * 5 + [(3, 64)]:
-        assert rel(g[off:off + o * i], g_ref[off:off + o * i]) < 2e-2
-        off += o * i
+    assert max(a["per_layer"]) < 1e-2, a
     c.Destroy()
 
 
@@ -203,28 +234,42 @@ def test_backward_is_bitwise_reproducible(cache, torch_gpu):
 
 
 def test_training_steps_match_oracle(cache, orc, torch_gpu):
+    """weights after ONE step <= 1e-3.  Every step starts from the same state on both sides (the oracle takes over the device's
+    four vectors and step count), so the bound is per step and nothing accumulates.  Adam's step is ~lr x sign(gradient) for every weight: one
+    whose gradient is fp16 noise around zero may move the other way on the two sides (a single such weight is 7e-4 of the update's norm), so
+    those are COUNTED and bounded -- at most 8, each with |gradient| < 1e-4 of the largest -- and the 1e-3 holds for the others, as in
+    __graft_entry__.smoke().  First moment <= 2e-3 (it is 0.1 x the gradient, whose bound with a ReLU tie is 2e-3), second <= 4e-3 (0.001 x its square)."""
     onn = orc.nn_create()
     n = 1024
     x = queries(n, seed=31, nan_frac=0.05)
     rng = np.random.default_rng(32)
     d_x = torch_gpu.from_numpy(x).cuda()
     for step in range(3):
+        for which in range(4):                   # identical state in front of the step
+            onn.buffer(which)[:] = cache.GetParams(which)
+        onn.set_step(cache.GetStep())
+        w0 = cache.GetParams(0).copy()
         t = rng.random((n, 3), dtype=np.float32)
         cache.Backward(d_x, torch_gpu.from_numpy(t).cuda())
         cache.OptimizerStep()
         loss_ref = onn.backward(x, t)
+        g_ref = np.array(onn.buffer(4))
         onn.optimizer_step()
-        assert abs(cache.GetLoss() - loss_ref) < 5e-3 * abs(loss_ref)
+        assert abs(cache.GetLoss() - loss_ref) < 2e-5 * abs(loss_ref)
+        w, w_ref = cache.GetParams(0), np.array(onn.buffer(0))
+        flipped = np.sign(w - w0) != np.sign(w_ref - w0)
+        assert flipped.sum() <= 8 and (np.abs(g_ref[flipped]) < 1e-4 * np.abs(g_ref).max()).all(), (step, int(flipped.sum()))
+        assert rel(w[~flipped], w_ref[~flipped]) < 1e-3, step
+        assert rel((w - w0)[~flipped], (w_ref - w0)[~flipped]) < 2e-2, step        # the update itself (~lr per weight), not only the weights
+        assert rel(cache.GetParams(1), onn.buffer(1)) < 1e-3, step                  # EMA
+        assert rel(cache.GetParams(2), onn.buffer(2)) < 2e-3 and rel(cache.GetParams(3), onn.buffer(3)) < 4e-3, step
     assert cache.GetStep() == 3
-    # Adam normalises every element's update to ~lr: elements whose gradient is ~0 +- fp16 noise may move the other way,
-    # so the bound after k steps is looser than the per-step 1e-3 of SURVEY 8c
-    assert rel(cache.GetParams(0), onn.buffer(0)) < 3e-3
-    assert rel(cache.GetParams(1), onn.buffer(1)) < 3e-3
-    assert rel(cache.GetParams(2), onn.buffer(2)) < 2e-2 and rel(cache.GetParams(3), onn.buffer(3)) < 4e-2
     # inference now uses the updated EMA weights
     out = torch_gpu.empty((n, 3), device="cuda")
     cache.Infer(d_x, out, True)
-    assert rel(out.cpu().numpy(), onn.forward(x, True, 1)) < 5e-3
+    for which in range(4):
+        onn.buffer(which)[:] = cache.GetParams(which)
+    assert rel(out.cpu().numpy(), onn.forward(x, True, 1)) < 2e-3
 
 
 def test_sharded_backward_sums_to_full_batch(api, torch_gpu):
@@ -791,3 +836,50 @@ def test_hashgrid_default_size_trains(api, torch_gpu):
         losses.append(c.GetLoss())
     assert np.isfinite(losses).all() and losses[-1] < 0.3 * losses[0]
     c.Destroy()
+
+
+def test_fp16_exchange_rounds_once_before_and_once_after_the_sum(api, torch_gpu):
+    """nrc_cache_set_exchange_dtype(NRC_EXCHANGE_F16) on one device, a gradient hook playing the second rank (it doubles the vector -- a second
+    rank with the same shard): the hook is handed round_f16(local fp32 sum x loss_scale), what reaches the optimizer is round_f16 of the hook's
+    sum, and the step from that vector is the step an fp32 cache takes when it is handed the same vector -- bit for bit"""
+    n = 1024
+    x = torch_gpu.from_numpy(queries(n, seed=61, nan_frac=0.0)).cuda()
+    t = torch_gpu.rand((n, 3), device="cuda", generator=torch_gpu.Generator(device="cuda").manual_seed(5))
+    seen = {}
+
+    def make(dtype, hook):
+        c = api.NeuralRadianceCache(api.AppConfig(train_batch_count=1, log2_train_batch_size=10, log2_infer_batch_size=10))
+        c.SetExchangeDtype(dtype)
+        assert c.GetExchangeDtype() == dtype
+        out = torch_gpu.zeros((n, 3), device="cuda")
+        c.Init(n, x, out, x, t)
+        c.SetGradHook(hook)
+        c.InferAndTrain(None, True)
+        torch_gpu.cuda.synchronize()
+        w = c.GetParams(0).copy()
+        g = c.GetParams(4).copy()
+        c.Destroy()
+        return w, g
+
+    def plain(g, _loss):
+        seen["g32"] = g.detach().cpu().numpy().copy()
+
+    def second_rank(g, _loss):
+        seen["g16_in"] = g.detach().cpu().numpy().copy()
+        g.mul_(2.0)
+
+    make("f32", plain)
+    w16, g16 = make("f16", second_rank)
+    n_p = seen["g32"].size - 2 if seen["g32"].size > 25792 else seen["g32"].size
+    g32 = seen["g32"][:25792]
+    with np.errstate(over="ignore"):
+        want_in = g32.astype(np.float16).astype(np.float32)
+        want_out = (want_in * 2.0).astype(np.float16).astype(np.float32)
+    assert np.array_equal(seen["g16_in"][:25792], want_in) and not np.array_equal(want_in, g32)
+    assert np.array_equal(g16[:25792], want_out)
+
+    def handed(g, _loss):
+        g[:25792].copy_(torch_gpu.from_numpy(want_out).cuda())
+
+    w32, _ = make("f32", handed)
+    assert np.array_equal(w16, w32)

@@ -14,14 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def run(api, sc, parallel, scene, cam, W, H, rank, world, frames, exchange, **model):
-    """exchange: None | "native" | "hook"."""
+def run(api, sc, parallel, scene, cam, W, H, rank, world, frames, exchange, dtype="f32", **model):
+    """exchange: None | "native" | "hook"; dtype: what travels (nrc_cache_set_exchange_dtype)"""
     cfg = api.AppConfig(train_batch_count=1, log2_train_batch_size=10, log2_infer_batch_size=14, **model)
     nrc = api.NeuralRadianceCache(cfg)
     if exchange == "native":
-        parallel.attach_gradient_allreduce(nrc, world, native=True)
+        parallel.attach_gradient_allreduce(nrc, world, native=True, dtype=dtype)
     elif exchange == "hook":
-        parallel.attach_gradient_allreduce(nrc, world, native=False)
+        parallel.attach_gradient_allreduce(nrc, world, native=False, dtype=dtype)
     lw = parallel.local_width(rank, world, W)
     ren = api.NrcHpmRenderer(lw, H, True, cam, cfg, scene, nrc, tile=parallel.column_tile(rank, world, W, H))
     frs = sc.frame_randoms(frames, seed=77)
@@ -56,6 +56,16 @@ def main():
                step=native["step"], finite=bool(np.isfinite(native["img"]).all() and np.isfinite(native["losses"]).all()),
                native_equals_hook=bool(np.array_equal(native["w"], hook["w"]) and native["losses"] == hook["losses"]
                                        and np.array_equal(native["img"], hook["img"])))
+    # the fp16 exchange (BASELINE.json configs[3]): ncclAllReduce(ncclHalf) inside the frame graph against the hook path's statement of it
+    # (values rounded to fp16, summed, rounded) -- the same bits for this world size; and it is NOT the fp32 run (the rounding is real)
+    native16 = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", dtype="f16")
+    hook16 = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "hook", dtype="f16")
+    res["fp16_native_equals_hook"] = bool(np.array_equal(native16["w"], hook16["w"]) and native16["losses"] == hook16["losses"]
+                                          and np.array_equal(native16["img"], hook16["img"]))
+    res["fp16_differs_from_fp32"] = bool(not np.array_equal(native16["w"], native["w"]))
+    res["fp16_weight_rel_diff"] = float(np.linalg.norm(native16["w"] - native["w"]) / np.linalg.norm(native["w"]))
+    res["fp16_finite"] = bool(np.isfinite(native16["losses"]).all() and np.isfinite(native16["w"]).all())
+    res["fp16_losses"] = native16["losses"]
     # HashGrid model (the reference's default encoding): the table gradient travels as all-gathered (entry, value) lists; its
     # packed-fp16 atomics sum in a different order every run, so the dense exchange is the reference only up to that noise
     hg = dict(pos_id=0, hashgrid_log2_size=14)
@@ -63,6 +73,9 @@ def main():
     os.environ["NRC_DENSE_GRID_EXCHANGE"] = "1"
     dense = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", **hg)
     del os.environ["NRC_DENSE_GRID_EXCHANGE"]
+    sparse16 = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", dtype="f16", **hg)
+    res["hashgrid_fp16_finite"] = bool(np.isfinite(sparse16["losses"]).all() and np.isfinite(sparse16["w"]).all())
+    res["hashgrid_fp16_weight_rel_diff"] = float(np.linalg.norm(sparse16["w"] - sparse["w"]) / np.linalg.norm(sparse["w"]))
     res["hashgrid_sparse_flags"] = [bool(sparse["sparse"]), bool(dense["sparse"]), bool(native["sparse"])]
     res["hashgrid_losses_sparse"], res["hashgrid_losses_dense"] = sparse["losses"], dense["losses"]
     res["hashgrid_finite"] = bool(np.isfinite(sparse["img"]).all() and np.isfinite(sparse["losses"]).all())
