@@ -357,6 +357,20 @@ typedef struct nrc_schedule {
 int nrc_renderer_set_schedule(nrc_renderer_t* r, const nrc_schedule* schedule);
 /* the values in use now; *tuning_done (may be NULL) = 1 once nothing is left to choose */
 int nrc_renderer_get_schedule(nrc_renderer_t* r, nrc_schedule* current, int* tuning_done);
+/* Schedules survive the process.  What the tuner settles on is remembered in a process-wide table under a key that names everything the
+ * choice depends on -- "<arch>:<CUs>cu:<XCDs>xcd|<model>|vol2^<log2 voxels>|<w>x<h>.of<global w>x<global h>|train<batches>x<rays>.len<train ray length>"
+ * (nrc_renderer_schedule_key) -- and a renderer created while its key is in the table starts on that schedule and skips the trials, so a run
+ * shorter than the tuner's ~400 frames is a tuned run all the same.  nrc_schedule_cache_save writes the table (text: one "<key> <pri> <lag>
+ * <window>" line per entry), nrc_schedule_cache_load merges a file into it (damaged lines are skipped; entries of other devices or models
+ * simply never match); *n_entries (may be NULL) = entries read / written.  nrc_renderer_schedule_source says where the schedule in use came
+ * from: "default" | "cache" | "tuner" (this renderer's own trials have ended) | "pinned" | "pinned in part".  The Python mirror loads
+ * nrc-hpm-renderer_amd/schedules.txt (the tuner's results on this pool's MI355X for the BASELINE presets, tools/tune_schedules.py) with
+ * the library (NRC_SCHEDULE_CACHE=<file> adds the host's own, NRC_SCHEDULE_CACHE="" loads none); a C++ host calls en::LoadScheduleCache(path). */
+const char* nrc_renderer_schedule_source(nrc_renderer_t* r);
+const char* nrc_renderer_schedule_key(nrc_renderer_t* r);
+int nrc_schedule_cache_load(const char* path, int* n_entries);
+int nrc_schedule_cache_save(const char* path, int* n_entries);
+int nrc_schedule_cache_clear(void);      /* forget every entry (renderers created afterwards start on the defaults and tune) */
 int nrc_renderer_set_cost_order(nrc_renderer_t* r, int on);
 size_t nrc_renderer_tile_order(nrc_renderer_t* r, uint32_t* host_out, size_t capacity);
 /* Hot tiles (on by default): a pixel whose RNG state can run into DeltaTrack's cap of 128 collisions inside a tile the empty-space

@@ -280,6 +280,11 @@ private:
     nrc_scene m_Scene{};
 };
 
+// schedules the renderers' tuners settled on in earlier processes (include/nrc_hpm.h: nrc_schedule_cache_load / _save / _clear); returns entries
+inline int LoadScheduleCache(const std::string& path) { int n = 0; nrc_check(nrc_schedule_cache_load(path.c_str(), &n)); return n; }
+inline int SaveScheduleCache(const std::string& path) { int n = 0; nrc_check(nrc_schedule_cache_save(path.c_str(), &n)); return n; }
+inline void ClearScheduleCache() { nrc_check(nrc_schedule_cache_clear()); }
+
 class NeuralRadianceCache {
 public:
     explicit NeuralRadianceCache(const AppConfig& appConfig) { nrc_check(nrc_cache_create(&appConfig.c, &h_)); }

@@ -66,7 +66,8 @@ ABI_SYMBOLS = [
     "nrc_cache_get_loss_blocking", "nrc_cache_get_loss_async", "nrc_cache_comm_info", "nrc_cache_comm_time_exchange", "nrc_renderer_release_frame", "nrc_renderer_is_blending", "nrc_mc_renderer_is_blending",
     "nrc_renderer_set_full_vertex_images", "nrc_renderer_vertex_image_bytes", "nrc_renderer_set_empty_skip", "nrc_mc_renderer_set_empty_skip",
     "nrc_cache_set_collective_hooks", "nrc_renderer_gather_frame", "nrc_renderer_export_exr_gathered", "nrc_compare_images_sharded",
-    "nrc_renderer_set_cost_order", "nrc_renderer_set_schedule", "nrc_renderer_get_schedule", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order", "nrc_renderer_set_hot_tiles", "nrc_renderer_hot_tiles",
+    "nrc_renderer_set_cost_order", "nrc_renderer_set_schedule", "nrc_renderer_get_schedule", "nrc_renderer_schedule_source", "nrc_renderer_schedule_key",
+    "nrc_schedule_cache_load", "nrc_schedule_cache_save", "nrc_schedule_cache_clear", "nrc_renderer_tile_order", "nrc_mc_renderer_set_cost_order", "nrc_renderer_set_hot_tiles", "nrc_renderer_hot_tiles",
     "nrc_cache_get_infer_batch_count", "nrc_cache_get_train_batch_count", "nrc_cache_get_infer_batch_size",
     "nrc_cache_get_train_batch_size", "nrc_cache_infer", "nrc_cache_backward", "nrc_cache_optimizer_step",
     "nrc_cache_grad_ptr", "nrc_cache_param_count", "nrc_cache_loss_ptr", "nrc_cache_set_loss_norm_factor",
@@ -147,7 +148,34 @@ def load_library():
                  "nrc_mc_renderer_frame_time_ms"):
         getattr(L, name).argtypes = [C.c_void_p]
     _lib = L
+    # schedules the tuner settled on in earlier processes (include/nrc_hpm.h, nrc_schedule_cache_load): the package's own table -- this pool's
+    # MI355X, the BASELINE presets -- and the host's (NRC_SCHEDULE_CACHE=<file>; "" = none of either)
+    if hasattr(L, "nrc_schedule_cache_load"):
+        L.nrc_renderer_schedule_source.restype = C.c_char_p
+        L.nrc_renderer_schedule_key.restype = C.c_char_p
+        user = os.environ.get("NRC_SCHEDULE_CACHE")
+        for path in ([] if user == "" else [os.path.join(_HERE, "schedules.txt")] + ([user] if user else [])):
+            if os.path.exists(path):
+                L.nrc_schedule_cache_load(path.encode(), None)
     return L
+
+
+def load_schedule_cache(path):
+    """nrc_schedule_cache_load: merge a file of tuned schedules into the process-wide table; returns the number of entries read"""
+    n = C.c_int(0)
+    _check(load_library().nrc_schedule_cache_load(path.encode(), C.byref(n)))
+    return n.value
+
+
+def clear_schedule_cache():
+    _check(load_library().nrc_schedule_cache_clear())
+
+
+def save_schedule_cache(path):
+    """nrc_schedule_cache_save: write the process-wide table (what the tuners of this process settled on + what was loaded)"""
+    n = C.c_int(0)
+    _check(load_library().nrc_schedule_cache_save(path.encode(), C.byref(n)))
+    return n.value
 
 
 class CommError(RuntimeError):
@@ -602,7 +630,11 @@ class NrcHpmRenderer:
         v = (C.c_int32 * 4)()
         done = C.c_int(0)
         _check(self.L.nrc_renderer_get_schedule(self.h, v, C.byref(done)))
-        return dict(camera_priority_low=v[0], cost_order_lag=v[1], xcd_window=v[2], composite_defer=v[3], tuning_done=bool(done.value))
+        d = dict(camera_priority_low=v[0], cost_order_lag=v[1], xcd_window=v[2], composite_defer=v[3], tuning_done=bool(done.value))
+        if hasattr(self.L, "nrc_renderer_schedule_source"):
+            d["source"] = (self.L.nrc_renderer_schedule_source(self.h) or b"").decode()
+            d["key"] = (self.L.nrc_renderer_schedule_key(self.h) or b"").decode()
+        return d
 
     def GatherFrame(self, stream=None):
         """the whole [global_h, global_w, 4] frame of a sharded renderer as a new torch CUDA tensor, on every rank (collective: one

@@ -28,12 +28,20 @@ def test_bench_json_line(torch_gpu):
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof
     assert 0.2 < d["roofline_mlp"]["frac"] < 0.7 and 0.2 < d["roofline_mlp"]["event_timed"]["frac"] < 0.7
-    # the headline is not a one-off: within 25 % (boxes of the pool hold clocks ~7 % apart, and the committed line is of another box) of the newest committed bench line of the same workload (profiles/rNN_bench.json)
+    # the headline is not a one-off: within 10 % of the newest committed bench line of the same workload (profiles/rNN_bench.json) once the
+    # box's clock class is divided out -- boxes of this pool hold clocks ~7 % apart, and both lines carry the same Monte-Carlo frames timed
+    # on their own box (gpu_mc_baseline: the same inner loops as the headline's dominant kernel), so value / gpu_mc_baseline is a property of
+    # the code, not of the box (the +-25 % this test allowed would have let a 20 % regression through)
     import glob
     ref = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")))[-1]
     want = json.loads(open(ref).read().strip().splitlines()[-1])
     assert want["config"]["workload"] == d["config"]["workload"]
-    assert abs(d["value"] - want["value"]) <= 0.25 * want["value"], (d["value"], want["value"], ref)
+    ratio, ratio_want = d["value"] / d["gpu_mc_baseline"]["value"], want["value"] / want["gpu_mc_baseline"]["value"]
+    assert abs(ratio / ratio_want - 1.0) <= 0.10, (d["value"], d["gpu_mc_baseline"]["value"], want["value"], want["gpu_mc_baseline"]["value"], ref)
+    assert abs(d["value"] - want["value"]) <= 0.17 * want["value"], (d["value"], want["value"], ref)      # (10 % + the 7 % between boxes)
+    q = d["quality"]
+    assert q["frames"] >= 512 and abs(q["rel_bias"] - q["faithful_limit"]["rel_bias"]) < 0.06 and q["mse"] < q["mc_equal_time"]["mse"]
+    assert "faithful" in d["config"]["workload"] and d["config"]["compat_fix"] == 0 and d["schedule"]["source"] in ("default", "cache", "tuner")
     assert len(d["build_id"]) == 16
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "Msamples/s" and cpu["sample"]

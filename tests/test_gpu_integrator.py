@@ -540,8 +540,17 @@ def test_the_renderer_chooses_its_schedule_on_live_frames_without_changing_them(
         nrc.Destroy()
         return out
 
+    knobs = lambda s_: (s_["camera_priority_low"], s_["cost_order_lag"], s_["xcd_window"])
+    api.clear_schedule_cache()      # (what earlier tuners of this process settled on, and the package's table: this test starts from the defaults)
     pinned = run(dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2), "batches")
+    assert pinned[2]["source"] == "pinned"
     free = run(None, "batches")
+    assert free[2]["source"] == "tuner" and free[2]["key"].startswith("gfx950:256cu:8xcd|pos3.dir0.w64.d6.hg0|vol2^24|1920x1080.of1920x1080|train1x1024")
+    # what the tuner settled on is remembered under the renderer's key: the next renderer of this kind STARTS on it and skips the trials --
+    # a run shorter than the tuner's ~400 frames is a tuned run (nrc_schedule_cache_save / _load carry the table to the next process)
+    cached = run(None, "sync")
+    assert cached[2]["source"] == "cache" and cached[2]["tuning_done"] and knobs(cached[2]) == knobs(free[2])
+    api.clear_schedule_cache()
     part = run(dict(cost_order_lag=3), "batches")
     assert pinned[2]["tuning_done"] and free[2]["tuning_done"] and part[2]["tuning_done"]
     assert part[2]["cost_order_lag"] == 3
@@ -549,8 +558,10 @@ def test_the_renderer_chooses_its_schedule_on_live_frames_without_changing_them(
     for other in (free, part):
         assert np.array_equal(pinned[0].view(np.uint32), other[0].view(np.uint32))
         assert np.array_equal(pinned[1].view(np.uint32), other[1].view(np.uint32))
+    api.clear_schedule_cache()
     starved = run(None, "sync")
-    assert not starved[2]["tuning_done"] or starved[2] == dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2, composite_defer=0, tuning_done=True)
+    assert not starved[2]["tuning_done"] or knobs(starved[2]) == (0, 2, 2)
+    assert starved[2]["source"] in ("default", "tuner")
     assert (starved[2]["camera_priority_low"], starved[2]["cost_order_lag"], starved[2]["xcd_window"]) == (0, 2, 2)
 
 
@@ -1102,3 +1113,40 @@ def test_cost_ordered_tile_launch_is_a_permutation_and_changes_no_pixel(api, sc,
         imgs[on] = mc.GetImage().cpu().numpy().copy()
         mc.Destroy()
     assert same_bits(imgs[True], imgs[False]) and imgs[True][..., :3].std() > 0.01
+
+
+def test_schedule_cache_file_roundtrip(api, sc, cloud16, torch_gpu, tmp_path):
+    """nrc_schedule_cache_save / _load / _clear: an entry under a renderer's key makes the next renderer of that kind start on it (source
+    "cache", no trials); entries of other keys never match; damaged lines are skipped; and -- like every value of every knob -- the cached
+    schedule changes no pixel"""
+    W, H = 256, 128
+    scene = sc.make_scene(cloud16, scene_id=4)
+    api.clear_schedule_cache()
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+    s0 = ren.GetSchedule()
+    assert s0["source"] == "default" and not s0["tuning_done"] and s0["key"]
+    frs = sc.frame_randoms(6, seed=3)
+    ren.RenderFrames(frs, True)
+    img0, w0 = ren.GetImage().cpu().numpy().copy(), nrc.GetParams(0).copy()
+    ren.Destroy()
+    nrc.Destroy()
+    path = str(tmp_path / "schedules.txt")
+    with open(path, "w") as f:
+        f.write("# a comment\n%s 1 3 16\nsome-other-device|model 0 2 0\n%s 1 99 16\nnot a line\n" % (s0["key"], s0["key"] + "x"))
+    assert api.load_schedule_cache(path) == 2          # (the lag of 99 is outside nrc_schedule's range: skipped, like the free text)
+    cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H)
+    s1 = ren.GetSchedule()
+    assert s1["source"] == "cache" and s1["tuning_done"] and (s1["camera_priority_low"], s1["cost_order_lag"], s1["xcd_window"]) == (1, 3, 16)
+    ren.RenderFrames(frs, True)
+    assert np.array_equal(img0.view(np.uint32), ren.GetImage().cpu().numpy().view(np.uint32)) and np.array_equal(w0, nrc.GetParams(0))
+    ren.SetSchedule(cost_order_lag=2)                   # a caller that knows better still pins
+    assert ren.GetSchedule()["cost_order_lag"] == 2 and ren.GetSchedule()["source"] == "pinned in part"
+    ren.Destroy()
+    nrc.Destroy()
+    out = str(tmp_path / "saved.txt")
+    assert api.save_schedule_cache(out) == 2
+    api.clear_schedule_cache()
+    assert api.load_schedule_cache(out) == 2
+    api.clear_schedule_cache()
+    with pytest.raises(RuntimeError, match="cannot read schedule cache"):
+        api.load_schedule_cache(str(tmp_path / "missing.txt"))
