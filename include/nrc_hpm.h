@@ -161,7 +161,7 @@ int nrc_cache_comm_time_exchange(nrc_cache_t* c, uint32_t reps, float* avg_us);
  * exchanged as all-gathered (entry, fp16x2 value) lists that every rank adds in rank order (replicas stay bit-identical), the
  * matrix gradients and the loss cell by ncclAllReduce as before.  Chosen at nrc_cache_comm_init when world x list capacity
  * (trainBatchSize x 16 levels x 8 corners, at most the table) < 2 x table entries, i.e. when the padded all-gather moves less
- * than the ring all-reduce; environment NRC_DENSE_GRID_EXCHANGE=1 / NRC_SPARSE_GRID_EXCHANGE=1 force either.  nrc_cache_comm_sparse: 1 when the list exchange is the one in use.  The two debug entry points expose its
+ * than the ring all-reduce; environment NRC_DEBUG=dense_grid_exchange forces the dense exchange.  nrc_cache_comm_sparse: 1 when the list exchange is the one in use.  The two debug entry points expose its
  * halves on one device (tests): the list of the last nrc_cache_backward -- words {count, 0, (entry, value) x capacity},
  * padding entries 0xffffffff, list_words >= 2 + 2 * nrc_cache_grid_list_capacity() -- and the gradient vector's table part
  * := sum of n_lists such lists (2 + 2 * capacity words apart), added in list order. */
@@ -439,8 +439,10 @@ int nrc_compare_images_sharded(nrc_cache_t* comm, const float* d_ref_local_rgba,
 int nrc_image_create(uint32_t w, uint32_t h, const float* host_rgba, float** d_out);
 int nrc_image_destroy(float* d_image);
 
-/* diagnostics (environment, read when the library first allocates): NRC_POISON_ALLOC=1 fills every device allocation with 0xFF
- * bytes at creation; NRC_GUARD_ALLOC=1 puts 4 KiB canaries around every allocation.  nrc_debug_check_guards returns -1 when the
+/* THE environment switch of the library: NRC_DEBUG="name[=value],..." -- diagnostic and test switches only, none changes a result
+ * (the list and what each does: csrc/nrc_common.hpp, debug_switch).
+ * diagnostics (read when the library first allocates): NRC_DEBUG=poison_alloc fills every device allocation with 0xFF
+ * bytes at creation; NRC_DEBUG=guard_alloc puts 4 KiB canaries around every allocation.  nrc_debug_check_guards returns -1 when the
  * guard mode is off, otherwise the number of allocations whose canaries were overwritten (0 = clean) and, in message, the first. */
 int nrc_debug_check_guards(char* message, size_t message_bytes);
 

@@ -869,7 +869,7 @@ def CompareImagesSharded(nrc, ref_local, own_local, stream=None):
 
 
 def check_guards():
-    """NRC_GUARD_ALLOC=1: (number of allocations whose canaries were overwritten, description of the first); (-1, "") when off"""
+    """NRC_DEBUG=guard_alloc: (number of allocations whose canaries were overwritten, description of the first); (-1, "") when off"""
     buf = C.create_string_buffer(512)
     n = load_library().nrc_debug_check_guards(buf, C.c_size_t(512))
     return int(n), buf.value.decode()

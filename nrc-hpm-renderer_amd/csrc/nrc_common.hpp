@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -35,6 +36,45 @@ struct CommError : std::runtime_error {
 };
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- THE environment switch of the product build: NRC_DEBUG="name[=value],name[=value],..." --------------------------------------------
+// Diagnostic and test switches only -- nothing a host needs in order to use the library, nothing that changes a result (the tests that set
+// them compare the two sides bit for bit).  Read when the object that consults it is created (a cache, a renderer), so a test can change
+// it between two objects of one process.  (-DNRC_DIAG builds add the NRC_INFER_* shape sweeps of tools/bench_mlp.py.)
+//   poison_alloc        every device allocation is filled with 0xFF bytes at creation (fp32 / fp16 NaN, index 0xFFFFFFFF): what a kernel reads
+//                       without anyone having written it shows up instead of hiding behind the zeros of a freshly booted box
+//   guard_alloc         4 KiB of 0xA5 canaries around every allocation; nrc_debug_check_guards() and every free verify them
+//   assume_xcds=N       the code paths of a device that does not have eight XCDs (placements for speed are switched off)
+//   single_stream       the renderer's frame on ONE stream in the reference's order (the four-stream graph must equal it bit for bit)
+//   no_live_list        renderer inference over the whole query buffer instead of the frame's live-query list
+//   zero_dead_queries   gen_rays writes the zero queries of pixels that did not scatter (the reference's zero-filled buffer)
+//   fused_composite     compositing as the epilogue of the inference launch (6 x 64 model; measured slower in the frame)
+//   dense_grid_exchange the HashGrid table gradient through the dense all-reduce instead of the all-gathered lists
+//   no_fused_opt        three optimizer launches (k_adam_ema / k_sgd_ema, k_pack, k_pack_grid) instead of the fused one
+//   grid_no_bins        every pair of the table gradient through the fixed-point shadow (no per-bin lists)
+//   wgrad_old=0|1       round 3's k_wgrad (1) or k_wgrad2 (0) whatever the width;   train_gen_old=0|1, train_gen_nt=N: likewise k_train_gen
+//   wave_priority_raise=0|1   nrc_set_wave_priority_raise for hosts that cannot call it (tests/cpp/stress_main)
+inline bool debug_switch(const char* name, long* value = nullptr)
+{
+    const char* e = getenv("NRC_DEBUG");
+    if (!e) return false;
+    const size_t n = std::strlen(name);
+    for (const char* p = e; *p;) {
+        const char* end = std::strchr(p, ',');
+        const size_t len = end ? (size_t)(end - p) : std::strlen(p);
+        if (len >= n && std::strncmp(p, name, n) == 0 && (len == n || p[n] == '=')) {
+            if (value) *value = len > n ? std::strtol(p + n + 1, nullptr, 10) : 1;
+            return true;
+        }
+        p += len + (end ? 1 : 0);
+    }
+    return false;
+}
+inline long debug_value(const char* name, long fallback)
+{
+    long v = fallback;
+    return debug_switch(name, &v) ? v : fallback;
+}
 
 // ---- events as part of a launch.  A hipEventRecord costs the host 3.5 us, a kernel launch 2.2 us -- and a launch that carries its own
 // start / stop event (hipExtLaunchKernelGGL) 1.6 us (tools/ext_launch_probe.hip: the stop event orders other streams and carries a time
@@ -85,19 +125,15 @@ struct LaunchTailScope {
 // never for correctness; they are written for the MI355X's eight and are switched off on any other count (another partition mode, another chip).
 inline int device_xcds()
 {
-    if (const char* e = getenv("NRC_ASSUME_XCDS")) return atoi(e);      // tests: the paths of a device that does not have eight
+    { long v = 0; if (debug_switch("assume_xcds", &v)) return (int)v; }      // tests: the paths of a device that does not have eight
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) return 0;
     return n;
 }
 
-// Every device allocation of the library goes through these two (nrc_api.hip).  Diagnostic environment switches, read once:
-//   NRC_POISON_ALLOC=1  every allocation is filled with 0xFF bytes at creation (fp32 NaN, fp16 NaN, index 0xFFFFFFFF): whatever a
-//                       kernel reads without anyone having written it shows up in the result instead of hiding behind the zeros
-//                       of a freshly booted box;
-//   NRC_GUARD_ALLOC=1   4 KiB of 0xA5 canary bytes in front of and behind every allocation; nrc_debug_check_guards() (and every
-//                       dev_free) verifies them -- a kernel that stores outside its buffer is named by the allocation it ran over.
+// Every device allocation of the library goes through these two (nrc_api.hip); NRC_DEBUG=poison_alloc / guard_alloc (above) make them
+// fill what they hand out with NaN bytes / fence it with canaries that nrc_debug_check_guards() and every dev_free verify.
 void dev_alloc(void** p, size_t bytes, const char* what = "");
 void dev_free(void* p);
 template <class T>

@@ -21,9 +21,6 @@
 #include "nrc_math.h"
 
 // 1: the tracking loops carry their predicates as uniform 64-bit lane masks (round 4); 0: as per-lane bools (round 3)
-#ifndef NRC_TRACK_MASKS
-#define NRC_TRACK_MASKS 1
-#endif
 // 1: every look-up tests the LDS occupancy bits unconditionally; 0 (product): behind a wave-uniform test for the table, as in round 3.
 // Round 4 measured both: without the test k_gen_rays is 1 % faster alone (0.2092 against 0.2117 ms: one branch and four mask merges
 // fewer per trip) and 12 % faster inside the configs[4] frame (0.283 against 0.318 ms) -- and the FRAMES are slower, 7 730 against 7 850
@@ -34,9 +31,6 @@
 #define NRC_OCC_ALWAYS 0
 #endif
 // 1 (product): software-pipelined, predicated tracking loops; 0 (diagnostic A/B build): the plain two-collision loops
-#ifndef NRC_TRACK_PIPELINE
-#define NRC_TRACK_PIPELINE 1
-#endif
 // waves per SIMD the camera kernels are register-allocated for
 #ifndef NRC_CAMERA_WAVES_PER_SIMD
 #define NRC_CAMERA_WAVES_PER_SIMD 5
@@ -182,6 +176,9 @@ struct CtxT {
 #ifdef NRC_LOOP_PROFILE
     uint32_t useful[8] = {0, 0, 0, 0, 0, 0, 0, 0}, issued[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fee_kind = 1;
+#endif
+#ifdef NRC_DIAG_CUT_TAIL2
+    uint32_t cut2 = 0;      // DIAGNOSTIC (wrong frames): the second vertex's delta walk stops when at most this many lanes still walk
 #endif
     __device__ __forceinline__ float rand(float max_val)
     {
@@ -389,23 +386,12 @@ __device__ __forceinline__ float hg_phase(const DevScene& s, float cos_theta)
     return (0.5f * (1.0f - g2)) / (x * sqrtf(x));
 }
 
-#ifndef NRC_DIAG_BISECT
-#define NRC_DIAG_BISECT_ROT(on, bit) do { } while (0)
-#else
-// (sub-regions of the SECOND rotation of new_ray_dir: 64 the axis normalisation, 128 sincos, 256 the matrix and its product)
-#define NRC_DIAG_BISECT_ROT(on, bit) do { if (SECOND && ((NRC_DIAG_BISECT) & (bit))) __builtin_amdgcn_s_setprio((on) ? 3 : 0); } while (0)
-#endif
 template <bool SECOND = false>
 __device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
 {
-    NRC_DIAG_BISECT_ROT(true, 64);
     axis = normalize(axis);
-    NRC_DIAG_BISECT_ROT(false, 64);
     float s, co;
-    NRC_DIAG_BISECT_ROT(true, 128);
     nrc_sincosf(angle, &s, &co);
-    NRC_DIAG_BISECT_ROT(false, 128);
-    NRC_DIAG_BISECT_ROT(true, 256);
     float oc = 1.0f - co;
     const float ox = oc * axis.x, oy = oc * axis.y, oz = oc * axis.z;
     V3 c0 = v3(nrc_fmaf_(ox, axis.x, co), nrc_fmaf_(ox, axis.y, -(axis.z * s)), nrc_fmaf_(oz, axis.x, axis.y * s));
@@ -414,33 +400,21 @@ __device__ __forceinline__ V3 rotate(V3 axis, float angle, V3 v)
     const V3 r = v3(nrc_fmaf_(c2.x, v.z, nrc_fmaf_(c1.x, v.y, c0.x * v.x)),
                     nrc_fmaf_(c2.y, v.z, nrc_fmaf_(c1.y, v.y, c0.y * v.x)),
                     nrc_fmaf_(c2.z, v.z, nrc_fmaf_(c1.z, v.y, c0.z * v.x)));
-    NRC_DIAG_BISECT_ROT(false, 256);
     return r;
 }
 
-// DIAGNOSTIC (tools/stress_lastdir.sh, -DNRC_DIAG_BISECT=<mask> on top of -DNRC_DIAG_LOWPRIO=8): the camera kernels run at wave
-// priority 0 except inside the code regions whose bit is set -- which stretch of code has to be protected for the frames to agree?
-//   1 the whole new_ray_dir call, 2 its normalisations of the old direction and the axis, 4 the polar angle, 8 the first rotation,
-//   16 the azimuth draw and the second rotation, 32 the final normalisation
-#ifdef NRC_DIAG_BISECT
-#define NRC_BISECT_ON(bit) do { if ((NRC_DIAG_BISECT) & (bit)) __builtin_amdgcn_s_setprio(3); } while (0)
-#define NRC_BISECT_OFF(bit) do { if ((NRC_DIAG_BISECT) & (bit)) __builtin_amdgcn_s_setprio(0); } while (0)
-#else
-#define NRC_BISECT_ON(bit) do { } while (0)
-#define NRC_BISECT_OFF(bit) do { } while (0)
-#endif
+// (The diagnostic builds of DESIGN.md section 7.1 -- -DNRC_DIAG_LASTDIR, -DNRC_DIAG_BISECT=<mask>: code regions of new_ray_dir bracketed with
+// s_setprio -- did their work in round 3 and left the product source in round 6; tools/stress_lastdir.sh, bisect_build.sh and
+// asm_patch_experiment.sh name the commit that still builds them.)
 template <class C>
 __device__ __forceinline__ V3 new_ray_dir(C& c, V3 old_dir, bool phase_sampling)
 {
     NRC_PROF(c, 4);
-    NRC_BISECT_ON(2);
     old_dir = normalize(old_dir);
     V3 ortho = old_dir.z < old_dir.x ? v3(old_dir.y, -old_dir.x, 0.0f) : v3(0.0f, -old_dir.z, old_dir.y);
     if (ortho.x == 0.0f && ortho.y == 0.0f && ortho.z == 0.0f) ortho = v3(0.0f, 1.0f, 0.0f);   // robustness
     ortho = normalize(ortho);
-    NRC_BISECT_OFF(2);
     float angle;
-    NRC_BISECT_ON(4);
     if (phase_sampling) {
         float g = c.sc.g;
         float cos_theta;
@@ -454,19 +428,10 @@ __device__ __forceinline__ V3 new_ray_dir(C& c, V3 old_dir, bool phase_sampling)
     } else {
         angle = c.rand(NRC_PI);
     }
-    NRC_BISECT_OFF(4);
-    NRC_BISECT_ON(8);
     V3 nd = rotate(ortho, angle, old_dir);
-    NRC_BISECT_OFF(8);
-    NRC_BISECT_ON(16);
-    NRC_BISECT_ON(512);      // (512: the azimuth draw alone)
     angle = c.rand(NRC_TWO_PI);
-    NRC_BISECT_OFF(512);
     nd = rotate<true>(old_dir, angle, nd);
-    NRC_BISECT_OFF(16);
-    NRC_BISECT_ON(32);
     nd = normalize(nd);
-    NRC_BISECT_OFF(32);
     return nd;
 }
 
@@ -499,9 +464,6 @@ __device__ __forceinline__ RatioTrip ratio_trip(float rng, float t, float t_max,
 // only serial part, a quarter of a trip's instructions), the two free-flight logs, positions, look-ups and transmittance factors
 // of collisions 1, 2 are lane p's work and those of 3, 4 lane p + 32's, exchanged with v_permlane32_swap, and the free-flight sums
 // and transmittance products are then formed by both lanes in the sequential order -- bit for bit the walk of the one-lane loop.
-#ifndef NRC_PAIR_TAIL
-#define NRC_PAIR_TAIL 1
-#endif
 // (value of the lower-half lane, value of the upper-half lane) of a pair, on both of its lanes
 __device__ __forceinline__ void pair_both(float x, float* lo, float* hi)
 {
@@ -510,86 +472,9 @@ __device__ __forceinline__ void pair_both(float x, float* lo, float* hi)
     *hi = nrc_u2f(r[1]);
 }
 
-// ---- the last walks: 32 lanes per walk ----------------------------------------------------------------------------------------
-// What ends a launch is a wave that still has one or two long walks when its neighbours are done (tools/loop_profile.py): in the
-// pair loop such a walk advances four collisions per round trip to memory.  When at most two walks are left and they still have a
-// long way to go, each gets HALF THE WAVE: the next 32 draws of its hash chain are made by all 32 lanes (the chain is the one serial
-// part; lane j keeps draw j + 1), the 32 free-flight logs, positions, look-ups and transmittance factors are one lane's work each,
-// and the running free-flight position and transmittance product are then replayed in the walk's own order with v_readlane -- bit
-// for bit the sequential walk, 32 collisions per memory round trip.
-// MEASURED AND SWITCHED OFF (round 3): bit-exact at the first attempt (every oracle comparison of tests/test_gpu_integrator.py), but the
-// walks it applies to are too few -- against a build that contains the code and never enters it, entering from 8 / 16 / 32 expected
-// collisions left gains 0.000 / 0.005 / 0.002 ms of 0.251 -- and its presence costs the whole kernel 0.038 ms (0.213 -> 0.251: 62 -> 162
-// SGPR spills and 8 bytes of scratch under the 96-VGPR cap).  -DNRC_WIDE_TAIL=1 builds it.
-#ifndef NRC_WIDE_TAIL
-#define NRC_WIDE_TAIL 0
-#endif
-#ifndef NRC_WIDE_MIN
-#define NRC_WIDE_MIN 8      // expected collisions left (free-flight lengths) from which a walk goes wide
-#endif
-// value of lane i of the lower half on the lower half's lanes, of lane 32 + i on the upper half's (i wave-uniform)
-__device__ __forceinline__ float half_bcast(float x, uint32_t i, bool upper)
-{
-    const float lo = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)i));
-    const float hi = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)(32u + i)));
-    return upper ? hi : lo;
-}
-// ratio walks in (R0, t0, T, tm, nn, st, dr), uniform over each half of the wave (`on`: the half has a walk); runs them to their end.
-// On exit T and rf (the last draw made) are the finished walks' results on every lane of their half.
-template <class C>
-__device__ __forceinline__ void ratio_wide(C& c, bool on, float R0, float t0, float tm, uint32_t nn, V3 st, V3 dr, float inv, float& T, float& rf)
-{
-    const uint32_t lane = threadIdx.x & 63u, j = lane & 31u;
-    const bool upper = (lane & 32u) != 0u;
-    for (;;) {
-        if (__ballot(on) == 0ull) break;
-        // 32 draws of the chain; lane j keeps draw j + 1
-        float R = R0, my_r = 0.0f;
-#pragma unroll
-        for (uint32_t i = 0; i < 32u; i++) {
-            R = random1(R);
-            my_r = (i == j) ? R : my_r;
-        }
-        const float l = logf2(f2{1.0f - my_r, 1.0f - my_r}).x;
-        // free-flight positions in the walk's order
-        float t = t0, my_t = 0.0f;
-#pragma unroll
-        for (uint32_t i = 0; i < 32u; i++) {
-            t = nrc_fmaf_(-half_bcast(l, i, upper), inv, t);
-            my_t = (i == j) ? t : my_t;
-        }
-        // draw j + 1 is made unless 128 collisions are done; the walk ends on the first draw that is not made or lies beyond the segment
-        const bool made = nn + j + 1u <= 128u;
-        const bool stop = on & (!made | (my_t >= tm));
-        const unsigned long long sm = __ballot(stop);
-        const uint32_t sh = upper ? (uint32_t)(sm >> 32) : (uint32_t)sm;
-        const uint32_t K = !on ? 0u : (sh != 0u ? (uint32_t)__builtin_ctz(sh) : 32u);      // collisions 1..K lie inside the segment
-        const bool inseg = j < K;
-        const Addr2 ad = fetch2_addr(c, dr, st, my_t, my_t, inseg, false);
-        const Fetch2 fa = fetch2_load(c, ad);
-        const float f = nrc_fmaf_(-fetch2_density(c.sc, fa).x, inv, 1.0f);
-        c.count(inseg ? 1u : 0u);
-        // the last draw made (1-based): 32 when the chunk has no stop, K when the cap ended the walk, K + 1 when draw K + 1 lies beyond
-        // the segment; 0: none in this chunk (the cap was reached with the chunk before)
-        const uint32_t last = K == 32u ? 32u : (nn + K + 1u > 128u ? K : K + 1u);
-        const float r_sel = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & 32u) + (last == 0u ? 0u : last - 1u)) * 4u), (int)nrc_f2u(my_r)));
-        rf = (on & (last != 0u)) ? r_sel : rf;
-        // transmittance in the walk's order (a wave-uniform loop: the longer of the two walks' chunks)
-        const uint32_t kmax = max((uint32_t)__builtin_amdgcn_readlane((int)K, 0), (uint32_t)__builtin_amdgcn_readlane((int)K, 32));
-#pragma unroll 4
-        for (uint32_t i = 0; i < 32u; i++) {
-            if (i >= kmax) break;
-            const float fi = half_bcast(f, i, upper);
-            T = (i < K) ? T * fi : T;
-        }
-        // no stop in this chunk: the walk goes on behind draw 32
-        on &= K == 32u;
-        nn += 32u;
-        R0 = R;
-        t0 = t;
-    }
-}
-
+// (Two further tails were built bit-exact, measured and removed -- docs/MEASUREMENT_LOG.md: `ratio_wide`, 32 lanes for each of a wave's last one
+// or two ratio walks: the walks it applies to are too few and its registers cost the kernel 0.038 ms; `delta_pairs`, the pair tail for
+// delta tracking: 144 B of scratch under the 96-register cap, slower at five waves per SIMD.  Their sources: git history, round 5's tree.)
 // the surviving walks of a ratio_track loop, two lanes per walk.  On entry: `alive` lanes have a located trip whose base state is
 // (bs, bt) = (chain value before its first draw, free-flight position before it), n collisions done.  On exit: tr / rng of the alive
 // lanes are the finished walks' results.
@@ -624,25 +509,6 @@ __device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool al
         const unsigned long long actm = __ballot(act);
         if (actm == 0ull) break;
         NRC_PROF_LIVE(1, actm & 0xffffffffull);
-#if NRC_WIDE_TAIL
-        // one or two walks left with a long way to go (at least eight more collisions expected): half the wave each (ratio_wide)
-        if (__popc((uint32_t)actm) <= 2 && __ballot(act & (tm - t0 >= (float)(NRC_WIDE_MIN) * inv)) != 0ull) {
-            const uint32_t ra = (uint32_t)__builtin_ctz((uint32_t)actm), rb = 31u - (uint32_t)__builtin_clz((uint32_t)actm);
-            auto pick = [&](float x) {
-                const float lo = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)ra));
-                const float hi = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(x), (int)rb));
-                return is_b ? hi : lo;
-            };
-            float Tw = pick(T), rfw = pick(rf);
-            ratio_wide(c, !is_b | (rb != ra), pick(R0), pick(t0), pick(tm), nrc_f2u(pick(nrc_u2f(nn))), v3(pick(st.x), pick(st.y), pick(st.z)),
-                       v3(pick(dr.x), pick(dr.y), pick(dr.z)), inv, Tw, rfw);
-            const float Ta = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(Tw), 0)), Tb = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(Tw), 32));
-            const float ra_f = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(rfw), 0)), rb_f = nrc_u2f((uint32_t)__builtin_amdgcn_readlane((int)nrc_f2u(rfw), 32));
-            if ((lane & 31u) == ra) { T = Ta; rf = ra_f; }
-            if (rb != ra && (lane & 31u) == rb) { T = Tb; rf = rb_f; }
-            break;
-        }
-#endif
         const float R1 = random1(R0), R2 = random1(R1), R3 = random1(R2), R4 = random1(R3);
         const f2 l = logf2(f2{1.0f - (is_b ? R3 : R1), 1.0f - (is_b ? R4 : R2)});
         float l1, l2, l3, l4;
@@ -680,7 +546,6 @@ __device__ __forceinline__ void ratio_pairs(C& c, unsigned long long am, bool al
     rng = alive ? rng_new : rng;
 }
 
-#if NRC_TRACK_PIPELINE
 // The loop is wave-uniform (it runs while any lane still walks) and its body is predicated with selects instead of per-lane
 // branches: with `break`s the compiler sinks the look-ahead into the continue path, i.e. behind the wait for the gathers, and
 // the overlap is gone.  Lanes that have finished keep their results and issue no gathers (offset 2^31).
@@ -700,7 +565,6 @@ __device__ __forceinline__ unsigned long long lane_mask(bool b) { return __built
 // recurrences (hash chain, free-flight sums, transmittance product) as DPP wave_shr:1 scans along the group (tools/scan_probe.hip,
 // tools/dpp_probe.hip).  Bit-exact at the first run of every oracle comparison -- and slower than the pair tail on every preset
 // (k_gen_rays alone 0.2111 -> 0.2138 ... 0.2181 ms by entry threshold, frame - 5 %, configs[4] - 4.7 %, Monte-Carlo renderer - 1.5 %).
-#if NRC_TRACK_MASKS
 template <bool UNI = false, class C>
 __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
 {
@@ -723,14 +587,12 @@ __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid 
 #else
         if (alive_m == 0ull) break;
 #endif
-#if NRC_PAIR_TAIL
         if constexpr (UNI) {
             if (__popcll(alive_m) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
                 ratio_pairs(c, alive_m, lane_bool(alive_m), start, dir, t_max, inv, bs, bt, i, tr, rng);
                 break;
             }
         }
-#endif
         const bool alive = lane_bool(alive_m);
         if (alive) NRC_PROF(c, 3);
         NRC_PROF_LIVE(0, alive_m);
@@ -759,119 +621,6 @@ __device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid 
     c.rng = rng;
     return tr;
 }
-#else      // round 3's loops: per-lane bools as the loop-carried predicates
-template <bool UNI = false, class C>
-__device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
-{
-    V3 d = sub(end, start);
-    const V3 dir = normalize(d);
-    const float t_max = length(d);
-    const float inv = c.sc.inv_max_density;
-    float tr = 1.0f;
-    float rng = c.rng;
-    bool alive = valid;
-    RatioTrip a = ratio_trip(rng, 0.0f, t_max, inv);
-    Addr2 ia = fetch2_addr(c, dir, start, a.t1, a.t2, a.live1, a.live1 & a.second);
-    float bs = rng, bt = 0.0f;                 // base of the located trip `a`: chain value and position before its first draw
-    for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:34)
-        rng = (alive & !a.live1) ? a.s1 : rng;                       // collision 1 beyond the segment: the walk ends on this draw
-        alive &= a.live1;
-#ifdef NRC_DIAG_CUT_TAIL
-        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
-#else
-        if (__ballot(alive) == 0ull) break;
-#endif
-#if NRC_PAIR_TAIL
-        if constexpr (UNI) {
-            const unsigned long long am = __ballot(alive);
-            if (__popcll(am) <= 31) {        // few walks left: two lanes each (ratio_pairs; lanes 31 and 63 stay free as push targets)
-                ratio_pairs(c, am, alive, start, dir, t_max, inv, bs, bt, i, tr, rng);
-                break;
-            }
-        }
-#endif
-        if (alive) NRC_PROF(c, 3);
-        NRC_PROF_LIVE(0, __ballot(alive));
-        const Fetch2 fa = fetch2_load(c, ia);                        // this trip's gathers ...
-        __builtin_amdgcn_sched_barrier(0);
-        const bool last = i + 2 >= 128;
-        const bool more = alive & a.second & !last;
-        const RatioTrip b = ratio_trip(a.s2, a.t2, t_max, inv);      // ... fly while the next trip is located
-        const Addr2 ib = fetch2_addr(c, dir, start, b.t1, b.t2, more & b.live1, more & b.live1 & b.second);
-        __builtin_amdgcn_sched_barrier(0);
-        const f2 dens = fetch2_density(c.sc, fa);
-        const bool two = alive & a.second;
-        c.count(alive ? (a.second ? 2u : 1u) : 0u);
-        tr = alive ? tr * nrc_fmaf_(-dens.x, inv, 1.0f) : tr;
-        tr = two ? tr * nrc_fmaf_(-dens.y, inv, 1.0f) : tr;
-        rng = (alive & (!a.second | last)) ? a.s2 : rng;              // ends after collision 1 / after the 128th collision
-        alive = more;
-        bs = a.s2;
-        bt = a.t2;
-        a = b;
-        ia = ib;
-    }
-    c.rng = rng;
-    return tr;
-}
-#endif
-#else
-// reference form of the loop (diagnostic build -DNRC_TRACK_PIPELINE=0): two collisions per trip, gathers awaited in the trip
-// get_density at start + dir*t1 and start + dir*t2 (second fetch masked unless `second`); returns densities
-template <class C>
-__device__ __forceinline__ f2 get_density2(C& c, V3 dir, V3 start, float t1, float t2, bool second)
-{
-    const DevScene& s = c.sc;
-    const f2 t = f2{t1, t2};
-    const f2 px = fma2(splat(dir.x), t, splat(start.x));
-    const f2 py = fma2(splat(dir.y), t, splat(start.y));
-    const f2 pz = fma2(splat(dir.z), t, splat(start.z));
-    const f2 u = fma2(px, splat(s.inv_size[0]), splat(0.5f));
-    const f2 v = fma2(py, splat(s.inv_size[1]), splat(0.5f));
-    const f2 w = fma2(pz, splat(s.inv_size[2]), splat(0.5f));
-    const f2 fx = u * splat(s.fnx), fy = v * splat(s.fny), fz = w * splat(s.fnz);
-    // 0 <= f < n  <=>  0 <= u < 1 (n >= 1; u*n never rounds up to n; u is never -0)  <=>  bits(u) < bits(1.0f)
-    const bool in0 = max(max(nrc_f2u(u.x), nrc_f2u(v.x)), nrc_f2u(w.x)) < 0x3f800000u;
-    const bool in1 = (max(max(nrc_f2u(u.y), nrc_f2u(v.y)), nrc_f2u(w.y)) < 0x3f800000u) & second;
-    uint32_t idx0 = index24((uint32_t)fz.x, s.ny, (uint32_t)fy.x, s.nx, (uint32_t)fx.x);
-    uint32_t idx1 = index24((uint32_t)fz.y, s.ny, (uint32_t)fy.y, s.nx, (uint32_t)fx.y);
-    idx0 = in0 ? idx0 : 0x80000000u;
-    idx1 = in1 ? idx1 : 0x80000000u;
-    const uint8_t b0 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx0, 0, 0);
-    const uint8_t b1 = __builtin_amdgcn_raw_buffer_load_b8(c.vol, (int)idx1, 0, 0);
-    return splat(s.density_factor) * (f2{(float)b0, (float)b1} * splat(1.0f / 255.0f));
-}
-template <bool UNI = false, class C>
-__device__ __forceinline__ float ratio_track(C& c, V3 start, V3 end, bool valid = true)
-{
-    if (!valid) return 1.0f;
-    V3 d = sub(end, start);
-    V3 dir = normalize(d);
-    const float t_max = length(d);
-    const float inv = c.sc.inv_max_density;
-    float tr = 1.0f, t = 0.0f;
-    float rng = c.rng;
-    for (uint32_t i = 0; i < 128; i += 2) {
-        NRC_PROF(c, 3);
-        const float s1 = random1(rng), s2 = random1(s1);
-        const f2 l = logf2(f2{1.0f - s1, 1.0f - s2});
-        const float t1 = nrc_fmaf_(-l.x, inv, t);
-        rng = s1;
-        if (t1 >= t_max) break;
-        const float t2 = nrc_fmaf_(-l.y, inv, t1);
-        const bool second = !(t2 >= t_max);
-        const f2 dens = get_density2(c, dir, start, t1, t2, second);
-        c.count(second ? 2u : 1u);
-        tr *= nrc_fmaf_(-dens.x, inv, 1.0f);
-        rng = s2;
-        if (!second) break;
-        tr *= nrc_fmaf_(-dens.y, inv, 1.0f);
-        t = t2;
-    }
-    c.rng = rng;
-    return tr;
-}
-#endif
 
 template <bool UNI = false, class C>
 __device__ __forceinline__ V3 trace_dir_light(C& c, V3 pos, V3 dir, bool valid = true)
@@ -985,97 +734,6 @@ __device__ __forceinline__ DeltaTrip delta_trip(float rng, float t, float t_max,
     r.second = !(r.t2 >= t_max);
     return r;
 }
-// NRC_PAIR_TAIL_DELTA (off): the same for delta tracking.  Bit-exact like ratio_pairs, but its eight draws and four-way resolution push
-// k_gen_rays past the 102 VGPRs of five waves per SIMD (144 B of scratch: stand-alone 0.242 -> 0.258 ms); at four waves per SIMD it
-// is the fastest stand-alone (0.241 ms) and slower inside the frame (gen_rays 0.283 instead of 0.266 ms).
-#ifndef NRC_PAIR_TAIL_DELTA
-#define NRC_PAIR_TAIL_DELTA 0
-#endif
-// the surviving walks of a delta_track loop, two lanes per walk (see ratio_pairs): four tentative collisions per iteration -- eight
-// draws (flight, acceptance, flight, ...) by both lanes, collisions 1, 2 located and looked up by the lower lane and 3, 4 by the
-// upper one, then resolved in sequence: exit on the first flight beyond the segment, hit on the first accepted collision.
-template <class C>
-__device__ __forceinline__ void delta_pairs(C& c, unsigned long long am, bool alive, V3 ro, V3 rd, float t_max, float inv, float bs, float bt,
-                                            uint32_t n, float& rng, bool& hit, float& t_hit, bool& vexit)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-    const uint32_t k = (uint32_t)__popcll(am);
-    const bool is_b = (lane & 32u) != 0u;
-    float y[10];
-    {
-        const float x[10] = {bs, bt, t_max, nrc_u2f(n), ro.x, ro.y, ro.z, rd.x, rd.y, rd.z};
-#pragma unroll
-        for (int q = 0; q < 10; q++) {
-            const int lo = __builtin_amdgcn_ds_permute((int)((alive ? rank : 31u) * 4u), (int)nrc_f2u(x[q]));
-            const int hi = __builtin_amdgcn_ds_permute((int)((alive ? rank + 32u : 63u) * 4u), (int)nrc_f2u(x[q]));
-            y[q] = nrc_u2f((uint32_t)(is_b ? hi : lo));
-        }
-    }
-    float R0 = y[0], t0 = y[1];
-    const float tm = y[2];
-    uint32_t nn = nrc_f2u(y[3]);
-    const V3 o = v3(y[4], y[5], y[6]), d = v3(y[7], y[8], y[9]);
-    bool act = (lane & 31u) < k;
-    float rf = R0, th = 0.0f;
-    bool hitf = false, vx = false;
-    for (;;) {
-        if (__ballot(act) == 0ull) break;
-        const float s1 = random1(R0), a1 = random1(s1), s2 = random1(a1), a2 = random1(s2);
-        const float s3 = random1(a2), a3 = random1(s3), s4 = random1(a3), a4 = random1(s4);
-        const f2 l = logf2(f2{1.0f - (is_b ? s3 : s1), 1.0f - (is_b ? s4 : s2)});
-        float l1, l2, l3, l4;
-        pair_both(l.x, &l1, &l3);
-        pair_both(l.y, &l2, &l4);
-        const float t1 = nrc_fmaf_(-l1, inv, t0), t2 = nrc_fmaf_(-l2, inv, t1), t3 = nrc_fmaf_(-l3, inv, t2), t4 = nrc_fmaf_(-l4, inv, t3);
-        const bool v1 = !(t1 >= tm), v2 = v1 & !(t2 >= tm), v3_ = v2 & !(t3 >= tm), v4 = v3_ & !(t4 >= tm);
-        // look-ups of every collision the walk can still reach (its acceptance draws decide below): 1, 2 lower lane, 3, 4 upper lane
-        const bool ma = act & (is_b ? (v3_ & (nn + 3u <= 128u)) : (v1 & (nn + 1u <= 128u)));
-        const bool mb = act & (is_b ? (v4 & (nn + 4u <= 128u)) : (v2 & (nn + 2u <= 128u)));
-        const Addr2 ad = fetch2_addr(c, d, o, is_b ? t3 : t1, is_b ? t4 : t2, ma, mb);
-        const Fetch2 fa = fetch2_load(c, ad);
-        const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
-        float d1, d2, d3, d4;
-        pair_both(dens.x, &d1, &d3);
-        pair_both(dens.y, &d2, &d4);
-        // the sequential walk
-        bool go = act;
-        uint32_t nf = 0;
-#define NRC_DELTA_STEP(K, S, A, T, V, D)                                                     \
-        {                                                                                    \
-            const bool dk = go & (nn + (K) <= 128u);      /* the flight draw is made */       \
-            rf = dk ? (S) : rf;                                                              \
-            vx |= dk & !(V);                              /* beyond the exit point */         \
-            const bool ak = dk & (V);                     /* acceptance draw + look-up */     \
-            rf = ak ? (A) : rf;                                                              \
-            nf += ak ? 1u : 0u;                                                              \
-            const bool acc = ak & ((D) > (A));                                               \
-            hitf |= acc;                                                                     \
-            th = acc ? (T) : th;                                                             \
-            go = ak & !acc;                                                                  \
-        }
-        NRC_DELTA_STEP(1u, s1, a1, t1, !(t1 >= tm), d1)
-        NRC_DELTA_STEP(2u, s2, a2, t2, !(t2 >= tm), d2)
-        NRC_DELTA_STEP(3u, s3, a3, t3, !(t3 >= tm), d3)
-        NRC_DELTA_STEP(4u, s4, a4, t4, !(t4 >= tm), d4)
-#undef NRC_DELTA_STEP
-        c.count(is_b ? 0u : nf);                     // counted once per walk
-        act = go & (nn + 4u < 128u);
-        nn += 4u;
-        R0 = a4;
-        t0 = t4;
-    }
-    const float rng_new = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)nrc_f2u(rf)));
-    const float th_new = nrc_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)nrc_f2u(th)));
-    const uint32_t fl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank * 4u), (int)((hitf ? 1u : 0u) | (vx ? 2u : 0u)));
-    rng = alive ? rng_new : rng;
-    t_hit = alive ? th_new : t_hit;
-    hit = alive ? ((fl & 1u) != 0u) : hit;
-    vexit = alive ? ((fl & 2u) != 0u) : vexit;
-}
-
-#if NRC_TRACK_PIPELINE
-#if NRC_TRACK_MASKS
 template <bool UNI = false, class C>
 __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
 {
@@ -1105,16 +763,8 @@ __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit,
 #else
         if (alive_m == 0ull) break;
 #endif
-#if NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
-        if constexpr (UNI) {
-            if (__popcll(alive_m) <= 31) {        // few walks left: two lanes each (delta_pairs)
-                bool hit = lane_bool(hit_m), vexit = lane_bool(vexit_m);
-                delta_pairs(c, alive_m, lane_bool(alive_m), ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
-                hit_m = lane_mask(hit);
-                vexit_m = lane_mask(vexit);
-                break;
-            }
-        }
+#ifdef NRC_DIAG_CUT_TAIL2
+        if ((uint32_t)__popcll(alive_m) <= c.cut2) break;      // DIAGNOSTIC (wrong frames): the same for the second vertex's delta walk alone
 #endif
         const bool alive = lane_bool(alive_m);
         if (alive) NRC_PROF(c, 2);
@@ -1160,122 +810,6 @@ __device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit,
     }
     return madd(rd, c.rand(t_max), ro);
 }
-#else
-template <bool UNI = false, class C>
-__device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
-{
-    V3 en, ex;
-    if constexpr (UNI) {      // lanes without a walk march a harmless ray (from the centre along +z): the march must end for them too
-        find_entry_exit(c, sel(valid, ro, v3(0.0f, 0.0f, 0.0f)), sel(valid, rd, v3(0.0f, 0.0f, 1.0f)), &en, &ex);
-    } else {
-        find_entry_exit(c, ro, rd, &en, &ex);
-    }
-    const float t_max = length(sub(ex, ro));
-    const float inv = c.sc.inv_max_density;
-    float rng = c.rng;
-    bool alive = valid, hit = false, vexit = false;
-    float t_hit = 0.0f;
-    DeltaTrip a = delta_trip(rng, 0.0f, t_max, inv);
-    Addr2 ia = fetch2_addr(c, rd, ro, a.t1, a.t2, a.live1, a.live1 & a.second);
-    float bs = rng, bt = 0.0f;                 // base of the located trip `a`
-    for (uint32_t i = 0;; i += 2) {            // i counts collisions: at most 128 (path_trace.glsl:161); predicated like ratio_track
-        const bool out1 = alive & !a.live1;                          // collision 1 beyond the exit point
-        rng = out1 ? a.s1 : rng;
-        vexit |= out1;
-        alive &= a.live1;
-#ifdef NRC_DIAG_CUT_TAIL
-        if (__popcll(__ballot(alive)) <= NRC_DIAG_CUT_TAIL) break;      // DIAGNOSTIC (wrong frames): what the trips with few live lanes cost
-#else
-        if (__ballot(alive) == 0ull) break;
-#endif
-#if NRC_PAIR_TAIL && NRC_PAIR_TAIL_DELTA
-        if constexpr (UNI) {
-            const unsigned long long am = __ballot(alive);
-            if (__popcll(am) <= 31) {        // few walks left: two lanes each (delta_pairs)
-                delta_pairs(c, am, alive, ro, rd, t_max, inv, bs, bt, i, rng, hit, t_hit, vexit);
-                break;
-            }
-        }
-#endif
-        if (alive) NRC_PROF(c, 2);
-        NRC_PROF_LIVE(2, __ballot(alive));
-        const Fetch2 fa = fetch2_load(c, ia);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool last = i + 2 >= 128;
-        const DeltaTrip b = delta_trip(a.a2, a.t2, t_max, inv);      // located ahead; used only if this trip accepts nothing
-        const bool maybe = alive & a.second & !last;
-        const Addr2 ib = fetch2_addr(c, rd, ro, b.t1, b.t2, maybe & b.live1, maybe & b.live1 & b.second);
-        __builtin_amdgcn_sched_barrier(0);
-        const f2 dens = fetch2_density(c.sc, fa) * splat(inv);
-        c.count(alive ? 1u : 0u);
-        const bool acc1 = alive & (dens.x > a.a1);
-        const bool alive2 = alive & !acc1;
-        const bool out2 = alive2 & !a.second;                        // collision 2 beyond the exit point
-        const bool alive3 = alive2 & a.second;
-        c.count(alive3 ? 1u : 0u);
-        const bool acc2 = alive3 & (dens.y > a.a2);
-        hit |= acc1 | acc2;
-        t_hit = acc1 ? a.t1 : (acc2 ? a.t2 : t_hit);
-        vexit |= out2;
-        // RNG state of the event that ended the walk: accept 1 -> a1, exit 2 -> s2, accept 2 or the 128-collision cap -> a2
-        rng = acc1 ? a.a1 : rng;
-        rng = out2 ? a.s2 : rng;
-        rng = (alive3 & (acc2 | last)) ? a.a2 : rng;
-        alive = alive3 & !acc2 & !last;
-        bs = a.a2;
-        bt = a.t2;
-        a = b;
-        ia.i0 = alive ? ib.i0 : 0x80000000u;                         // a lane that has just finished fetches nothing next trip
-        ia.i1 = alive ? ib.i1 : 0x80000000u;
-    }
-    c.rng = rng;
-    *volume_exit = vexit;
-    if (hit) return madd(rd, t_hit, ro);
-    if constexpr (UNI) {
-        if (!valid) return ro;          // no walk: no draw
-    }
-    return madd(rd, c.rand(t_max), ro);
-}
-#endif
-#else
-template <bool UNI = false, class C>
-__device__ __forceinline__ V3 delta_track(C& c, V3 ro, V3 rd, bool* volume_exit, bool valid = true)
-{
-    *volume_exit = false;
-    if (!valid) return ro;
-    V3 en, ex;
-    find_entry_exit(c, ro, rd, &en, &ex);
-    const float t_max = length(sub(ex, ro));
-    const float inv = c.sc.inv_max_density;
-    float t = 0.0f;
-    float rng = c.rng;
-    bool hit = false;
-    float t_hit = 0.0f;
-    for (uint32_t i = 0; i < 128; i += 2) {
-        NRC_PROF(c, 2);
-        const float s1 = random1(rng), a1 = random1(s1), s2 = random1(a1), a2 = random1(s2);
-        const f2 l = logf2(f2{1.0f - s1, 1.0f - s2});
-        const float t1 = nrc_fmaf_(-l.x, inv, t);
-        rng = s1;
-        if (t1 >= t_max) { *volume_exit = true; break; }
-        const float t2 = nrc_fmaf_(-l.y, inv, t1);
-        const bool second = !(t2 >= t_max);
-        const f2 dens = get_density2(c, rd, ro, t1, t2, second) * splat(inv);
-        c.count(1u);
-        rng = a1;
-        if (dens.x > a1) { hit = true; t_hit = t1; break; }
-        rng = s2;
-        if (!second) { *volume_exit = true; break; }
-        c.count(1u);
-        rng = a2;
-        if (dens.y > a2) { hit = true; t_hit = t2; break; }
-        t = t2;
-    }
-    c.rng = rng;
-    if (hit) return madd(rd, t_hit, ro);
-    return madd(rd, c.rand(t_max), ro);
-}
-#endif
 
 // camera ray: mc/render.comp:42-60, nrc/gen_rays.comp:53-72 (no half-pixel offset, no y flip)
 __device__ __forceinline__ void camera_ray(const DevCamera& cam, float u, float v, V3* ro, V3* rd)
@@ -1547,35 +1081,16 @@ __device__ __forceinline__ void count_fetches(unsigned long long* counter, uint3
     if ((threadIdx.x & 63u) == 0) atomicAdd(counter, v);
 }
 
-// The stores of k_gen_rays' frame outputs (primary colour, scatter flag, query: 40 B per pixel = 83 MB per 1080p launch).
-// NRC_OUT_STORES: 0 plain (write-back: what is still dirty in the eight L2s when the kernel ends is written back then, in front of the
-// next launch), 1 write-through (sc0 sc1: the line goes to memory at once and stays in the L2 for the consumers on the same XCD), 2
-// non-temporal.
-#ifndef NRC_OUT_STORES
-#define NRC_OUT_STORES 0
-#endif
+// The stores of k_gen_rays' frame outputs (primary colour, scatter flag, query: 40 B per pixel = 83 MB per 1080p launch) are plain
+// write-back stores; write-through (sc0 sc1) and non-temporal stores were measured and lost (docs/MEASUREMENT_LOG.md).
 typedef float out_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void out_store(float4* p, float4 v)
 {
-#if NRC_OUT_STORES == 1
-    const out_f4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
-#elif NRC_OUT_STORES == 2
-    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
-    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
-#else
     *p = v;
-#endif
 }
 __device__ __forceinline__ void out_store(float* p, float v)
 {
-#if NRC_OUT_STORES == 1
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-#elif NRC_OUT_STORES == 2
-    __builtin_nontemporal_store(v, p);
-#else
     *p = v;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ nrc/gen_rays.comp + prep_infer_rays.comp
@@ -1671,25 +1186,20 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
     // stored NOW, before the walk; a pixel that scatters overwrites it at the end (same lane, same address: the stores are
     // performed in order).  The camera ray direction is therefore dead during the walk; kept live for the end, two of its
     // components were the one value this kernel spilled to scratch (tests/test_abi.py checks that there is none).
-#ifndef NRC_LATE_ENV
     if (inside) {
         const V3 e = sample_env_dir(sc, rd);
         out_store(&primary[(size_t)y * fr.w + lx], make_float4(e.x, e.y, e.z, 1.0f));
     }
-#endif
     V3 light = v3(0, 0, 0);
     V3 cur = entry, dir = rd;      // TracePath recomputes the same entry (gen_rays.comp:11)
     float factor = 1.0f;
     bool did_scatter = false, walking = entered;
-#ifdef NRC_DIAG_LASTDIR
-    // diagnostic build (tests/cpp/stress_main.cpp): RNG state and incoming direction in front of the path's last
-    // new_ray_dir, stored in the w components of the vertex images
-    float dbg_rng_in = 0.0f;
-    V3 dbg_old = v3(0.0f, 0.0f, 0.0f);
-#endif
     for (int i = 0;; i++) {
         if (__ballot(walking) == 0ull) break;
         bool vexit = false;
+#ifdef NRC_DIAG_CUT_TAIL2
+        c.cut2 = i >= 1 ? (uint32_t)(NRC_DIAG_CUT_TAIL2) : 0u;
+#endif
         const V3 nc = delta_track<true>(c, cur, dir, &vexit, walking);
         cur = sel(walking, nc, cur);
         walking &= !vexit;
@@ -1699,18 +1209,7 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
         const V3 ts = trace_scene<true>(c, cur, dir, walking);
         if (walking) {
             light = add(light, mul(ts, factor));
-#ifdef NRC_DIAG_LASTDIR
-            dbg_rng_in = c.rng;
-            dbg_old = dir;
-#endif
-            NRC_BISECT_ON(1);
             dir = new_ray_dir(c, dir, true);
-            NRC_BISECT_OFF(1);
-#ifdef NRC_DIAG_LASTDIR
-            // the direction as it left new_ray_dir goes to memory AT ONCE; the end of the kernel reads it back and compares it with the
-            // registers it is about to store: did the value change in the register file, or was it computed differently?
-            if (inside) origin[(size_t)y * fr.w + lx] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-#endif
             if ((uint32_t)i >= primary_ray_length) {
                 if (c.rand(1.0f) >= primary_ray_prob || i == 128) walking = false;
             }
@@ -1729,28 +1228,14 @@ __global__ __launch_bounds__(64 * CAMERA_WAVES_PER_BLOCK, NRC_GEN_WAVES_PER_SIMD
                 on_grid = (qx * tg.x_dist == lx) & (qy * tg.y_dist == y) & (qx < tg.tw) & (qy < tg.th);
             }
             if (on_grid) {
-#ifdef NRC_DIAG_LASTDIR
-                const float4 early = origin[pix];      // (written right behind the last new_ray_dir, see there)
-                const bool moved = did_scatter && (nrc_f2u(early.x) != nrc_f2u(dir.x) || nrc_f2u(early.y) != nrc_f2u(dir.y) || nrc_f2u(early.z) != nrc_f2u(dir.z));
-                // the incoming direction instead of the vertex -- or, when the registers no longer hold what was computed, that value
-                origin[pix] = moved ? make_float4(early.x, early.y, early.z, dbg_rng_in) : make_float4(dbg_old.x, dbg_old.y, dbg_old.z, dbg_rng_in);
-                dirs[pix] = make_float4(dir.x, dir.y, dir.z, moved ? 1.0f : 0.0f);
-#else
                 origin[pix] = make_float4(cur.x, cur.y, cur.z, 0.0f);
                 dirs[pix] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-#endif
             }
             if (did_scatter) {
                 nrc_query(sc, cur, dir, q);
                 out_store(&primary[pix], make_float4(light.x, light.y, light.z, factor));      // replaces the environment colour stored above
             }
         }
-#ifdef NRC_LATE_ENV
-        if (!(entered && did_scatter)) {
-            const V3 e = sample_env_dir(sc, rd);
-            primary[pix] = make_float4(e.x, e.y, e.z, 1.0f);
-        }
-#endif
         out_store(&info[pix], did_scatter ? 1.0f : 0.0f);
         // the reference zero-fills the query buffer each frame (vkCmdFillBuffer, NrcHpmRenderer.cu:1996) and prep_infer_rays writes only
         // scattered pixels.  Here: no memset; without the live-query list every slot is written (zeros for the others: the list-free
@@ -2038,18 +1523,28 @@ __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, 
 __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, TrainGrid tg, const float4* __restrict__ origin,
                                                    const float4* __restrict__ dirs, const uint32_t* __restrict__ ring,
                                                    const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
-                                                   float* __restrict__ train_target)
+                                                   float* __restrict__ train_target, uint32_t rays_per_wave)
 {
     NRC_RAISE_WAVE_PRIORITY(4);
     __shared__ uint32_t s_occ[kOccMaxWords];
     const uint32_t* occ = load_occupancy(sc, s_occ);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t tx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t T = tg.tw * tg.th;
+    uint32_t tx = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    uint32_t ty = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
     // wave-uniform control flow with per-lane predicates, as in k_gen_rays: lanes beyond the train grid or done with their path stay in
     // the instruction stream and help with the last walks of every tracking loop (ratio_pairs)
-    const bool in_grid = tx < tg.tw && ty < tg.th;
-    const uint32_t T = tg.tw * tg.th;
+    bool in_grid = tx < tg.tw && ty < tg.th;
+    // Long train paths (quirk Q2 fixed: up to TRAIN_RAY_LENGTH = 32 vertices, three walks each): the launch is a few hundred waves whose
+    // duration is the longest of their 64 paths, on a chip with 5 120 wave slots.  rays_per_wave < 64 gives a wave only that many rays (its
+    // first lanes; the others help with the pair tails): the maximum runs over fewer paths, every ratio walk starts on lane pairs, and four
+    // to eight times as many waves share the chip -- the same rays, the same targets, bit for bit (a ray's result does not depend on its lane).
+    if (rays_per_wave < 64u) {
+        const uint32_t i_lin = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * rays_per_wave + lane;
+        in_grid = lane < rays_per_wave && i_lin < T;
+        tx = in_grid ? i_lin % tg.tw : 0u;
+        ty = in_grid ? i_lin / tg.tw : 0u;
+    }
     const uint32_t i = in_grid ? ty * tg.tw + tx : 0u;
     CtxT<false> c{sc, 0.0f, 0u};
     c.occ = occ;
@@ -2442,8 +1937,12 @@ void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& 
     const uint32_t T = tg.tw * tg.th;
     hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(1024), 0, s, fr, tg, info, ring, scratch);
     NRC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_prep_train, pixel_grid(tg.tw, tg.th), dim3(256), 0, s, sc, fr, tg, (const float4*)origin,
-                       (const float4*)dir, (const uint32_t*)ring, (const uint32_t*)scratch, train_in, train_target);
+    // (one 8x8 block of the train grid per wave for the reference's single-vertex targets; 32 rays per wave for long paths: k_prep_train)
+    // (measured on the bench frame with train ray length 32: 64 / 32 / 16 / 8 rays per wave -> 2 309 / 2 412 / 2 367 / 2 347 Msamples/s)
+    const uint32_t rpw = tg.ray_length * tg.spp >= 4u ? 32u : 64u;
+    const dim3 grid = rpw >= 64u ? pixel_grid(tg.tw, tg.th) : dim3(ceil_div(T, 4u * rpw), 1);
+    hipLaunchKernelGGL(k_prep_train, grid, dim3(256), 0, s, sc, fr, tg, (const float4*)origin,
+                       (const float4*)dir, (const uint32_t*)ring, (const uint32_t*)scratch, train_in, train_target, rpw >= 64u ? 64u : rpw);
     NRC_HIP(hipGetLastError());
     launch_last(k_ring_push, dim3(ceil_div(T, 256)), dim3(256), 0u, s, fr, tg, (const float4*)origin,
                 (const float4*)dir, ring, (const uint32_t*)scratch);

@@ -2641,7 +2641,7 @@ Mlp::Mlp(const nrc_config& cfg) : cfg_(cfg)
         NRC_HIP(hipMemset(p, 0, sf.size() * 2));      // k_opt_pack never writes the padding slots
     }
     // inverse maps for the one-launch optimizer step (k_opt_pack): parameter -> its slot in each image
-    fused_opt_ = getenv("NRC_NO_FUSED_OPT") == nullptr;
+    fused_opt_ = !debug_switch("no_fused_opt");
     if (fused_opt_) {
         std::vector<int32_t> dst((size_t)3 * n_mlp_, -1);
         auto invert = [&](const int32_t* src, size_t n_slots, int32_t* out) {
@@ -3012,8 +3012,8 @@ void Mlp::build_wgrad_tasks()
     // ones alone at every width (8x128: 138 -> 64 us per step) and what the 128-wide frame needs (configs[4] 6 850 against 5 750 Msamples/s
     // with round 3's pair); beside gen_rays the 64-wide models run better with round 3's k_wgrad / k_train_gen -- fewer, lighter workgroups
     // (default preset + 0.7 %, HashGrid + 3.2 %, TriangleWave 64 + 2.5 %, A/B on one box).  The renderer's frame is what the library is
-    // for: round 3's kernels up to 64 neurons, round 4's for 128.  NRC_WGRAD_OLD / NRC_TRAIN_GEN_OLD = 0 | 1 override.
-    wgrad_old_ = getenv("NRC_WGRAD_OLD") ? atoi(getenv("NRC_WGRAD_OLD")) != 0 : kw_ <= 64;
+    // for: round 3's kernels up to 64 neurons, round 4's for 128.  NRC_DEBUG=wgrad_old / NRC_DEBUG=train_gen_old = 0 | 1 override.
+    wgrad_old_ = debug_value("wgrad_old", kw_ <= 64 ? 1 : 0) != 0;
     std::vector<WgradTask> tasks;
     const uint32_t D = depth_;
     for (uint32_t l = 0; l <= D; l++) {
@@ -3081,7 +3081,7 @@ void Mlp::ensure_train_workspace(uint32_t n)
         if (d_grid_counters_) dev_free(d_grid_counters_);
         d_grid_counters_ = nullptr;
         grid_bins_total_ = 0;
-        const bool no_bins = getenv("NRC_GRID_NO_BINS") != nullptr;      // tests: every pair through the fixed-point shadow
+        const bool no_bins = debug_switch("grid_no_bins");      // tests: every pair through the fixed-point shadow
         std::vector<uint32_t> info;      // uint4 per bin: {first entry, pair offset of the list, capacity, 0}
         size_t pairs = 0;
         for (uint32_t l = 0; l < HG_LEVELS; l++) {
@@ -3209,11 +3209,11 @@ void Mlp::backward(const float* d_in, const float* d_target, uint32_t n, uint32_
             attr_train_set_ = true;
         }
         const uint4 *fw = (const uint4*)d_pk_fwd_, *bw = (const uint4*)d_pk_bwd_;
-        // round 4: rows split over the waves (k_train_gen2); NRC_TRAIN_GEN_OLD=0|1 picks k_train_gen2 / k_train_gen, NRC_TRAIN_GEN_NT=1|2 sets the tiles
+        // round 4: rows split over the waves (k_train_gen2); NRC_DEBUG=train_gen_old=0|1 picks k_train_gen2 / k_train_gen, NRC_DEBUG=train_gen_nt|2 sets the tiles
         // per sample group
         // (the environment is read per call: a test compares the kernels inside one process)
-        const bool gen_old = getenv("NRC_TRAIN_GEN_OLD") ? atoi(getenv("NRC_TRAIN_GEN_OLD")) != 0 : kw_ <= 64;      // (see build_wgrad_tasks)
-        const int gen_nt_env = getenv("NRC_TRAIN_GEN_NT") ? atoi(getenv("NRC_TRAIN_GEN_NT")) : 0;
+        const bool gen_old = debug_value("train_gen_old", kw_ <= 64 ? 1 : 0) != 0;      // (see build_wgrad_tasks)
+        const int gen_nt_env = (int)debug_value("train_gen_nt", 0);
         if (!gen_old) {
             const uint32_t sgn = 4u / (uint32_t)mtg;                 // sample groups per workgroup
             // (a 16 384-ray batch of an 8x128 net, stand-alone: 29.5 us with one tile per sample group, 39.8 with two; two halve the weight

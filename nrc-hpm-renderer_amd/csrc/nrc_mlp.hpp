@@ -60,7 +60,7 @@ public:
     void grad_vector_is_source() { grid16_valid_ = false; }
     // EMA{Adam} step + re-pack of the fp16 MFMA fragment images.  loss_cell (host-mapped, may be null): where the step's
     // {loss, loss_seq} pair is published; returns true when the step's own launch did that (k_opt_pack), false when the caller
-    // still has to (models with a trainable encoding, NRC_NO_FUSED_OPT=1)
+    // still has to (models with a trainable encoding, NRC_DEBUG=no_fused_opt)
     bool optimizer_step(hipStream_t s, uint32_t loss_seq = 0, unsigned long long* loss_cell = nullptr);
     void repack(hipStream_t s);
 
@@ -148,7 +148,7 @@ private:
     int n_wgrad_tiles_ = 0;
     void* d_tasks_ = nullptr;    // WgradTask[] (row-block tasks of k_wgrad2)
     int n_wgrad_tasks_ = 0;
-    bool wgrad_old_ = false;     // round 3's k_wgrad (up to 64 neurons; NRC_WGRAD_OLD=0|1)
+    bool wgrad_old_ = false;     // round 3's k_wgrad (up to 64 neurons; NRC_DEBUG=wgrad_old=0|1)
     void build_wgrad_tasks();
     uint32_t wgrad_chunk(uint32_t n);
 };

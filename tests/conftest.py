@@ -60,3 +60,13 @@ def torch_gpu():
 
 
 FRAME_RANDOM = [0.25, 0.5, 0.75, 1.0]
+
+
+def nrc_debug(monkeypatch, **switches):
+    """NRC_DEBUG="name[=value],..." (csrc/nrc_common.hpp: the library's one environment switch, read when a cache / renderer is created):
+    nrc_debug(monkeypatch, single_stream=True, wgrad_old=0); no arguments (or only False / None values) = unset"""
+    parts = [k if v is True else "%s=%d" % (k, int(v)) for k, v in switches.items() if v is not None and v is not False]
+    if parts:
+        monkeypatch.setenv("NRC_DEBUG", ",".join(parts))
+    else:
+        monkeypatch.delenv("NRC_DEBUG", raising=False)

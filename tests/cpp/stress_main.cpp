@@ -11,7 +11,7 @@
 //
 //   stress_main <mode: tiles|pipe|both> <iters> <perturb: 0|1|2> [width height frames]
 // Linked against libnrc_hpm.so (rpath); tools/stress.sh runs it >= 100 times in fresh processes under the environment variants
-// NRC_POISON_ALLOC=1, NRC_GUARD_ALLOC=1, GPU_MAX_HW_QUEUES=2/4/8 and against the diagnostic -DNRC_DIAG_LOWPRIO=8 build (camera kernels at wave priority 0 beside raised neighbours).
+// NRC_DEBUG=poison_alloc,guard_alloc, GPU_MAX_HW_QUEUES=2/4/8 and against the diagnostic -DNRC_DIAG_LOWPRIO=8 build (camera kernels at wave priority 0 beside raised neighbours).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -426,9 +426,12 @@ int main(int argc, char** argv)
                 const uint32_t W = 1920, H = 1080;
                 nrc_config c2 = cfg;
                 c2.log2_train_batch_size = 14;
-                setenv("NRC_SINGLE_STREAM", "1", 1);
+                // NRC_DEBUG is a list (csrc/nrc_common.hpp): single_stream is added to what the caller set (poison_alloc, guard_alloc) and removed again
+                const char* dbg0 = getenv("NRC_DEBUG");
+                const std::string dbg = dbg0 ? dbg0 : "";
+                setenv("NRC_DEBUG", (dbg.empty() ? std::string("single_stream") : dbg + ",single_stream").c_str(), 1);
                 Snapshot base = render(su, c2, W, H, W, nullptr, true, true);
-                unsetenv("NRC_SINGLE_STREAM");
+                if (dbg.empty()) unsetenv("NRC_DEBUG"); else setenv("NRC_DEBUG", dbg.c_str(), 1);
                 for (int rep = 0; rep < 3; rep++) {
                     Snapshot p = render(su, c2, W, H, W, nullptr, true, true);
                     size_t first = 0;

@@ -134,7 +134,7 @@ def test_xcd_aware_mappings_are_placement_only(api, sc, torch_gpu, monkeypatch):
         return img, w
 
     img8, w8 = run()
-    monkeypatch.setenv("NRC_ASSUME_XCDS", "4")
+    monkeypatch.setenv("NRC_DEBUG", "assume_xcds=4")
     img4, w4 = run()
     # (HashGrid training is bitwise repeatable since round 5 -- the table gradient's sums are exact --, so the comparison is strict)
     assert np.array_equal(w8, w4)

@@ -438,15 +438,13 @@ def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu
 def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_gpu, model, monkeypatch):
     """the four-stream frame graph (train rays, training and inference of frame N beside gen_rays of frame N+1; triple-buffered
     gen_rays outputs, double-buffered train rays and inference weights) is pure scheduling: after 8 trained, blended frames the
-    framebuffer, the loss and every parameter equal the single-stream order (NRC_SINGLE_STREAM=1) bit for bit"""
+    framebuffer, the loss and every parameter equal the single-stream order (NRC_DEBUG=single_stream) bit for bit"""
     W, H = 256, 160
     scene = sc.make_scene(cloud16, scene_id=4)
     frs = sc.frame_randoms(8, seed=21)
     results = []
-    for mode in ("NRC_SINGLE_STREAM", None, None, None, None):     # the full graph several times: races are rare
-        monkeypatch.delenv("NRC_SINGLE_STREAM", raising=False)
-        if mode:
-            monkeypatch.setenv(mode, "1")
+    for mode in ("single_stream", None, None, None, None):     # the full graph several times: races are rare
+        nrc_debug(monkeypatch, single_stream=mode is not None)
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
                                         train_batch_count=model[4], log2_train_batch_size=10 if model[4] == 1 else 8)
         ren.SetBlend(True)
@@ -469,7 +467,7 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
 def test_no_value_of_the_schedule_changes_a_pixel(api, sc, cloud16, torch_gpu, monkeypatch):
     """nrc_schedule is scheduling only: camera kernels at the default wave priority under the library's other kernels or at the common one,
     two or three frames between a cost sample and the launch order made of it, the XCD-aware finish of that order off / narrow / wide,
-    round 3's or round 4's training kernels (NRC_TRAIN_GEN_OLD / NRC_WGRAD_OLD) -- after 10 trained, blended frames the framebuffer, the loss
+    round 3's or round 4's training kernels (NRC_DEBUG=train_gen_old / wgrad_old) -- after 10 trained, blended frames the framebuffer, the loss
     and the parameters are the same bit for bit whichever way they are set (the weight-gradient kernels differ in their chunk sums: not
     toggled here), and a renderer left to itself reports the neutral start values"""
     W, H = 256, 160
@@ -477,14 +475,14 @@ def test_no_value_of_the_schedule_changes_a_pixel(api, sc, cloud16, torch_gpu, m
     frs = sc.frame_randoms(10, seed=33)
     results = []
     for sched, env in ((None, {}), (dict(camera_priority_low=1), {}), (dict(cost_order_lag=3), {}), (dict(xcd_window=0), {}),
-                       (dict(xcd_window=16), {}), (dict(camera_priority_low=1, cost_order_lag=3, xcd_window=16), {}), (None, {"NRC_TRAIN_GEN_OLD": "1"})):
-        monkeypatch.delenv("NRC_TRAIN_GEN_OLD", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+                       (dict(xcd_window=16), {}), (dict(camera_priority_low=1, cost_order_lag=3, xcd_window=16), {}), (None, {"train_gen_old": 1})):
+        nrc_debug(monkeypatch, **env)
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=3, dir_id=0, nn_width=128, nn_depth=3, train_batch_count=1,
                                         log2_train_batch_size=10)
         if sched is None:
-            assert ren.GetSchedule() == dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2, composite_defer=0, tuning_done=False)
+            got = ren.GetSchedule()
+            assert {k: got[k] for k in ("camera_priority_low", "cost_order_lag", "xcd_window", "composite_defer", "tuning_done", "source")} == \
+                dict(camera_priority_low=0, cost_order_lag=2, xcd_window=2, composite_defer=0, tuning_done=False, source="default")
         else:
             ren.SetSchedule(**sched)
             got = ren.GetSchedule()
@@ -496,7 +494,7 @@ def test_no_value_of_the_schedule_changes_a_pixel(api, sc, cloud16, torch_gpu, m
         results.append((ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy()))
         ren.Destroy()
         nrc.Destroy()
-    monkeypatch.delenv("NRC_TRAIN_GEN_OLD", raising=False)
+    nrc_debug(monkeypatch)
     base = results[0]
     assert np.isfinite(base[0]).all() and base[0].max() > 0.0
     for other in results[1:]:
@@ -607,18 +605,13 @@ def test_live_query_list_changes_no_pixel(api, sc, cloud16, torch_gpu, model, mo
     """renderer inference builds its 32-query tiles from the frame's live-query list (k_gen_rays appends the query index of every
     pixel that scattered; k_infer, k_infer_gen, k_encode_hash_list) instead of computing every tile of four pixel rows that holds a
     live query: results are per query, so framebuffer, loss and parameters after 6 trained frames equal the list-free path
-    (NRC_NO_LIVE_LIST=1) bit for bit, and so does the radiance of every scattered pixel of the last frame"""
+    (NRC_DEBUG=no_live_list) bit for bit, and so does the radiance of every scattered pixel of the last frame"""
     W, H = 256, 160
     scene = sc.make_scene(cloud16, scene_id=4)
     frs = sc.frame_randoms(6, seed=29)
     results = []
     for no_list in ("1", None, None, "zero-dead"):      # ("zero-dead": the list, with gen_rays writing the zero queries of unscattered pixels)
-        monkeypatch.delenv("NRC_NO_LIVE_LIST", raising=False)
-        monkeypatch.delenv("NRC_ZERO_DEAD_QUERIES", raising=False)
-        if no_list == "1":
-            monkeypatch.setenv("NRC_NO_LIVE_LIST", no_list)
-        elif no_list == "zero-dead":
-            monkeypatch.setenv("NRC_ZERO_DEAD_QUERIES", "1")
+        nrc_debug(monkeypatch, no_live_list=no_list == "1", zero_dead_queries=no_list == "zero-dead")
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
                                         hashgrid_log2_size=model[4], log2_infer_batch_size=21)      # ONE inference batch: the list is used
         ren.SetBlend(True)
@@ -1009,7 +1002,7 @@ def test_a_tile_listed_twice_in_the_hot_list_is_still_traced_once(api, orc, sc, 
 
 
 def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, torch_gpu, monkeypatch):
-    """nrc/render.comp as the epilogue of the inference launch (NRC_FUSED_COMPOSITE=1; the queries are tile-major inside the
+    """nrc/render.comp as the epilogue of the inference launch (NRC_DEBUG=fused_composite; the queries are tile-major inside the
     renderer) blends the same image, bit for bit, as k_composite behind the launch -- trained, blended frames of a ragged size"""
     W, H = 328, 200
     scene = sc.make_scene(cloud16, scene_id=4, env=sc.procedural_sky(32, 16))
@@ -1018,10 +1011,7 @@ def test_fused_composite_epilogue_equals_the_separate_pass(api, sc, cloud16, tor
     frs = np.asarray(sc.frame_randoms(6, seed=9), np.float32)
     out = {}
     for fused in (True, False):
-        if fused:
-            monkeypatch.setenv("NRC_FUSED_COMPOSITE", "1")
-        else:
-            monkeypatch.delenv("NRC_FUSED_COMPOSITE", raising=False)
+        nrc_debug(monkeypatch, fused_composite=fused)
         nrc = api.NeuralRadianceCache(cfg)
         ren = api.NrcHpmRenderer(W, H, True, cam, cfg, scene, nrc)
         ren.RenderFrames(frs, True)

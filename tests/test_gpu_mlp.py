@@ -6,6 +6,8 @@ weights after a step rel-L2 <= 1e-3.  (fp32 MFMA accumulation order differs from
 import numpy as np
 import pytest
 
+from conftest import nrc_debug
+
 pytestmark = pytest.mark.gpu
 
 
@@ -293,13 +295,13 @@ def test_sharded_backward_sums_to_full_batch(api, torch_gpu):
                          ids=["north-star", "sgd", "8x128", "2x16", "identity-3x32"])
 def test_one_launch_optimizer_equals_the_three_launch_path_bitwise(api, torch_gpu, model, monkeypatch):
     """k_opt_pack (update + scatter into the three fragment images + loss publication in one launch) against k_adam_ema /
-    k_sgd_ema + k_pack (NRC_NO_FUSED_OPT=1, read when the cache is created): gradients, weights, EMA, moments and both
+    k_sgd_ema + k_pack (NRC_DEBUG=no_fused_opt, read when the cache is created): gradients, weights, EMA, moments and both
     inference paths stay identical to the last bit over four training steps"""
-    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    nrc_debug(monkeypatch)
     a = api.NeuralRadianceCache(api.AppConfig(**model))
-    monkeypatch.setenv("NRC_NO_FUSED_OPT", "1")
+    nrc_debug(monkeypatch, no_fused_opt=True)
     b = api.NeuralRadianceCache(api.AppConfig(**model))
-    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    nrc_debug(monkeypatch)
     n = 4096
     x = torch_gpu.from_numpy(queries(n, seed=71, nan_frac=0.0)).cuda()
     t = torch_gpu.rand((n, 3), device="cuda")
@@ -323,17 +325,17 @@ def test_one_launch_optimizer_equals_the_three_launch_path_bitwise(api, torch_gp
 @pytest.mark.parametrize("optimizer", ["Adam", "SGD"])
 def test_hashgrid_one_launch_table_optimizer_equals_the_separate_kernels_bitwise(api, torch_gpu, optimizer, monkeypatch):
     """HashGrid model: k_opt_pack + k_grid_opt (table gradient read from the packed fp16 table, update, fp16 gather copies) against
-    k_grid_grad_f32 + k_adam_ema / k_sgd_ema + k_pack + k_pack_grid (NRC_NO_FUSED_OPT=1).  The packed-fp16 atomics of the table
+    k_grid_grad_f32 + k_adam_ema / k_sgd_ema + k_pack + k_pack_grid (NRC_DEBUG=no_fused_opt).  The packed-fp16 atomics of the table
     gradient sum in a different order in every run, so cache B never runs its own backward: it is handed A's gradient vector
     (which also exercises the path that reads the fp32 vector after an exchange) -- weights, EMA, moments and both inference paths
     (matrix images and table copies) then agree to the last bit, step after step"""
     kw = dict(pos_id=0, hashgrid_log2_size=14, nn_depth=3, optimizer=optimizer)
-    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    nrc_debug(monkeypatch)
     a = api.NeuralRadianceCache(api.AppConfig(**kw))
     a2 = api.NeuralRadianceCache(api.AppConfig(**kw))            # fused too, but fed through the fp32 vector
-    monkeypatch.setenv("NRC_NO_FUSED_OPT", "1")
+    nrc_debug(monkeypatch, no_fused_opt=True)
     b = api.NeuralRadianceCache(api.AppConfig(**kw))
-    monkeypatch.delenv("NRC_NO_FUSED_OPT", raising=False)
+    nrc_debug(monkeypatch)
     n = 2048
     rng = np.random.default_rng(9)
     t = torch_gpu.rand((n, 3), device="cuda")
@@ -564,7 +566,7 @@ def test_generic_models_match_oracle(api, orc, torch_gpu, pos_id, dir_id, width,
                                                        (0, 0, 128, 2), (3, 0, 16, 3)])
 def test_training_kernels_agree(api, torch_gpu, monkeypatch, pos_id, dir_id, width, depth):
     """k_train_gen2 (round 4: every layer's rows split over the waves of a workgroup, operands exchanged through LDS, weight fragments
-    read straight from L2) against k_train_gen (NRC_TRAIN_GEN_OLD=1): each output element is the same sequence of MFMAs, so loss and
+    read straight from L2) against k_train_gen (NRC_DEBUG=train_gen_old=1): each output element is the same sequence of MFMAs, so loss and
     gradient agree bit for bit -- one and two tiles per sample group, full and ragged batches (the last workgroup half empty)"""
     hg = 11 if pos_id == 0 else 0
     rng = np.random.default_rng(13)
@@ -576,13 +578,10 @@ def test_training_kernels_agree(api, torch_gpu, monkeypatch, pos_id, dir_id, wid
         t = torch_gpu.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
         got = {}
         for mode in ("old", "1", "2"):
-            monkeypatch.delenv("NRC_TRAIN_GEN_OLD", raising=False)
-            monkeypatch.delenv("NRC_TRAIN_GEN_NT", raising=False)
             if mode == "old":
-                monkeypatch.setenv("NRC_TRAIN_GEN_OLD", "1")
+                nrc_debug(monkeypatch, train_gen_old=1)
             else:
-                monkeypatch.setenv("NRC_TRAIN_GEN_OLD", "0")      # (unset: k_train_gen up to 64 neurons, k_train_gen2 for 128)
-                monkeypatch.setenv("NRC_TRAIN_GEN_NT", mode)
+                nrc_debug(monkeypatch, train_gen_old=0, train_gen_nt=int(mode))      # (unset: k_train_gen up to 64 neurons, k_train_gen2 for 128)
             c = api.NeuralRadianceCache(api.AppConfig(pos_id=pos_id, dir_id=dir_id, nn_width=width, nn_depth=depth, hashgrid_log2_size=hg))
             c.Backward(x, t)
             got[mode] = (c.GetParams(4).copy(), c.GetLoss())
@@ -607,7 +606,7 @@ def c_mlp_params(width, depth, enc):
 @pytest.mark.parametrize("width,depth,exact", [(64, 6, True), (128, 8, False), (32, 3, False)], ids=["6x64", "8x128", "3x32"])
 def test_weight_gradient_kernels_agree_at_full_batch(api, torch_gpu, monkeypatch, width, depth, exact):
     """k_wgrad2 (round 4: one wave per 32-row block of a layer's delta, up to four accumulators, K-chunks sized for the launch)
-    against round 3's k_wgrad (NRC_WGRAD_OLD=1, 128-sample chunks) on a full 16 384-ray batch and on a ragged one: the same products
+    against round 3's k_wgrad (NRC_DEBUG=wgrad_old=1, 128-sample chunks) on a full 16 384-ray batch and on a ragged one: the same products
     summed over other chunk boundaries -- fp32 rounding apart; for the 6x64 model the chunks are the same and so is every bit"""
     rng = np.random.default_rng(11)
     grads = {}
@@ -615,7 +614,7 @@ def test_weight_gradient_kernels_agree_at_full_batch(api, torch_gpu, monkeypatch
         x = torch_gpu.from_numpy(queries(n, seed=3, nan_frac=0.0)).cuda()
         t = torch_gpu.from_numpy(rng.random((n, 3), dtype=np.float32)).cuda()
         for old in (False, True):
-            monkeypatch.setenv("NRC_WGRAD_OLD", "1" if old else "0")      # (unset: k_wgrad up to 64 neurons, k_wgrad2 for 128)
+            nrc_debug(monkeypatch, wgrad_old=1 if old else 0)      # (unset: k_wgrad up to 64 neurons, k_wgrad2 for 128)
             c = api.NeuralRadianceCache(api.AppConfig(nn_width=width, nn_depth=depth))
             c.Backward(x, t)
             grads[old] = c.GetParams(4).copy()
@@ -718,7 +717,7 @@ def test_hashgrid_model_matches_oracle(api, orc, torch_gpu, dir_id, width, depth
 def test_table_gradient_is_exact_whatever_path_its_pairs_take(api, orc, torch_gpu, monkeypatch, log2):
     """k_grid_scatter + k_grid_gather: the pairs of the levels with at least 8 bins of 4 096 entries go to per-bin lists and are summed in
     LDS, the coarse levels and what overflows a list are added into the table's fixed-point shadow -- every sum in 64-bit fixed point,
-    i.e. EXACT, and rounded to fp16 once.  So the gradient does not depend on which path a pair takes (NRC_GRID_NO_BINS=1: everything
+    i.e. EXACT, and rounded to fp16 once.  So the gradient does not depend on which path a pair takes (NRC_DEBUG=grid_no_bins: everything
     through the shadow) nor on the order of arrival: bit-identical between the two builds of the path and from run to run, on a full
     batch (every list far from full) and on a batch whose samples sit in one corner of the volume (lists overflow into the shadow);
     and it is the oracle's gradient within fp16 rounding."""
@@ -731,10 +730,7 @@ def test_table_gradient_is_exact_whatever_path_its_pairs_take(api, orc, torch_gp
         t = torch_gpu.from_numpy(tq).cuda()
         g = []
         for no_bins in (False, True, False):
-            if no_bins:
-                monkeypatch.setenv("NRC_GRID_NO_BINS", "1")
-            else:
-                monkeypatch.delenv("NRC_GRID_NO_BINS", raising=False)
+            nrc_debug(monkeypatch, grid_no_bins=no_bins)
             c = api.NeuralRadianceCache(api.AppConfig(pos_id=0, dir_id=0, nn_width=64, nn_depth=2, hashgrid_log2_size=log2))
             c.Backward(x, t)
             first = c.GetParams(4).copy()

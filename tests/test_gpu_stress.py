@@ -18,7 +18,7 @@ def test_fresh_processes_with_a_perturbing_kernel_stay_bitwise_identical(torch_g
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
     exe = entry.build_cpp_stress()
-    runs = [("both", "1", {}), ("both", "2", {}), ("tiles", "1", {"NRC_POISON_ALLOC": "1"}), ("pipe", "1", {"NRC_GUARD_ALLOC": "1", "NRC_POISON_ALLOC": "1"}),
+    runs = [("both", "1", {}), ("both", "2", {}), ("tiles", "1", {"NRC_DEBUG": "poison_alloc"}), ("pipe", "1", {"NRC_DEBUG": "guard_alloc,poison_alloc"}),
             ("tiles", "1", {"GPU_MAX_HW_QUEUES": "4"}), ("tiles", "0", {}), ("tiles", "1", {}), ("tiles", "1", {})]
     for mode, perturb, extra in runs:
         env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
@@ -26,5 +26,5 @@ def test_fresh_processes_with_a_perturbing_kernel_stay_bitwise_identical(torch_g
         r = subprocess.run([exe, mode, "1", perturb], capture_output=True, text=True, timeout=200, env=env)
         assert r.returncode == 0, (mode, perturb, extra, r.stdout[-3000:], r.stderr[-1000:])
         assert "0 mismatching comparisons" in r.stdout
-        if "NRC_GUARD_ALLOC" in extra:
+        if "guard_alloc" in extra.get("NRC_DEBUG", ""):
             assert "guard check 0" in r.stdout

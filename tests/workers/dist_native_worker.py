@@ -70,9 +70,9 @@ def main():
     # packed-fp16 atomics sum in a different order every run, so the dense exchange is the reference only up to that noise
     hg = dict(pos_id=0, hashgrid_log2_size=14)
     sparse = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", **hg)
-    os.environ["NRC_DENSE_GRID_EXCHANGE"] = "1"
+    os.environ["NRC_DEBUG"] = "dense_grid_exchange"
     dense = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", **hg)
-    del os.environ["NRC_DENSE_GRID_EXCHANGE"]
+    del os.environ["NRC_DEBUG"]
     sparse16 = run(api, sc, parallel, scene, cam, W, H, rank, world, frames, "native", dtype="f16", **hg)
     res["hashgrid_fp16_finite"] = bool(np.isfinite(sparse16["losses"]).all() and np.isfinite(sparse16["w"]).all())
     res["hashgrid_fp16_weight_rel_diff"] = float(np.linalg.norm(sparse16["w"] - sparse["w"]) / np.linalg.norm(sparse["w"]))

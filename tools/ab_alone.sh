@@ -3,7 +3,7 @@
 TAG=$1; VOL=$2; shift 2
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 for L in "$@"; do
-  NRC_HPM_LIB=$PWD/nrc-hpm-renderer_amd/$L/libnrc_hpm.so NRC_SINGLE_STREAM=1 timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --train 0 --no-cpu-baseline --volume $VOL > $OUT/alone_${L}_$VOL.json 2> $OUT/alone_${L}_$VOL.err || { tail -3 $OUT/alone_${L}_$VOL.err; continue; }
+  NRC_HPM_LIB=$PWD/nrc-hpm-renderer_amd/$L/libnrc_hpm.so NRC_DEBUG=single_stream timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --train 0 --no-cpu-baseline --volume $VOL > $OUT/alone_${L}_$VOL.json 2> $OUT/alone_${L}_$VOL.err || { tail -3 $OUT/alone_${L}_$VOL.err; continue; }
   python3 -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline_integrator']

@@ -11,6 +11,6 @@ for L in "$@"; do
   export NRC_HPM_LIB=$PWD/nrc-hpm-renderer_amd/$L/libnrc_hpm.so
   timeout -k 10 200 python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline > $OUT/bench_$L.json 2> $OUT/bench_$L.err || { tail -5 $OUT/bench_$L.err; exit 1; }
   summ $OUT/bench_$L.json "$L frame"
-  NRC_SINGLE_STREAM=1 timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --train 0 --no-cpu-baseline > $OUT/alone_$L.json 2> $OUT/alone_$L.err || { tail -5 $OUT/alone_$L.err; exit 1; }
+  NRC_DEBUG=single_stream timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --train 0 --no-cpu-baseline > $OUT/alone_$L.json 2> $OUT/alone_$L.err || { tail -5 $OUT/alone_$L.err; exit 1; }
   summ $OUT/alone_$L.json "$L alone"
 done

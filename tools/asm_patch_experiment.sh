@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): -DNRC_DIAG_LASTDIR / -DNRC_DIAG_BISECT left the product source; this tool builds them from the tree of commit aa01da1 (round 5): git worktree add /tmp/r05 aa01da1
 # Which instruction of the SLP-made packed-FP32 cluster in new_ray_dir's second rotation is it?  
 # Builds the every-process-failing probe library (tools/bisect_build.sh 0) from its DEVICE ASSEMBLY with one edit applied to the cluster
 # of k_gen_rays<false>, through the steps hipcc itself takes (device -S, assemble, lld, clang-offload-bundler, host compile with

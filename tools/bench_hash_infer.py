@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dense inference of the HashGrid model (k_encode_hash_lm + k_infer_gen), event-timed:  python3 tools/bench_hash_infer.py [n] [reps]
-(the level-major mapping is what a device without eight XCDs gets: NRC_ASSUME_XCDS=4)."""
+(the level-major mapping is what a device without eight XCDs gets: NRC_DEBUG=assume_xcds=4)."""
 import os
 import sys
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): -DNRC_DIAG_LASTDIR / -DNRC_DIAG_BISECT left the product source; this tool builds them from the tree of commit aa01da1 (round 5): git worktree add /tmp/r05 aa01da1
 # (the product is compiled with -fno-slp-vectorize since the cause was found: these diagnostic builds switch the vectoriser back ON)
 # builds the probe library + harness with -DNRC_DIAG_BISECT=<mask> (see new_ray_dir in nrc_integrator.hip): tools/bisect_build.sh <mask>...
 cd "$(dirname "$0")/.."

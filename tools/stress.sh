@@ -36,8 +36,8 @@ run_variant() {      # name, binary, perturb, env...
 run_variant first_processes    stress_main      0 GPU_MAX_HW_QUEUES=8
 run_variant spin_wave_per_cu   stress_main      1 GPU_MAX_HW_QUEUES=8
 run_variant spin_lds_workgroup stress_main      2 GPU_MAX_HW_QUEUES=8
-run_variant poison_alloc       stress_main      1 GPU_MAX_HW_QUEUES=8 NRC_POISON_ALLOC=1
-run_variant guard_alloc        stress_main      1 GPU_MAX_HW_QUEUES=8 NRC_GUARD_ALLOC=1 NRC_POISON_ALLOC=1
+run_variant poison_alloc       stress_main      1 GPU_MAX_HW_QUEUES=8 NRC_DEBUG=poison_alloc
+run_variant guard_alloc        stress_main      1 GPU_MAX_HW_QUEUES=8 NRC_DEBUG=guard_alloc,poison_alloc
 run_variant hw_queues_2        stress_main      1 GPU_MAX_HW_QUEUES=2
 run_variant hw_queues_4        stress_main      1 GPU_MAX_HW_QUEUES=4
 run_variant setprio_build      stress_main_prio 1 GPU_MAX_HW_QUEUES=8

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The determinism harness on the shipped build: tools/stress_final.sh [N]   (N fresh processes per arrangement; run on the GPU box)
 #   raised   the product's default: every kernel of the library at s_setprio 3, the perturbing kernel raised too
-#   lowered  NRC_WAVE_PRIORITY_RAISE=0 (what nrc_cache_comm_init selects for world > 1): the library at the default priority UNDER a raised
+#   lowered  NRC_DEBUG=wave_priority_raise=0 (what nrc_cache_comm_init selects for world > 1): the library at the default priority UNDER a raised
 #            perturbing kernel -- the arrangement that failed 1-3 % of the time before the integrator was compiled without the SLP vectoriser
 cd "$(dirname "$0")/.."
 N=${1:-40}; OUT=gpurun_out/stress_final; mkdir -p $OUT; : > $OUT/summary.txt
@@ -9,7 +9,7 @@ EXE=$(python3 -c "import __graft_entry__ as e; print(e.build_cpp_stress())") || 
 for spec in "raised 1" "lowered 0"; do
   set -- $spec; name=$1; val=$2; bad=0; : > $OUT/$name.log
   for i in $(seq 1 $N); do
-    NRC_WAVE_PRIORITY_RAISE=$val GPU_MAX_HW_QUEUES=8 timeout -k 5 150 $EXE both 1 1 >> $OUT/$name.log 2>&1; rc=$?
+    NRC_DEBUG=wave_priority_raise=$val GPU_MAX_HW_QUEUES=8 timeout -k 5 150 $EXE both 1 1 >> $OUT/$name.log 2>&1; rc=$?
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$name: time limit -- stopping" | tee -a $OUT/summary.txt; exit 1; fi
     [ $rc -ne 0 ] && bad=$((bad + 1))
     [ $((i % 10)) -eq 0 ] && echo "$name: $bad of $i so far"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): -DNRC_DIAG_LASTDIR / -DNRC_DIAG_BISECT left the product source; this tool builds them from the tree of commit aa01da1 (round 5): git worktree add /tmp/r05 aa01da1
 # the failing arrangement (camera kernels at wave priority 0 beside raised neighbours) with the last-direction probes in
 # (-DNRC_DIAG_LASTDIR -DNRC_DIAG_LOWPRIO=8): for every affected pixel the log says whether the direction the kernel stored at its
 # end is still the one new_ray_dir had produced (written to memory right behind the call) -- i.e. whether the value changed in

@@ -3,7 +3,7 @@
 set -o pipefail
 TAG=$1; shift
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
-export TMPDIR=/tmp NRC_SINGLE_STREAM=1
+export TMPDIR=/tmp NRC_DEBUG=single_stream
 PY=$(readlink -f "$(command -v python3)")
 for L in "$@"; do
   export NRC_HPM_LIB=$REPO/nrc-hpm-renderer_amd/$L/libnrc_hpm.so

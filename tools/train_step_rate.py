@@ -1,5 +1,5 @@
 """Stand-alone rate of the training chain (backward -> optimizer step) on an idle GPU:
-python3 tools/train_step_rate.py [batch] [steps] [nn_width] [nn_depth] [pos_id]      (NRC_NO_FUSED_OPT=1 for the three-launch optimizer)."""
+python3 tools/train_step_rate.py [batch] [steps] [nn_width] [nn_depth] [pos_id]      (NRC_DEBUG=no_fused_opt for the three-launch optimizer)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,4 +24,4 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print("batch %d, %dx%d pos_id %d: %.1f us per training step (fused optimizer: %s), loss %.5f"
-      % (n, depth, width, pos_id, dt * 1e6, os.environ.get("NRC_NO_FUSED_OPT") is None, c.GetLoss()))
+      % (n, depth, width, pos_id, dt * 1e6, "no_fused_opt" not in os.environ.get("NRC_DEBUG", ""), c.GetLoss()))

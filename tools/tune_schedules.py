@@ -40,6 +40,7 @@ def main():
     for name, extra in PRESETS:
         votes, key = [], None
         for _ in range(a.rounds):
+            api.clear_schedule_cache()      # (the previous round's result is in the process-wide table: tune from the defaults again)
             args = bench.parse_args(extra + ["--no-quality", "--no-cpu-baseline"])
             strong = bench.apply_preset(args)
             job = bench.Job(args, strong, 0, 1, False, False)
