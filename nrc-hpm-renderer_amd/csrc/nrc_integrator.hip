@@ -1520,10 +1520,17 @@ __global__ __launch_bounds__(1024) void k_train_scan(DevFrame fr, TrainGrid tg, 
 // ------------------------------------------------------------------------------------------------ nrc/prep_train_rays.comp
 // Phase A (k_prep_train): pop / trace / write train data; pushes are deferred into `pending` so that every pop sees the
 // ring as it was at frame start.  Phase B (k_ring_push): apply pushes in linear order, advance head/tail.
+// MODE 0: the whole of prep_train_rays.comp in one launch (pop / trace / write).  Long train paths (quirk Q2 fixed: up to 32 vertices) make
+// that launch the longest of the frame -- a few hundred latency-bound waves, ~0.8 ms beside the camera kernels -- and its place in the
+// frame graph (behind gen_rays(N), in front of ring_push(N), on ONE stream) makes the frames queue up behind it.  The frame graph then
+// splits it: MODE 1 (k_train_start's work: tiny) takes the rays' start vertices from the images or the ring, writes them to `start`
+// ([T][6] floats) and the training INPUT they determine; MODE 2 traces from `start` and writes the TARGET -- it touches neither the
+// images nor the ring, so frame N's trace can run beside frame N + 1's on another stream.  Same arithmetic, same results, bit for bit.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, TrainGrid tg, const float4* __restrict__ origin,
                                                    const float4* __restrict__ dirs, const uint32_t* __restrict__ ring,
                                                    const uint32_t* __restrict__ scratch, float* __restrict__ train_in,
-                                                   float* __restrict__ train_target, uint32_t rays_per_wave)
+                                                   float* __restrict__ train_target, uint32_t rays_per_wave, float* __restrict__ start)
 {
     NRC_RAISE_WAVE_PRIORITY(4);
     __shared__ uint32_t s_occ[kOccMaxWords];
@@ -1553,17 +1560,38 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     init_random(c, (float)gx * fr.inv_gw, (float)ty * fr.inv_gh, fr.random);
     V3 ro = v3(0, 0, 0);
     V3 rdir = normalize(v3(1.0f, 1.0f, 1.0f));
-    const bool scat = in_grid && scratch[i] != 0u;
-    if (scat) {
-        const size_t p = (size_t)(ty * tg.y_dist) * fr.w + tx * tg.x_dist;
-        const float4 o = origin[p], d = dirs[p];
-        ro = v3(o.x, o.y, o.z);
-        rdir = v3(d.x, d.y, d.z);
-    } else if (in_grid && tg.ring_size > 0) {
-        const uint32_t tail = scratch[2 * T + 3];
-        const float* r = reinterpret_cast<const float*>(ring + 2) + 6 * (size_t)((tail + scratch[T + i]) % tg.ring_size);
-        ro = v3(r[0], r[1], r[2]);
-        rdir = v3(r[3], r[4], r[5]);
+    if constexpr (MODE == 2) {
+        if (in_grid) {
+            const float* r = start + 6 * (size_t)i;
+            ro = v3(r[0], r[1], r[2]);
+            rdir = v3(r[3], r[4], r[5]);
+        }
+    } else {
+        const bool scat = in_grid && scratch[i] != 0u;
+        if (scat) {
+            const size_t p = (size_t)(ty * tg.y_dist) * fr.w + tx * tg.x_dist;
+            const float4 o = origin[p], d = dirs[p];
+            ro = v3(o.x, o.y, o.z);
+            rdir = v3(d.x, d.y, d.z);
+        } else if (in_grid && tg.ring_size > 0) {
+            const uint32_t tail = scratch[2 * T + 3];
+            const float* r = reinterpret_cast<const float*>(ring + 2) + 6 * (size_t)((tail + scratch[T + i]) % tg.ring_size);
+            ro = v3(r[0], r[1], r[2]);
+            rdir = v3(r[3], r[4], r[5]);
+        }
+    }
+    if constexpr (MODE == 1) {      // the start vertices and the input they determine; the trace is another launch's
+        if (in_grid) {
+            float* r = start + 6 * (size_t)i;
+            r[0] = ro.x; r[1] = ro.y; r[2] = ro.z; r[3] = rdir.x; r[4] = rdir.y; r[5] = rdir.z;
+            if (tg.ring_size > 0) {
+                float q[5];
+                nrc_query(sc, ro, rdir, q);
+#pragma unroll
+                for (int k = 0; k < 5; k++) train_in[5 * (size_t)i + k] = q[k];
+            }
+        }
+        return;
     }
     V3 target = v3(0, 0, 0);
     for (uint32_t s = 0; s < tg.spp; s++) {
@@ -1592,10 +1620,12 @@ __global__ __launch_bounds__(256) void k_prep_train(DevScene sc, DevFrame fr, Tr
     const float fs = (float)tg.spp;
     target = v3(target.x / fs, target.y / fs, target.z / fs);
     if (in_grid && tg.ring_size > 0) {
-        float q[5];
-        nrc_query(sc, ro, rdir, q);
+        if constexpr (MODE == 0) {
+            float q[5];
+            nrc_query(sc, ro, rdir, q);
 #pragma unroll
-        for (int k = 0; k < 5; k++) train_in[5 * (size_t)i + k] = q[k];
+            for (int k = 0; k < 5; k++) train_in[5 * (size_t)i + k] = q[k];
+        }
         train_target[3 * (size_t)i + 0] = fminf(8.0f, target.x);
         train_target[3 * (size_t)i + 1] = fminf(8.0f, target.y);
         train_target[3 * (size_t)i + 2] = fminf(8.0f, target.z);
@@ -1932,20 +1962,36 @@ void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& 
 
 void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& tg, const float* info, const float* origin,
                        const float* dir, uint32_t* ring, uint32_t* scratch, float* train_in, float* train_target,
-                       hipStream_t s)
+                       hipStream_t s, float* start)
 {
     const uint32_t T = tg.tw * tg.th;
     hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(1024), 0, s, fr, tg, info, ring, scratch);
     NRC_HIP(hipGetLastError());
     // (one 8x8 block of the train grid per wave for the reference's single-vertex targets; 32 rays per wave for long paths: k_prep_train)
     // (measured on the bench frame with train ray length 32: 64 / 32 / 16 / 8 rays per wave -> 2 309 / 2 412 / 2 367 / 2 347 Msamples/s)
-    const uint32_t rpw = tg.ray_length * tg.spp >= 4u ? 32u : 64u;
+    const uint32_t rpw = train_paths_are_long(tg) ? 32u : 64u;
     const dim3 grid = rpw >= 64u ? pixel_grid(tg.tw, tg.th) : dim3(ceil_div(T, 4u * rpw), 1);
-    hipLaunchKernelGGL(k_prep_train, grid, dim3(256), 0, s, sc, fr, tg, (const float4*)origin,
-                       (const float4*)dir, (const uint32_t*)ring, (const uint32_t*)scratch, train_in, train_target, rpw >= 64u ? 64u : rpw);
+    if (start == nullptr)
+        hipLaunchKernelGGL(k_prep_train<0>, grid, dim3(256), 0, s, sc, fr, tg, (const float4*)origin, (const float4*)dir, (const uint32_t*)ring,
+                           (const uint32_t*)scratch, train_in, train_target, rpw, (float*)nullptr);
+    else      // the split frame graph: start vertices + inputs here, the trace by launch_train_trace on a stream of its own
+        hipLaunchKernelGGL(k_prep_train<1>, pixel_grid(tg.tw, tg.th), dim3(256), 0, s, sc, fr, tg, (const float4*)origin, (const float4*)dir,
+                           (const uint32_t*)ring, (const uint32_t*)scratch, train_in, train_target, 64u, start);
     NRC_HIP(hipGetLastError());
     launch_last(k_ring_push, dim3(ceil_div(T, 256)), dim3(256), 0u, s, fr, tg, (const float4*)origin,
                 (const float4*)dir, ring, (const uint32_t*)scratch);
+    NRC_HIP(hipGetLastError());
+}
+
+bool train_paths_are_long(const TrainGrid& tg) { return tg.ray_length * tg.spp >= 4u; }
+
+// the trace of the split frame graph (k_prep_train<2>): from the start vertices launch_prep_train(..., start) left, to the training targets
+void launch_train_trace(const DevScene& sc, const DevFrame& fr, const TrainGrid& tg, const float* start, float* train_target, hipStream_t s)
+{
+    const uint32_t T = tg.tw * tg.th;
+    const uint32_t rpw = 32u;
+    launch_last(k_prep_train<2>, dim3(ceil_div(T, 4u * rpw), 1), dim3(256), 0u, s, sc, fr, tg, (const float4*)nullptr, (const float4*)nullptr,
+                (const uint32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, train_target, rpw, const_cast<float*>(start));
     NRC_HIP(hipGetLastError());
 }
 

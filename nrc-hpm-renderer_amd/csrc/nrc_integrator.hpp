@@ -128,9 +128,13 @@ void launch_mc_render(const DevScene& sc, const DevCamera& cam, const DevFrame& 
                       float blend_factor, float* out_rgba, float* info, unsigned long long* fetch_counter, hipStream_t s);
 
 // ring: {uint head, uint tail, RayInfo[ring_size]}; scratch: uint32[2*T + 4]
+// start == nullptr: the whole of prep_train_rays.comp (scan, pop / trace / write, ring push).  start != nullptr (long train paths, the split
+// frame graph): scan, the rays' start vertices -> start ([T][6] floats) + the training inputs, ring push; launch_train_trace does the rest
 void launch_prep_train(const DevScene& sc, const DevFrame& fr, const TrainGrid& tg, const float* info,
                        const float* origin, const float* dir, uint32_t* ring, uint32_t* scratch, float* train_in,
-                       float* train_target, hipStream_t s);
+                       float* train_target, hipStream_t s, float* start = nullptr);
+void launch_train_trace(const DevScene& sc, const DevFrame& fr, const TrainGrid& tg, const float* start, float* train_target, hipStream_t s);
+bool train_paths_are_long(const TrainGrid& tg);      // train ray length x spp >= 4 (quirk Q2 fixed, or a reference build with longer paths)
 
 void integrator_set_wave_priority_raise(int on);      // nrc_common.hpp: NRC_RAISE_WAVE_PRIORITY's run-time switch, this file's kernels
 void launch_composite(const DevFrame& fr, uint32_t show_nrc, float blend_factor, const float* primary,

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FRAME_RANDOM, GOLDEN
+from conftest import FRAME_RANDOM, GOLDEN, nrc_debug
 
 pytestmark = pytest.mark.gpu
 
@@ -434,11 +434,16 @@ def test_full_nrc_frame_matches_oracle_pipeline(api, orc, sc, cloud16, torch_gpu
     nrc.Destroy()
 
 
-@pytest.mark.parametrize("model", [(3, 0, 64, 6, 1), (2, 2, 64, 3, 1), (3, 0, 64, 6, 4)], ids=["fused", "generic", "fused-4-train-batches"])
+@pytest.mark.parametrize("model", [(3, 0, 64, 6, 1), (2, 2, 64, 3, 1), (3, 0, 64, 6, 4), (3, 0, 64, 6, 1, 2), (2, 2, 64, 3, 2, 3)],
+                         ids=["fused", "generic", "fused-4-train-batches", "q2-fixed-long-train-paths", "generic-q1q2-fixed"])
 def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_gpu, model, monkeypatch):
     """the four-stream frame graph (train rays, training and inference of frame N beside gen_rays of frame N+1; triple-buffered
     gen_rays outputs, double-buffered train rays and inference weights) is pure scheduling: after 8 trained, blended frames the
-    framebuffer, the loss and every parameter equal the single-stream order (NRC_DEBUG=single_stream) bit for bit"""
+    framebuffer, the loss and every parameter equal the single-stream order (NRC_DEBUG=single_stream) bit for bit.  With quirk Q2 fixed
+    (train paths of up to 32 vertices) the graph has six streams: the train rays' start vertices and the ring on D, the TRACES of even and
+    odd frames on two streams of their own, overlapping each other (k_prep_train<1> / <2>) -- against the one-launch kernel of the
+    single-stream order"""
+    fix = dict(compat_fix=model[5], train_ray_length=32, train_spp=1) if len(model) > 5 else {}
     W, H = 256, 160
     scene = sc.make_scene(cloud16, scene_id=4)
     frs = sc.frame_randoms(8, seed=21)
@@ -446,13 +451,14 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
     for mode in ("single_stream", None, None, None, None):     # the full graph several times: races are rare
         nrc_debug(monkeypatch, single_stream=mode is not None)
         cfg, nrc, cam, ren = _nrc_setup(api, sc, scene, W, H, pos_id=model[0], dir_id=model[1], nn_width=model[2], nn_depth=model[3],
-                                        train_batch_count=model[4], log2_train_batch_size=10 if model[4] == 1 else 8)
+                                        train_batch_count=model[4], log2_train_batch_size=10 if model[4] == 1 else 8, **fix)
         ren.SetBlend(True)
         for f in range(8):
             ren.SetFrameRandom(frs[f])
-            ren.Render(None, True)        # no host synchronisation between frames
+            ren.Render(None, f != 5)      # no host synchronisation between frames (one frame without training: the graph's other branch)
         results.append((ren.GetImage().cpu().numpy().copy(), nrc.GetLoss(), nrc.GetParams(0).copy(), nrc.GetParams(1).copy(),
-                        ren.Buffer("train_input").cpu().numpy().copy()))
+                        ren.Buffer("train_input").cpu().numpy().copy(), ren.Buffer("train_target").cpu().numpy().copy(),
+                        ren.Buffer("ring").cpu().numpy().copy()))
         ren.Destroy()
         nrc.Destroy()
     base = results[0]
@@ -462,6 +468,7 @@ def test_pipelined_streams_equal_single_stream_bitwise(api, sc, cloud16, torch_g
         assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32))
         assert np.array_equal(base[3].view(np.uint32), other[3].view(np.uint32))
         assert np.array_equal(base[4].view(np.uint32), other[4].view(np.uint32))
+        assert np.array_equal(base[5].view(np.uint32), other[5].view(np.uint32)) and np.array_equal(base[6].view(np.uint32), other[6].view(np.uint32))
 
 
 def test_no_value_of_the_schedule_changes_a_pixel(api, sc, cloud16, torch_gpu, monkeypatch):

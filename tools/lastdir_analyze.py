@@ -1,5 +1,5 @@
-# NOTE (round 6): -DNRC_DIAG_LASTDIR / -DNRC_DIAG_BISECT left the product source; this tool builds them from the tree of commit aa01da1 (round 5): git worktree add /tmp/r05 aa01da1
 #!/usr/bin/env python3
+# NOTE (round 6): -DNRC_DIAG_LASTDIR / -DNRC_DIAG_BISECT left the product source; this tool builds them from the tree of commit aa01da1 (round 5): git worktree add /tmp/r05 aa01da1
 """Offline analysis of the k_gen_rays glitch samples of tests/cpp/stress_main.cpp (-DNRC_DIAG_LASTDIR build): for every affected
 pixel the log holds the RNG state and the incoming direction in front of the path's last new_ray_dir, the direction the glitching
 wave produced and the direction the other rendering produced.  This script restates new_ray_dir (dir_gen.glsl:22-64 as
