@@ -415,6 +415,10 @@ public:
     // the reads of the image enqueued on consumerStream end here: the next frame's compositing waits for them
     void ReleaseImage(void* consumerStream) { nrc_check(nrc_renderer_release_frame(h_, consumerStream)); }
     bool IsBlending() const { return nrc_renderer_is_blending(h_) != 0; }
+    // where the schedule in use came from ("default" | "cache" | "tuner" | "pinned" | "pinned in part") and the key it is remembered under
+    // (include/nrc_hpm.h, nrc_schedule_cache_load / _save)
+    std::string GetScheduleSource() const { return nrc_renderer_schedule_source(h_); }
+    std::string GetScheduleKey() const { return nrc_renderer_schedule_key(h_); }
     float GetFrameTimeMS() const { return nrc_renderer_frame_time_ms(h_, nullptr); }
     const float* GetStageTimesMS() const { return stage_ms_; }
     // the timestamp queries of every frame since the last statistics reset as a timeline: [frames][6] ms from the first frame's start

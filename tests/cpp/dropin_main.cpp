@@ -60,12 +60,34 @@ int main(int argc, char** argv)
         int commRank = -1, commWorld = -1;
         nrc.CommInfo(&commRank, &commWorld);
         if (commRank != 0 || commWorld != 1 || nrc.CommSparse()) throw std::runtime_error("CommInfo after CommInit(id, 0, 1)");
+        // round 6: what the exchange carries (fp32 is the default and what this program keeps: its frames are compared bit for bit)
+        nrc.SetExchangeDtype(NRC_EXCHANGE_F16);
+        if (nrc.GetExchangeDtype() != NRC_EXCHANGE_F16) throw std::runtime_error("SetExchangeDtype(NRC_EXCHANGE_F16)");
+        nrc.SetExchangeDtype(NRC_EXCHANGE_F32);
+        if (nrc.GetExchangeDtype() != NRC_EXCHANGE_F32) throw std::runtime_error("SetExchangeDtype(NRC_EXCHANGE_F32)");
         en::HpmScene hpmScene(appConfig, density.data(), nx, ny, nz, env, 1, 1);          // src/main.cu:177
         const float aspectRatio = static_cast<float>(W) / static_cast<float>(H);
         en::Camera camera(en::vec3(64.0f, 0.0f, 0.0f), en::vec3(-1.0f, 0.0f, 0.0f), en::vec3(0.0f, 1.0f, 0.0f), aspectRatio,
                           en::radians(60.0f), 0.1f, 100.0f);                                // src/main.cu:180-187
         en::NrcHpmRenderer nrcHpmRenderer(W, H, false, &camera, appConfig, hpmScene, nrc);  // src/main.cu:203-210
         if (nrcHpmRenderer.IsBlending()) throw std::runtime_error("IsBlending() after blend = false");
+        // round 6: the schedule cache through the C++ surface -- a table saved, cleared and loaded again holds this renderer's key, and a
+        // second renderer of the same kind then starts on the cached schedule
+        {
+            en::ClearScheduleCache();
+            const std::string key = nrcHpmRenderer.GetScheduleKey(), path = std::string(argv[2]) + ".sched";
+            if (key.empty() || nrcHpmRenderer.GetScheduleSource() != "default") throw std::runtime_error("GetScheduleKey / GetScheduleSource");
+            FILE* sf = std::fopen(path.c_str(), "w");
+            if (!sf) throw std::runtime_error("cannot write the schedule file");
+            std::fprintf(sf, "%s 1 3 16\n", key.c_str());
+            std::fclose(sf);
+            if (en::LoadScheduleCache(path) != 1 || en::SaveScheduleCache(path) != 1) throw std::runtime_error("LoadScheduleCache / SaveScheduleCache");
+            en::NrcHpmRenderer second(W, H, false, &camera, appConfig, hpmScene, nrc);
+            if (second.GetScheduleSource() != "cache") throw std::runtime_error("a renderer whose key is in the table starts on the cached schedule");
+            second.Destroy();
+            en::ClearScheduleCache();
+            std::remove(path.c_str());
+        }
         nrcHpmRenderer.SetBlend(true);
         if (!nrcHpmRenderer.IsBlending()) throw std::runtime_error("IsBlending() after SetBlend(true)");
         float polled = 0.0f;
