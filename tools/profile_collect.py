@@ -73,6 +73,16 @@ def main():
     put(first(src + "/prof_hash/**/*kernel_stats.csv"), "hashgrid_kernel_stats.csv")
     last_json_line(os.path.join(src, "c4_bench.json"), "c4_bench.json")
     put(os.path.join(src, "c4_rank_emulation.txt"), "c4_rank_emulation.txt")
+    # round 6 (tools/r06_collect.sh): the driver's command, the Q2-fixed preset, the convergence curves, the quality calibration, the gradient
+    # attribution, the XCD balance
+    last_json_line(os.path.join(src, "bench_driver_command.json"), "bench_driver_command.json")
+    last_json_line(os.path.join(src, "bench_q2.json"), "bench_q2.json")
+    put(first(src + "/prof_q2/**/*kernel_stats.csv"), "q2_kernel_stats.csv")
+    for sid in (0, 4):
+        put(os.path.join(src, "convergence_%d.txt" % sid), "convergence_%d.txt" % sid)
+    put(os.path.join(src, "quality_calibration.txt"), "quality_calibration.txt")
+    put(os.path.join(src, "grad_drift.txt"), "grad_drift.txt")
+    put(os.path.join(src, "xcd_balance.txt"), "xcd_balance.txt")
     print("profiles/%s_*: %s" % (rnd, ", ".join(copied) if copied else "nothing found under " + src))
 
 
