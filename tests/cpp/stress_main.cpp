@@ -257,7 +257,7 @@ static uint32_t global_col(uint32_t i, uint32_t r, uint32_t world, uint32_t bloc
 
 int main(int argc, char** argv)
 {
-    if (argc < 4) { std::fprintf(stderr, "usage: stress_main <tiles|pipe|both> <iters> <perturb 0|1|2> [width height frames]\n"); return 2; }
+    if (argc < 4) { std::fprintf(stderr, "usage: stress_main <tiles|pipe|pipeq2|both> <iters> <perturb 0|1|2> [width height frames]\n"); return 2; }
     const std::string mode = argv[1];
     const int iters = std::atoi(argv[2]), perturb = std::atoi(argv[3]);
     const uint32_t GW = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 3840, GH = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 2160;
@@ -422,10 +422,13 @@ int main(int argc, char** argv)
                 en::nrc_check(nrc_renderer_destroy(r));
                 en::nrc_check(nrc_cache_destroy(c));
             }
-            if (mode == "pipe" || mode == "both") {
+            // pipeq2 (round 6): the same comparison with quirk Q2 fixed -- 32-vertex train paths, whose traces of four consecutive frames
+            // overlap on streams of their own (k_prep_train<1> / <2>, staging sets) -- against the one-launch kernel of the single-stream order
+            if (mode == "pipe" || mode == "both" || mode == "pipeq2") {
                 const uint32_t W = 1920, H = 1080;
                 nrc_config c2 = cfg;
                 c2.log2_train_batch_size = 14;
+                if (mode == "pipeq2") { c2.compat_fix = NRC_FIX_Q2_TRAIN_RAY_LEN; c2.train_ray_length = 32; }
                 // NRC_DEBUG is a list (csrc/nrc_common.hpp): single_stream is added to what the caller set (poison_alloc, guard_alloc) and removed again
                 const char* dbg0 = getenv("NRC_DEBUG");
                 const std::string dbg = dbg0 ? dbg0 : "";

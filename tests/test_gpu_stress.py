@@ -19,7 +19,8 @@ def test_fresh_processes_with_a_perturbing_kernel_stay_bitwise_identical(torch_g
     import __graft_entry__ as entry
     exe = entry.build_cpp_stress()
     runs = [("both", "1", {}), ("both", "2", {}), ("tiles", "1", {"NRC_DEBUG": "poison_alloc"}), ("pipe", "1", {"NRC_DEBUG": "guard_alloc,poison_alloc"}),
-            ("tiles", "1", {"GPU_MAX_HW_QUEUES": "4"}), ("tiles", "0", {}), ("tiles", "1", {}), ("tiles", "1", {})]
+            ("tiles", "1", {"GPU_MAX_HW_QUEUES": "4"}), ("tiles", "0", {}), ("tiles", "1", {}), ("tiles", "1", {}),
+            ("pipeq2", "1", {}), ("pipeq2", "1", {"GPU_MAX_HW_QUEUES": "4", "NRC_DEBUG": "guard_alloc,poison_alloc"})]
     for mode, perturb, extra in runs:
         env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
         env.update(extra)

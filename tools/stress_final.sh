@@ -6,10 +6,11 @@
 cd "$(dirname "$0")/.."
 N=${1:-40}; OUT=gpurun_out/stress_final; mkdir -p $OUT; : > $OUT/summary.txt
 EXE=$(python3 -c "import __graft_entry__ as e; print(e.build_cpp_stress())") || exit 1
-for spec in "raised 1" "lowered 0"; do
-  set -- $spec; name=$1; val=$2; bad=0; : > $OUT/$name.log
+#   q2       round 6: the long-train-path graph (quirk Q2 fixed: traces of four frames on streams of their own) against the single-stream order
+for spec in "raised 1 both" "lowered 0 both" "q2 1 pipeq2"; do
+  set -- $spec; name=$1; val=$2; what=$3; bad=0; : > $OUT/$name.log
   for i in $(seq 1 $N); do
-    NRC_DEBUG=wave_priority_raise=$val GPU_MAX_HW_QUEUES=8 timeout -k 5 150 $EXE both 1 1 >> $OUT/$name.log 2>&1; rc=$?
+    NRC_DEBUG=wave_priority_raise=$val GPU_MAX_HW_QUEUES=8 timeout -k 5 150 $EXE $what 1 1 >> $OUT/$name.log 2>&1; rc=$?
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$name: time limit -- stopping" | tee -a $OUT/summary.txt; exit 1; fi
     [ $rc -ne 0 ] && bad=$((bad + 1))
     [ $((i % 10)) -eq 0 ] && echo "$name: $bad of $i so far"
