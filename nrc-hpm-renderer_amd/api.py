@@ -436,8 +436,15 @@ class NeuralRadianceCache:
         import torch
 
         def tramp(_user, _g, _n, _l, stream):
-            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+            s = torch.cuda.ExternalStream(int(stream or 0))
+            with torch.cuda.stream(s):
                 fn(g, lo)
+                # What fn enqueued through torch must be COMPLETE when the library launches its next kernel on the stream.  Measured (round 6,
+                # tools/_build/bisect_flaky.sh): an in-place torch kernel launched here on this very stream overlapped the library's next
+                # kernel on it -- 300..4 700 of 25 792 gradient words kept their old value -- in a process that had created a dozen streams
+                # before (tests/test_gpu_frame_graph.py in front of the fp16-exchange test), never in a fresh one; a stream synchronisation
+                # here ends it.  The collective hooks below synchronise for the same reason.  (The library's own RCCL path has no hook.)
+                s.synchronize()
 
         self._hook_keep = GRAD_HOOK(tramp)
         _check(self.L.nrc_cache_set_grad_hook(self.h, self._hook_keep, None))
