@@ -82,8 +82,12 @@ def test_per_frame_loss_poll_does_not_drain_the_pipeline(api, sc, torch_gpu):
         nrc.Destroy()
         return dt, seen, final, t_enqueued
 
+    # (the two loops alternate and each keeps its better time: a 60 ms loop right after an idle millisecond runs at the GPU's ramping
+    # clock -- the comparison is about the poll, not about which loop ran second)
     t_none, _, _, _ = loop("none")
     t_poll, polled, final, t_enq = loop("poll")
+    t_none = min(t_none, loop("none")[0])
+    t_poll = min(t_poll, loop("poll")[0])
     t_block, blocked, _, _ = loop("block")
     assert final[0] == final[1]                                      # drained: both polls agree
     # the poll keeps up with training: while the host was enqueueing, the GPU retired about t_enq / t_poll frames, each with a new
