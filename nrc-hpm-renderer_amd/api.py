@@ -441,9 +441,11 @@ class NeuralRadianceCache:
                 fn(g, lo)
                 # What fn enqueued through torch must be COMPLETE when the library launches its next kernel on the stream.  Measured (round 6,
                 # tools/_build/bisect_flaky.sh): an in-place torch kernel launched here on this very stream overlapped the library's next
-                # kernel on it -- 300..4 700 of 25 792 gradient words kept their old value -- in a process that had created a dozen streams
-                # before (tests/test_gpu_frame_graph.py in front of the fp16-exchange test), never in a fresh one; a stream synchronisation
-                # here ends it.  The collective hooks below synchronise for the same reason.  (The library's own RCCL path has no hook.)
+                # kernel on it -- 300..4 700 of 25 792 gradient words kept their old value -- whenever tests/test_gpu_frame_graph.py had run
+                # in the same process before (3 of 3), never in a fresh process whatever the number of streams or hardware queues
+                # (tools/_build/hook_overlap_probe.py: 0 of 180); round 4 met the same between torch and the NULL stream on a warm GPU.
+                # A stream synchronisation here ends it; the collective hooks below synchronise for the same reason.  (The library's
+                # own RCCL path has no hook, and two of its own kernels on one stream have never been seen out of order: every bitwise test.)
                 s.synchronize()
 
         self._hook_keep = GRAD_HOOK(tramp)
